@@ -1,0 +1,462 @@
+"""ctypes binding of the CPU oracle (oracle/libscann_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  Nothing under scann_rust_amd/ may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libscann_oracle.so")
+
+SQUARED_L2, L2, DOT_PRODUCT = 0, 1, 2
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "scann_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_LIB_PATH)
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "libscann_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+f32p = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+sz = C.c_size_t
+
+
+class TxhIndexC(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32), ("dim", C.c_uint32), ("stride", C.c_uint32),
+        ("data", f32p),
+        ("L", C.c_uint32),
+        ("centers", f32p),
+        ("leaf_off", u32p),
+        ("leaf_ids", u32p),
+        ("S", C.c_uint32), ("K", C.c_uint32), ("dsub", C.c_uint32),
+        ("codebook", f32p),
+        ("codes", u8p),
+        ("use_residuals", C.c_int32),
+        ("partitions_to_search", C.c_uint32),
+        ("pre_reorder_multiplier", C.c_float),
+    ]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.or_squared_l2_avx2.restype = C.c_float
+        L.or_squared_l2_avx2.argtypes = [f32p, f32p, sz]
+        L.or_dot_product_avx2.restype = C.c_float
+        L.or_dot_product_avx2.argtypes = [f32p, f32p, sz]
+        L.or_squared_l2_portable.restype = C.c_float
+        L.or_squared_l2_portable.argtypes = [f32p, f32p, sz]
+        L.or_dot_product_portable.restype = C.c_float
+        L.or_dot_product_portable.argtypes = [f32p, f32p, sz]
+        L.or_squared_l2_sequential.restype = C.c_float
+        L.or_squared_l2_sequential.argtypes = [f32p, f32p, sz]
+        L.or_one_to_many_squared_l2.argtypes = [f32p, sz, f32p, sz, sz, f32p]
+        L.or_one_to_many_dot_product.argtypes = [f32p, sz, f32p, sz, sz, f32p]
+        L.or_compute_stride.restype = sz
+        L.or_compute_stride.argtypes = [sz]
+        for name in ("or_topk_run", "or_fast_top_neighbors_run",
+                     "or_fast_top_neighbors_push_batch"):
+            fn = getattr(L, name)
+            fn.restype = sz
+            fn.argtypes = [sz, u32p, f32p, sz, u32p, f32p]
+        L.or_bf_search.restype = C.c_int
+        L.or_bf_search.argtypes = [f32p, sz, sz, sz, C.c_int, f32p, sz, sz, u32p, f32p]
+        L.or_bf_search_batched.restype = C.c_int
+        L.or_bf_search_batched.argtypes = [f32p, sz, sz, sz, C.c_int, f32p, sz, sz, sz,
+                                           u32p, f32p, u32p, C.c_int]
+        L.or_bf_search_radius.restype = sz
+        L.or_bf_search_radius.argtypes = [f32p, sz, sz, sz, C.c_int, f32p, C.c_float,
+                                          u32p, f32p]
+        L.or_partition.restype = sz
+        L.or_partition.argtypes = [f32p, sz, sz, f32p, sz, u32p, f32p]
+        L.or_encode.argtypes = [f32p, sz, sz, sz, f32p, u8p]
+        L.or_lut_from_query.argtypes = [f32p, sz, sz, sz, f32p, f32p]
+        L.or_lut_distance.restype = C.c_float
+        L.or_lut_distance.argtypes = [f32p, sz, sz, u8p]
+        L.or_pack4_bytes_per_point.restype = sz
+        L.or_pack4_bytes_per_point.argtypes = [sz]
+        L.or_pack4.argtypes = [u8p, sz, sz, u8p]
+        L.or_unpack4.argtypes = [u8p, sz, sz, u8p]
+        L.or_lut16_distance_packed_f32.restype = C.c_float
+        L.or_lut16_distance_packed_f32.argtypes = [f32p, sz, u8p]
+        L.or_lut16_quantize.argtypes = [f32p, sz, u8p, f32p, f32p]
+        L.or_lut16_distances_batch_raw.argtypes = [u8p, u8p, sz, sz, f32p]
+        L.or_lut16_distances_batch.argtypes = [u8p, u8p, sz, sz, C.c_float, C.c_float, f32p]
+        L.or_lut16_distance_single.restype = C.c_float
+        L.or_lut16_distance_single.argtypes = [u8p, sz, C.c_float, C.c_float, u8p]
+        L.or_ah_search.restype = C.c_int
+        L.or_ah_search.argtypes = [f32p, sz, sz, sz, u8p, sz, f32p, sz, sz, u32p, f32p]
+        L.or_ah_search_with_reordering.restype = C.c_int
+        L.or_ah_search_with_reordering.argtypes = [f32p, sz, sz, sz, u8p, sz, f32p, sz,
+                                                   f32p, sz, sz, sz, u32p, f32p]
+        L.or_txh_search.restype = C.c_int
+        L.or_txh_search.argtypes = [C.POINTER(TxhIndexC), f32p, sz, sz, u32p, f32p,
+                                    u32p, f32p, C.POINTER(sz), u32p, f32p, C.POINTER(sz)]
+        L.or_txh_search_batched.restype = C.c_int
+        L.or_txh_search_batched.argtypes = [C.POINTER(TxhIndexC), f32p, sz, sz, sz,
+                                            u32p, f32p, u32p, C.c_int]
+        L.or_reorder.restype = sz
+        L.or_reorder.argtypes = [f32p, sz, sz, f32p, u32p, sz, sz, u32p, f32p]
+        L.or_exact_ground_truth.argtypes = [f32p, sz, sz, sz, f32p, sz, sz, sz, u32p, C.c_int]
+        L.or_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(f32p)
+
+
+def _u32(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a, a.ctypes.data_as(u32p)
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(u8p)
+
+
+def max_threads():
+    return lib().or_max_threads()
+
+
+# ---- L1 kernels ------------------------------------------------------------
+def squared_l2_avx2(a, b):
+    a, pa = _f(a); b, pb = _f(b)
+    return float(np.float32(lib().or_squared_l2_avx2(pa, pb, a.size)))
+
+
+def dot_product_avx2(a, b):
+    a, pa = _f(a); b, pb = _f(b)
+    return float(np.float32(lib().or_dot_product_avx2(pa, pb, a.size)))
+
+
+def squared_l2_portable(a, b):
+    a, pa = _f(a); b, pb = _f(b)
+    return float(np.float32(lib().or_squared_l2_portable(pa, pb, a.size)))
+
+
+def dot_product_portable(a, b):
+    a, pa = _f(a); b, pb = _f(b)
+    return float(np.float32(lib().or_dot_product_portable(pa, pb, a.size)))
+
+
+def squared_l2_sequential(a, b):
+    a, pa = _f(a); b, pb = _f(b)
+    return float(np.float32(lib().or_squared_l2_sequential(pa, pb, a.size)))
+
+
+def one_to_many(q, db, stride, n, measure):
+    q, pq = _f(q); db, pdb = _f(db)
+    out = np.empty(n, np.float32)
+    po = out.ctypes.data_as(f32p)
+    if measure == DOT_PRODUCT:
+        lib().or_one_to_many_dot_product(pq, q.size, pdb, stride, n, po)
+    else:
+        lib().or_one_to_many_squared_l2(pq, q.size, pdb, stride, n, po)
+        if measure == L2:
+            out = np.sqrt(out)
+    return out
+
+
+def compute_stride(dim):
+    return int(lib().or_compute_stride(dim))
+
+
+def to_strided(rows):
+    """DenseDataset::from_vecs layout (data_format/dataset.rs:99-123)."""
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    n, d = rows.shape
+    st = compute_stride(d)
+    out = np.zeros((n, st), np.float32)
+    out[:, :d] = rows
+    return out, st
+
+
+# ---- top-k -------------------------------------------------------------------
+def _run_topk(fn, k, idx, dist):
+    idx, pi = _u32(idx); dist, pd = _f(dist)
+    oi = np.empty(max(k, 1), np.uint32); od = np.empty(max(k, 1), np.float32)
+    r = fn(k, pi, pd, idx.size, oi.ctypes.data_as(u32p), od.ctypes.data_as(f32p))
+    return oi[:r].copy(), od[:r].copy()
+
+
+def topk_run(k, idx, dist):
+    return _run_topk(lib().or_topk_run, k, idx, dist)
+
+
+def fast_top_neighbors_run(k, idx, dist):
+    return _run_topk(lib().or_fast_top_neighbors_run, k, idx, dist)
+
+
+def fast_top_neighbors_push_batch(k, idx, dist):
+    return _run_topk(lib().or_fast_top_neighbors_push_batch, k, idx, dist)
+
+
+# ---- brute force ---------------------------------------------------------------
+def bf_search(data, n, dim, stride, measure, q, k):
+    data, pd = _f(data); q, pq = _f(q)
+    kk = max(min(k, n), 1)
+    oi = np.empty(kk, np.uint32); od = np.empty(kk, np.float32)
+    r = lib().or_bf_search(pd, n, dim, stride, measure, pq, q.size, k,
+                           oi.ctypes.data_as(u32p), od.ctypes.data_as(f32p))
+    if r < 0:
+        raise ValueError("InvalidArgument")
+    return oi[:r].copy(), od[:r].copy()
+
+
+def bf_search_batched(data, n, dim, stride, measure, queries, k, nthreads=0):
+    data, pd = _f(data); queries, pq = _f(queries)
+    nq = queries.shape[0]
+    oi = np.zeros((nq, max(k, 1)), np.uint32); od = np.zeros((nq, max(k, 1)), np.float32)
+    oc = np.zeros(nq, np.uint32)
+    r = lib().or_bf_search_batched(pd, n, dim, stride, measure, pq, nq, queries.shape[1],
+                                   k, oi.ctypes.data_as(u32p), od.ctypes.data_as(f32p),
+                                   oc.ctypes.data_as(u32p), nthreads)
+    if r < 0:
+        raise ValueError("InvalidArgument")
+    return oi[:, :k], od[:, :k], oc
+
+
+def bf_search_radius(data, n, dim, stride, measure, q, radius):
+    data, pd = _f(data); q, pq = _f(q)
+    oi = np.empty(max(n, 1), np.uint32); od = np.empty(max(n, 1), np.float32)
+    r = lib().or_bf_search_radius(pd, n, dim, stride, measure, pq, radius,
+                                  oi.ctypes.data_as(u32p), od.ctypes.data_as(f32p))
+    return oi[:r].copy(), od[:r].copy()
+
+
+# ---- partitioner / codebook / LUT ------------------------------------------------
+def partition(centers, q, num_partitions):
+    centers, pc = _f(centers); q, pq = _f(q)
+    L, d = centers.shape
+    r_max = max(min(num_partitions, L), 1)
+    ot = np.empty(r_max, np.uint32); od = np.empty(r_max, np.float32)
+    r = lib().or_partition(pc, L, d, pq, num_partitions,
+                           ot.ctypes.data_as(u32p), od.ctypes.data_as(f32p))
+    return ot[:r].copy(), od[:r].copy()
+
+
+def encode(codebook, x):
+    codebook, pc = _f(codebook); x, px = _f(x)
+    S, K, dsub = codebook.shape
+    out = np.empty(S, np.uint8)
+    lib().or_encode(pc, S, K, dsub, px, out.ctypes.data_as(u8p))
+    return out
+
+
+def encode_many(codebook, X):
+    codebook, pc = _f(codebook)
+    X = np.ascontiguousarray(X, np.float32)
+    S, K, dsub = codebook.shape
+    out = np.empty((X.shape[0], S), np.uint8)
+    L = lib()
+    for i in range(X.shape[0]):
+        L.or_encode(pc, S, K, dsub, X[i].ctypes.data_as(f32p), out[i].ctypes.data_as(u8p))
+    return out
+
+
+def lut_from_query(codebook, q):
+    codebook, pc = _f(codebook); q, pq = _f(q)
+    S, K, dsub = codebook.shape
+    out = np.empty((S, K), np.float32)
+    lib().or_lut_from_query(pc, S, K, dsub, pq, out.ctypes.data_as(f32p))
+    return out
+
+
+def lut_distance(lut, codes):
+    lut, pl = _f(lut); codes, pc = _u8(codes)
+    S, K = lut.shape
+    return float(np.float32(lib().or_lut_distance(pl, S, K, pc)))
+
+
+# ---- LUT16 ---------------------------------------------------------------------------
+def pack4(codes):
+    codes, pc = _u8(codes)
+    n, S = codes.shape
+    bpp = (S + 1) // 2
+    out = np.empty((n, bpp), np.uint8)
+    lib().or_pack4(pc, n, S, out.ctypes.data_as(u8p))
+    return out
+
+
+def unpack4(packed, S):
+    packed, pp = _u8(packed)
+    n = packed.shape[0]
+    out = np.empty((n, S), np.uint8)
+    lib().or_unpack4(pp, n, S, out.ctypes.data_as(u8p))
+    return out
+
+
+def lut16_distance_packed_f32(tables, packed_row):
+    tables, pt = _f(tables); packed_row, pp = _u8(packed_row)
+    return float(np.float32(lib().or_lut16_distance_packed_f32(pt, tables.shape[0], pp)))
+
+
+def lut16_quantize(tables):
+    tables, pt = _f(tables)
+    S = tables.shape[0]
+    lut8 = np.empty((S, 16), np.uint8)
+    bias = C.c_float(); mult = C.c_float()
+    lib().or_lut16_quantize(pt, S, lut8.ctypes.data_as(u8p), C.byref(bias), C.byref(mult))
+    return lut8, float(bias.value), float(mult.value)
+
+
+def lut16_distances_batch_raw(packed, lut8, S, n):
+    packed, pp = _u8(packed); lut8, pl = _u8(lut8)
+    out = np.empty(n, np.float32)
+    lib().or_lut16_distances_batch_raw(pp, pl, S, n, out.ctypes.data_as(f32p))
+    return out
+
+
+def lut16_distances_batch(packed, lut8, S, n, bias, mult):
+    packed, pp = _u8(packed); lut8, pl = _u8(lut8)
+    out = np.empty(n, np.float32)
+    lib().or_lut16_distances_batch(pp, pl, S, n, bias, mult, out.ctypes.data_as(f32p))
+    return out
+
+
+def lut16_distance_single(lut8, S, bias, mult, codes):
+    lut8, pl = _u8(lut8); codes, pc = _u8(codes)
+    return float(np.float32(lib().or_lut16_distance_single(pl, S, bias, mult, pc)))
+
+
+# ---- AsymmetricHasher -------------------------------------------------------------------
+def ah_search(codebook, codes, q, k):
+    codebook, pcb = _f(codebook); codes, pc = _u8(codes); q, pq = _f(q)
+    S, K, dsub = codebook.shape
+    n = codes.shape[0]
+    oi = np.empty(max(k, 1), np.uint32); od = np.empty(max(k, 1), np.float32)
+    r = lib().or_ah_search(pcb, S, K, dsub, pc, n, pq, q.size, k,
+                           oi.ctypes.data_as(u32p), od.ctypes.data_as(f32p))
+    if r < 0:
+        raise ValueError("InvalidArgument")
+    return oi[:r].copy(), od[:r].copy()
+
+
+def ah_search_with_reordering(codebook, codes, data, stride, q, k, pre_k):
+    codebook, pcb = _f(codebook); codes, pc = _u8(codes); q, pq = _f(q); data, pd = _f(data)
+    S, K, dsub = codebook.shape
+    n = codes.shape[0]
+    kk = max(k, pre_k, 1)
+    oi = np.empty(kk, np.uint32); od = np.empty(kk, np.float32)
+    r = lib().or_ah_search_with_reordering(pcb, S, K, dsub, pc, n, pd, stride, pq, q.size,
+                                           k, pre_k, oi.ctypes.data_as(u32p),
+                                           od.ctypes.data_as(f32p))
+    if r < 0:
+        raise ValueError("InvalidArgument")
+    return oi[:r].copy(), od[:r].copy()
+
+
+# ---- Tree-X-Hybrid --------------------------------------------------------------------------
+class TxhIndex:
+    """Flat Tree-X-Hybrid index (what tree_x_hybrid/mod.rs:131-209 builds)."""
+
+    def __init__(self, data, stride, dim, centers, leaf_off, leaf_ids, codebook, codes,
+                 use_residuals=True, partitions_to_search=10, pre_reorder_multiplier=3.0):
+        self.data = np.ascontiguousarray(data, np.float32)
+        self.centers = np.ascontiguousarray(centers, np.float32)
+        self.leaf_off = np.ascontiguousarray(leaf_off, np.uint32)
+        self.leaf_ids = np.ascontiguousarray(leaf_ids, np.uint32)
+        self.codebook = np.ascontiguousarray(codebook, np.float32)
+        self.codes = np.ascontiguousarray(codes, np.uint8)
+        self.n = int(self.leaf_ids.size)
+        self.dim = int(dim)
+        self.stride = int(stride)
+        self.L = int(self.centers.shape[0])
+        self.S, self.K, self.dsub = (int(x) for x in self.codebook.shape)
+        self.use_residuals = bool(use_residuals)
+        self.partitions_to_search = int(partitions_to_search)
+        self.pre_reorder_multiplier = float(pre_reorder_multiplier)
+
+    def c_struct(self):
+        s = TxhIndexC()
+        s.n, s.dim, s.stride = self.n, self.dim, self.stride
+        s.data = self.data.ctypes.data_as(f32p)
+        s.L = self.L
+        s.centers = self.centers.ctypes.data_as(f32p)
+        s.leaf_off = self.leaf_off.ctypes.data_as(u32p)
+        s.leaf_ids = self.leaf_ids.ctypes.data_as(u32p)
+        s.S, s.K, s.dsub = self.S, self.K, self.dsub
+        s.codebook = self.codebook.ctypes.data_as(f32p)
+        s.codes = self.codes.ctypes.data_as(u8p)
+        s.use_residuals = 1 if self.use_residuals else 0
+        s.partitions_to_search = self.partitions_to_search
+        s.pre_reorder_multiplier = self.pre_reorder_multiplier
+        return s
+
+
+def pre_reorder_k(k, multiplier):
+    """(k as f32 * multiplier) as usize  (tree_x_hybrid/mod.rs:263)."""
+    v = np.float32(k) * np.float32(multiplier)
+    return int(v) if v > 0 else 0
+
+
+def txh_search(ix, q, k, stages=False):
+    q, pq = _f(q)
+    s = ix.c_struct()
+    m = pre_reorder_k(k, ix.pre_reorder_multiplier)
+    P = min(ix.partitions_to_search, ix.L)
+    oi = np.empty(max(k, 1), np.uint32); od = np.empty(max(k, 1), np.float32)
+    tok = np.empty(max(P, 1), np.uint32); tokd = np.empty(max(P, 1), np.float32)
+    ci = np.empty(max(m, 1), np.uint32); cd = np.empty(max(m, 1), np.float32)
+    nt = sz(0); nc = sz(0)
+    r = lib().or_txh_search(C.byref(s), pq, q.size, k, oi.ctypes.data_as(u32p),
+                            od.ctypes.data_as(f32p), tok.ctypes.data_as(u32p),
+                            tokd.ctypes.data_as(f32p), C.byref(nt),
+                            ci.ctypes.data_as(u32p), cd.ctypes.data_as(f32p), C.byref(nc))
+    if r < 0:
+        raise ValueError("InvalidArgument")
+    if stages:
+        return (oi[:r].copy(), od[:r].copy(), tok[:nt.value].copy(), tokd[:nt.value].copy(),
+                ci[:nc.value].copy(), cd[:nc.value].copy())
+    return oi[:r].copy(), od[:r].copy()
+
+
+def txh_search_batched(ix, queries, k, nthreads=0):
+    queries, pq = _f(queries)
+    nq = queries.shape[0]
+    s = ix.c_struct()
+    oi = np.zeros((nq, max(k, 1)), np.uint32); od = np.zeros((nq, max(k, 1)), np.float32)
+    oc = np.zeros(nq, np.uint32)
+    r = lib().or_txh_search_batched(C.byref(s), pq, nq, queries.shape[1], k,
+                                    oi.ctypes.data_as(u32p), od.ctypes.data_as(f32p),
+                                    oc.ctypes.data_as(u32p), nthreads)
+    if r < 0:
+        raise ValueError("InvalidArgument")
+    return oi[:, :k], od[:, :k], oc
+
+
+def reorder(data, stride, dim, q, cand_idx, k):
+    data, pd = _f(data); q, pq = _f(q); cand_idx, pc = _u32(cand_idx)
+    n = cand_idx.size
+    oi = np.empty(max(n, 1), np.uint32); od = np.empty(max(n, 1), np.float32)
+    r = lib().or_reorder(pd, stride, dim, pq, pc, n, k, oi.ctypes.data_as(u32p),
+                         od.ctypes.data_as(f32p))
+    return oi[:r].copy(), od[:r].copy()
+
+
+def exact_ground_truth(train, n, dim, stride, queries, k, nthreads=0):
+    train, pt = _f(train); queries, pq = _f(queries)
+    nq = queries.shape[0]
+    gt = np.zeros((nq, k), np.uint32)
+    lib().or_exact_ground_truth(pt, n, dim, stride, pq, nq, queries.shape[1], k,
+                                gt.ctypes.data_as(u32p), nthreads)
+    return gt
