@@ -1,0 +1,255 @@
+/*
+ * scann_hip.h -- C ABI of libscann_hip.so: the MI355X (gfx950) implementation
+ * of the sunbains/scann-rust Tree-X-Hybrid / brute-force hot path.
+ *
+ * The reference crate has no FFI of its own (pure Rust); the
+ * drop-in boundary is its Rust API.  Each entry point below names the Rust
+ * item(s) whose body it replaces (paths relative to /root/reference/src); the
+ * Rust-side `extern "C"` block a maintainer would add is in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++/torch types.
+ *  - every function returns a scann_hip_status (== ErrorCode discriminant in
+ *    declaration order, error.rs:10-45); scann_hip_last_error() returns the
+ *    thread-local message of the last failure on the calling thread.
+ *  - *_create copies host arrays to the device; the caller keeps ownership of
+ *    its host memory and may free it on return.  Handles own device memory until
+ *    scann_hip_index_destroy.
+ *  - host entry points are synchronous (outputs filled on return).  The *_device
+ *    variants take device pointers + a hipStream_t (passed as void*), enqueue
+ *    only, and never synchronise: inputs already resident in HBM.
+ *  - result rows are ascending by distance; rows shorter than k are reported via
+ *    out_count (the reference returns shorter Vecs: brute_force/searcher.rs:91,
+ *    tree_x_hybrid/mod.rs:360-363).  Unused slots: idx 0xFFFFFFFF, dist +inf.
+ *  - any thread may call search functions concurrently on one handle (Searcher:
+ *    Send + Sync, searcher.rs:148); create/destroy need external synchronisation.
+ */
+#ifndef SCANN_HIP_H
+#define SCANN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error.rs:10-45 (ErrorCode, declaration order) */
+typedef enum {
+    SCANN_HIP_OK = 0,
+    SCANN_HIP_CANCELLED = 1,
+    SCANN_HIP_UNKNOWN = 2,
+    SCANN_HIP_INVALID_ARGUMENT = 3,
+    SCANN_HIP_DEADLINE_EXCEEDED = 4,
+    SCANN_HIP_NOT_FOUND = 5,
+    SCANN_HIP_ALREADY_EXISTS = 6,
+    SCANN_HIP_PERMISSION_DENIED = 7,
+    SCANN_HIP_RESOURCE_EXHAUSTED = 8,
+    SCANN_HIP_FAILED_PRECONDITION = 9,
+    SCANN_HIP_ABORTED = 10,
+    SCANN_HIP_OUT_OF_RANGE = 11,
+    SCANN_HIP_UNIMPLEMENTED = 12,
+    SCANN_HIP_INTERNAL = 13,
+    SCANN_HIP_UNAVAILABLE = 14,
+    SCANN_HIP_DATA_LOSS = 15,
+    SCANN_HIP_UNAUTHENTICATED = 16
+} scann_hip_status;
+
+/* distance_measures/mod.rs:32-66: the measures the hot path dispatches on
+ * (brute_force/searcher.rs:119-138). */
+typedef enum {
+    SCANN_HIP_SQUARED_L2 = 0,
+    SCANN_HIP_L2 = 1,
+    SCANN_HIP_DOT_PRODUCT = 2 /* distance = -dot (simd/x86.rs:247-250) */
+} scann_hip_measure;
+
+typedef struct scann_hip_ctx scann_hip_ctx;     /* one device + stream/workspace pool */
+typedef struct scann_hip_index scann_hip_index; /* one searcher */
+
+/* ---- context ------------------------------------------------------------ */
+int scann_hip_init(int device_id, scann_hip_ctx **out_ctx);
+void scann_hip_shutdown(scann_hip_ctx *ctx);
+const char *scann_hip_last_error(void);
+const char *scann_hip_version(void);
+/* data_format/dataset.rs:90-96 (DenseDataset::compute_stride for f32) */
+uint32_t scann_hip_compute_stride(uint32_t dim);
+
+/* ---- brute force --------------------------------------------------------- */
+/* Replaces BruteForceSearcher::new / with_shared_dataset
+ * (brute_force/searcher.rs:34-54).  data: n rows of `stride` floats, the
+ * DenseDataset::raw_data() buffer (data_format/dataset.rs:176-179, 228-230).
+ * n == 0 is legal (searches return empty rows, searcher.rs:78-80). */
+int scann_hip_bf_create(scann_hip_ctx *ctx, const float *data, uint64_t n, uint32_t dim,
+                        uint32_t stride, int measure, scann_hip_index **out_index);
+
+/* ---- Tree-X-Hybrid / AsymmetricHasher ------------------------------------ */
+/* The trained index TreeXHybridSearcher::build (tree_x_hybrid/mod.rs:131-209)
+ * or AsymmetricHasher::build (hashes/hasher.rs:109-134) produced, flattened:
+ *   centers       [num_partitions][dim]  TreePartitioner.centers (tree_partitioner.rs:29)
+ *   leaf_offsets  [num_partitions+1]     CSR over PartitionData.indices (mod.rs:81-90)
+ *   leaf_ids      [n_local]              datapoint index of CSR row i
+ *   codebook      [S][K][dsub]           Codebook.subspaces[s].centroids (codebook.rs:59-67)
+ *   codes         CSR row order; unpacked [n_local][S] u8 (PartitionData.encoded) or
+ *                 packed 4-bit [n_local][ceil(S/2)] (PackedCodes4Bit, lut16.rs:43-61)
+ *   data          [n_rows][stride] original rows indexed by DATAPOINT index (re-rank,
+ *                 mod.rs:342-364); may be NULL (AsymmetricHasher::build_no_store,
+ *                 hasher.rs:137-159): exact re-ordering then fails FailedPrecondition.
+ * num_partitions == 0 selects AsymmetricHasher mode: one implicit leaf holding all
+ * n points in datapoint order (leaf_offsets / leaf_ids / centers ignored).
+ *
+ * Multi-GPU leaf sharding (one process per GPU): each rank passes only the leaves
+ * it owns (unowned leaves have zero local length) plus leaf_sizes_global, so every
+ * rank derives identical merge keys; data then holds only the local rows in CSR row
+ * order (data_is_csr_order = 1).  leaf_sizes_global == NULL means unsharded. */
+typedef struct {
+    const float *data;
+    uint64_t n_rows;
+    uint32_t dim;
+    uint32_t stride;
+    int32_t data_is_csr_order;
+    const float *centers;
+    uint32_t num_partitions;
+    const uint32_t *leaf_offsets;
+    const uint32_t *leaf_ids;
+    const uint32_t *leaf_sizes_global;
+    uint64_t n_local;
+    const float *codebook;
+    uint32_t num_subspaces;      /* S */
+    uint32_t num_codes;          /* K <= 16 (LUT16) */
+    uint32_t dims_per_subspace;  /* dsub; S * dsub must equal dim (codebook.rs:154-159) */
+    const uint8_t *codes;
+    int32_t codes_packed4;
+    int32_t use_residuals;            /* TreeXHybridConfig.use_residuals (mod.rs:31) */
+    uint32_t partitions_to_search;    /* TreeXHybridConfig.partitions_to_search (mod.rs:27) */
+    float pre_reorder_multiplier;     /* TreeXHybridConfig.pre_reorder_multiplier (mod.rs:33) */
+} scann_hip_txh_desc;
+
+/* Replaces the search side of TreeXHybridSearcher::build / AsymmetricHasher::build.
+ * Errors: n_local == 0 -> InvalidArgument (mod.rs:132-134, hasher.rs:110-112);
+ * dim % S != 0 -> InvalidArgument (codebook.rs:154-159). */
+int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *desc,
+                         scann_hip_index **out_index);
+
+typedef struct {
+    /* 0 = the index default.  SearchParameters.num_leaves_to_search is ignored by
+     * the reference searcher; this knob exists for sweeps. */
+    uint32_t partitions_to_search;
+    /* candidates kept by approximate distance before re-ranking.
+     * 0 = (k as f32 * pre_reorder_multiplier) as usize (mod.rs:263). */
+    uint32_t pre_reorder_k;
+    /* 1 (default for Tree-X-Hybrid; AsymmetricHasher::search_with_reordering,
+     * hasher.rs:188-229): exact SquaredL2 re-rank of the pre_reorder_k candidates.
+     * 0: return the k best by APPROXIMATE distance (AsymmetricHasher::search,
+     * hasher.rs:162-185); pre_reorder_k is then ignored. */
+    int32_t exact_reorder;
+    /* optional per-stage outputs for parity checks (host pointers or NULL):
+     *   tokens/token_dists [nq][P]      TreePartitioner::partition result (tree_partitioner.rs:196-229)
+     *   cand_idx/cand_dist [nq][m], cand_count [nq]   merged candidates before re-rank (mod.rs:283-290) */
+    uint32_t *tokens;
+    float *token_dists;
+    uint32_t *cand_idx;
+    float *cand_dist;
+    uint32_t *cand_count;
+} scann_hip_search_opts;
+
+void scann_hip_search_opts_default(scann_hip_search_opts *opts);
+
+/* ---- search ---------------------------------------------------------------- */
+/* Replaces, per index kind:
+ *   BruteForceSearcher::{search, search_batched}       brute_force/searcher.rs:77-208
+ *   AsymmetricHasher::{search, search_with_reordering, search_batched}  hashes/hasher.rs:162-238
+ *   TreeXHybridSearcher::{search, search_with_filter(None)} + Searcher::search_batched_with_params
+ *                                                       tree_x_hybrid/mod.rs:240-294, 382-409
+ * queries: nq rows, row i at queries + i*q_stride, q_dim valid floats each.
+ * q_dim != index dim -> InvalidArgument (searcher.rs:83-89, hasher.rs:167-171,
+ * mod.rs:251-253).  out_idx/out_dist: [nq][k]; out_count: [nq]. */
+int scann_hip_search_batched(scann_hip_index *index, const float *queries, uint32_t nq,
+                             uint32_t q_stride, uint32_t q_dim, uint32_t k,
+                             const scann_hip_search_opts *opts, uint32_t *out_idx,
+                             float *out_dist, uint32_t *out_count);
+
+/* Same, all pointers device-resident, enqueued on `hip_stream`, no sync.  The caller
+ * must first reserve workspace for the largest batch it will submit. */
+int scann_hip_index_reserve(scann_hip_index *index, uint32_t max_nq, uint32_t max_k,
+                            const scann_hip_search_opts *opts);
+int scann_hip_search_batched_device(scann_hip_index *index, const float *d_queries,
+                                    uint32_t nq, uint32_t q_stride, uint32_t k,
+                                    const scann_hip_search_opts *opts, uint32_t *d_out_idx,
+                                    float *d_out_dist, uint32_t *d_out_count,
+                                    void *hip_stream);
+/* Device status word of the last *_device call on this index (0 = ok, else a
+ * scann_hip_status: candidate-buffer overflow -> ResourceExhausted).  Synchronises
+ * the stream. */
+int scann_hip_index_last_device_status(scann_hip_index *index, void *hip_stream);
+
+/* ---- multi-GPU: leaf-sharded Tree-X-Hybrid ------------------- */
+/* Local stage: this rank's best-m candidates per query by approximate distance, with
+ * their exact distances, as (merge key u64, datapoint idx u32, exact f32) triples
+ * [nq][m] (+ count [nq]).  The merge key orders candidates exactly as the reference's
+ * flatten + stable sort does (mod.rs:283-290) and is identical on every rank. */
+int scann_hip_txh_search_local_device(scann_hip_index *index, const float *d_queries,
+                                      uint32_t nq, uint32_t q_stride, uint32_t k,
+                                      const scann_hip_search_opts *opts, uint64_t *d_keys,
+                                      uint32_t *d_idx, float *d_exact, uint32_t *d_count,
+                                      void *hip_stream);
+/* Merge stage on the gathered triples of `world` ranks ([world][nq][m] each):
+ * stable sort by key -> truncate m -> stable sort by exact -> truncate k
+ * (mod.rs:289-290, 360-361). */
+int scann_hip_txh_merge_device(scann_hip_ctx *ctx, uint32_t world, uint32_t nq, uint32_t m,
+                               uint32_t k, const uint64_t *d_keys, const uint32_t *d_idx,
+                               const float *d_exact, const uint32_t *d_count,
+                               uint32_t *d_out_idx, float *d_out_dist, uint32_t *d_out_count,
+                               void *hip_stream);
+/* Greedy size-balanced leaf->rank assignment used by the harness (not in the reference). */
+int scann_hip_assign_leaves(const uint32_t *leaf_sizes, uint32_t num_partitions,
+                            uint32_t world, uint32_t *out_owner);
+
+/* ---- building blocks exposed for parity tests / callers ---------------------- */
+/* TreePartitioner::partition for a batch (tree_partitioner.rs:196-229). */
+int scann_hip_txh_partition(scann_hip_index *index, const float *queries, uint32_t nq,
+                            uint32_t q_stride, uint32_t q_dim, uint32_t num_partitions,
+                            uint32_t *out_tokens, float *out_dists, uint32_t *out_count);
+/* LookupTable::from_query (hashes/lut.rs:47-70) for nq queries; leaf_for_query NULL =
+ * no residual, else residual against centers[leaf_for_query[i]] (mod.rs:309-316).
+ * out_lut: [nq][S][K]. */
+int scann_hip_lut_from_query(scann_hip_index *index, const float *queries, uint32_t nq,
+                             uint32_t q_stride, const uint32_t *leaf_for_query,
+                             float *out_lut);
+/* LookupTable::compute_distance over every local point (hashes/lut.rs:74-82,
+ * hasher.rs:179-182) for nq explicit f32 LUTs [nq][S][K]: out [nq][n_local] in CSR
+ * row order. */
+int scann_hip_adc_distances(scann_hip_index *index, const float *luts, uint32_t nq,
+                            float *out_dist);
+/* Lut16SimdTables::compute_distances_batch (hashes/lut16_simd.rs:119-141 ->
+ * simd/dispatch.rs:259-295): u8 tables [S][16], packed codes [n][ceil(S/2)];
+ * out[i] = sum_u32 * multiplier + bias * S. */
+int scann_hip_lut16_distances_batch(scann_hip_ctx *ctx, const uint8_t *packed_codes,
+                                    const uint8_t *lut8, uint32_t num_subspaces, uint64_t n,
+                                    float bias, float multiplier, float *out);
+/* Codebook::encode over rows (hashes/codebook.rs:82-95, 205-215); optional residual
+ * against centers[leaf_of_row[i]] (tree_x_hybrid/mod.rs:177-189).  out_codes [n][S]. */
+int scann_hip_encode(scann_hip_ctx *ctx, const float *codebook, uint32_t num_subspaces,
+                     uint32_t num_codes, uint32_t dims_per_subspace, const float *rows,
+                     uint64_t n, uint32_t stride, const float *centers,
+                     const uint32_t *leaf_of_row, uint8_t *out_codes);
+/* one_to_many_{squared_l2,dot_product}_strided for a batch = the dense Q x N matrix of
+ * batch_squared_l2_simd / batch_dot_product_simd (distance_measures/one_to_many.rs:228-373,
+ * many_to_many.rs:301-373).  out [nq][n]. */
+int scann_hip_bf_distances(scann_hip_index *index, const float *queries, uint32_t nq,
+                           uint32_t q_stride, float *out);
+
+/* ---- introspection ------------------------------------------------------------- */
+uint64_t scann_hip_index_size(const scann_hip_index *index);          /* Searcher::dataset_size */
+uint32_t scann_hip_index_dimensionality(const scann_hip_index *index);/* Searcher::dimensionality */
+void scann_hip_index_destroy(scann_hip_index *index);
+
+/* Kernel timing hook for bench.py: HIP-event time (ms) of the dominant kernel of the
+ * last search on `index`, measured on the stream the kernel was launched on
+ * (0 if timing was not enabled). */
+void scann_hip_index_enable_timing(scann_hip_index *index, int enable);
+float scann_hip_index_last_kernel_ms(scann_hip_index *index, const char **out_kernel_name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,798 @@
+// api.hip -- C ABI of libscann_hip.so (include/scann_hip.h): contexts, index handles,
+// workspace management and host orchestration.  No CPU compute fallback exists: every
+// search entry point runs the HIP kernels or fails.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "bf.h"
+#include "common.h"
+#include "txh.h"
+
+namespace scann {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+int fail(int status, const std::string &msg) {
+    g_last_error = msg;
+    return status;
+}
+
+}  // namespace scann
+
+using namespace scann;
+
+struct scann_hip_ctx {
+    int device = 0;
+    int num_cus = 256;
+};
+
+enum IndexKind { KIND_BF = 1, KIND_TXH = 2 };
+
+struct TxhWorkspace {
+    DevBuf queries, cdist, tokens, token_dists, vbase, leaf_cnt, leaf_cursor, pair_off, tile_off,
+        counters, pair_q, pair_leaf, pair_vbase, slot_of, lutq, thr, cand_cnt, cand, cand_key,
+        cand_idx, cand_dist, cand_exact, cand_count, out_idx, out_dist, out_count;
+};
+
+struct scann_hip_index {
+    scann_hip_ctx *ctx = nullptr;
+    int kind = 0;
+    std::mutex mu;  // serialises searches on one handle (callers may be concurrent)
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = false;
+    bool timing_valid = false;
+    const char *timed_kernel = "";
+    DevBuf status_word;
+
+    // ---- brute force ----
+    BfIndexDev bf{};
+    DevBuf bf_rows;
+    BfWorkspace bfw;
+
+    // ---- tree-x-hybrid / AH ----
+    TxhIndexDev tx{};
+    DevBuf d_centers, d_leaf_off, d_leaf_gsize, d_leaf_ids, d_codes, d_rows, d_codebook;
+    std::vector<uint32_t> local_sizes_desc;  // local leaf sizes, descending, prefix-summed
+    uint32_t default_P = 0;
+    float multiplier = 3.0f;
+    TxhWorkspace ws;
+    TxhWork last_work{};
+};
+
+static int set_device(const scann_hip_ctx *ctx) {
+    SCANN_HIP_CHECK(hipSetDevice(ctx->device));
+    return SCANN_HIP_OK;
+}
+
+extern "C" {
+
+const char *scann_hip_last_error(void) { return g_last_error.c_str(); }
+const char *scann_hip_version(void) { return "scann_hip 0.1.0 (gfx950)"; }
+
+uint32_t scann_hip_compute_stride(uint32_t dim) {
+    const uint32_t per_line = 64 / sizeof(float);  // data_format/dataset.rs:90-96
+    return (dim + per_line - 1) / per_line * per_line;
+}
+
+int scann_hip_init(int device_id, scann_hip_ctx **out_ctx) {
+    if (!out_ctx) return fail(SCANN_HIP_INVALID_ARGUMENT, "out_ctx is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(SCANN_HIP_UNAVAILABLE,
+                    "no HIP device available (libscann_hip has no CPU fallback)");
+    if (device_id < 0 || device_id >= n)
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "device_id out of range");
+    SCANN_HIP_CHECK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    SCANN_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(SCANN_HIP_FAILED_PRECONDITION,
+                    std::string("libscann_hip is built for gfx950 only; device is ") +
+                        prop.gcnArchName);
+    auto *c = new scann_hip_ctx();
+    c->device = device_id;
+    c->num_cus = prop.multiProcessorCount;
+    *out_ctx = c;
+    return SCANN_HIP_OK;
+}
+
+void scann_hip_shutdown(scann_hip_ctx *ctx) { delete ctx; }
+
+void scann_hip_search_opts_default(scann_hip_search_opts *o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->exact_reorder = 1;
+}
+
+static int index_common_init(scann_hip_index *ix) {
+    SCANN_HIP_CHECK(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+    SCANN_HIP_CHECK(hipEventCreate(&ix->ev0));
+    SCANN_HIP_CHECK(hipEventCreate(&ix->ev1));
+    return SCANN_HIP_OK;
+}
+
+void scann_hip_index_destroy(scann_hip_index *ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->ctx->device);
+    if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+    if (ix->ev0) (void)hipEventDestroy(ix->ev0);
+    if (ix->ev1) (void)hipEventDestroy(ix->ev1);
+    if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    delete ix;
+}
+
+uint64_t scann_hip_index_size(const scann_hip_index *ix) {
+    if (!ix) return 0;
+    return ix->kind == KIND_BF ? ix->bf.n : ix->tx.n_local;
+}
+uint32_t scann_hip_index_dimensionality(const scann_hip_index *ix) {
+    if (!ix) return 0;
+    return ix->kind == KIND_BF ? ix->bf.dim : ix->tx.dim;
+}
+
+void scann_hip_index_enable_timing(scann_hip_index *ix, int enable) {
+    if (ix) ix->timing = enable != 0;
+}
+
+float scann_hip_index_last_kernel_ms(scann_hip_index *ix, const char **name) {
+    if (name) *name = ix ? ix->timed_kernel : "";
+    if (!ix || !ix->timing_valid) return 0.0f;
+    float ms = 0.0f;
+    if (hipEventSynchronize(ix->ev1) != hipSuccess) return 0.0f;
+    if (hipEventElapsedTime(&ms, ix->ev0, ix->ev1) != hipSuccess) return 0.0f;
+    return ms;
+}
+
+// =====================================================================================
+// Brute force
+// =====================================================================================
+int scann_hip_bf_create(scann_hip_ctx *ctx, const float *data, uint64_t n, uint32_t dim,
+                        uint32_t stride, int measure, scann_hip_index **out) {
+    if (!ctx || !out) return fail(SCANN_HIP_INVALID_ARGUMENT, "null ctx/out_index");
+    if (n > 0 && !data) return fail(SCANN_HIP_INVALID_ARGUMENT, "data is null");
+    if (n > 0 && (dim == 0 || stride < dim))
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "bad dim/stride");
+    if (measure != SCANN_HIP_SQUARED_L2 && measure != SCANN_HIP_L2 &&
+        measure != SCANN_HIP_DOT_PRODUCT)
+        return fail(SCANN_HIP_UNIMPLEMENTED,
+                    "brute force supports SquaredL2, L2 and DotProduct on the GPU path");
+    if (n >= 0xFFFFFFFFull) return fail(SCANN_HIP_OUT_OF_RANGE, "DatapointIndex is u32");
+    SCANN_TRY(set_device(ctx));
+    auto *ix = new scann_hip_index();
+    ix->ctx = ctx;
+    ix->kind = KIND_BF;
+    int s = index_common_init(ix);
+    if (s == SCANN_HIP_OK) s = upload(ix->bf_rows, data, (size_t)n * stride * sizeof(float));
+    if (s != SCANN_HIP_OK) {
+        scann_hip_index_destroy(ix);
+        return s;
+    }
+    ix->bf.rows = ix->bf_rows.as<float>();
+    ix->bf.n = n;
+    ix->bf.dim = dim;
+    ix->bf.stride = stride;
+    ix->bf.measure = measure;
+    *out = ix;
+    return SCANN_HIP_OK;
+}
+
+// =====================================================================================
+// Tree-X-Hybrid / AsymmetricHasher index
+// =====================================================================================
+int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_hip_index **out) {
+    if (!ctx || !d || !out) return fail(SCANN_HIP_INVALID_ARGUMENT, "null ctx/desc/out_index");
+    const bool ah = d->num_partitions == 0;
+    if (d->n_local == 0)  // tree_x_hybrid/mod.rs:132-134, hashes/hasher.rs:110-112
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "Cannot build from empty dataset");
+    if (d->n_local >= 0xFFFFFFFFull) return fail(SCANN_HIP_OUT_OF_RANGE, "DatapointIndex is u32");
+    if (!d->codebook || !d->codes) return fail(SCANN_HIP_INVALID_ARGUMENT, "codebook/codes null");
+    const uint32_t S = d->num_subspaces, K = d->num_codes, dsub = d->dims_per_subspace;
+    if (S == 0 || d->dim == 0 || d->dim % S != 0 || dsub != d->dim / S)  // codebook.rs:154-159
+        return fail(SCANN_HIP_INVALID_ARGUMENT,
+                    "Dimensionality " + std::to_string(d->dim) +
+                        " must be divisible by num_subspaces " + std::to_string(S));
+    if (K == 0 || K > 16)
+        return fail(SCANN_HIP_UNIMPLEMENTED, "LUT16 path requires 1 <= num_codes <= 16");
+    if (S % 8 != 0 || S > 64 || S == 40 || S == 56)
+        return fail(SCANN_HIP_UNIMPLEMENTED, "num_subspaces must be 8,16,24,32,48 or 64");
+    if (!ah) {
+        if (!d->centers || !d->leaf_offsets || !d->leaf_ids)
+            return fail(SCANN_HIP_INVALID_ARGUMENT, "centers/leaf_offsets/leaf_ids null");
+        if (d->num_partitions > kMaxLeavesSelect)
+            return fail(SCANN_HIP_UNIMPLEMENTED, "num_partitions > 16384");
+        if (d->leaf_offsets[0] != 0 || d->leaf_offsets[d->num_partitions] != d->n_local)
+            return fail(SCANN_HIP_INVALID_ARGUMENT, "leaf_offsets must span [0, n_local]");
+        for (uint32_t l = 0; l < d->num_partitions; ++l)
+            if (d->leaf_offsets[l + 1] < d->leaf_offsets[l])
+                return fail(SCANN_HIP_INVALID_ARGUMENT, "leaf_offsets not monotone");
+    }
+    if (d->data && d->stride < d->dim) return fail(SCANN_HIP_INVALID_ARGUMENT, "stride < dim");
+    if (d->data && d->data_is_csr_order && d->n_rows != d->n_local)
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "CSR-ordered data must have n_local rows");
+    SCANN_TRY(set_device(ctx));
+
+    auto *ix = new scann_hip_index();
+    ix->ctx = ctx;
+    ix->kind = KIND_TXH;
+    auto bail = [&](int s) {
+        scann_hip_index_destroy(ix);
+        return s;
+    };
+    int s = index_common_init(ix);
+    if (s != SCANN_HIP_OK) return bail(s);
+
+    const uint32_t L = ah ? 1u : d->num_partitions;
+    const uint32_t nw = S / 8;
+    const uint64_t n = d->n_local;
+
+    // leaf tables
+    std::vector<uint32_t> off(L + 1), gsz(L);
+    if (ah) {
+        off[0] = 0;
+        off[1] = (uint32_t)n;
+        gsz[0] = (uint32_t)n;
+    } else {
+        std::memcpy(off.data(), d->leaf_offsets, (size_t)(L + 1) * 4);
+        for (uint32_t l = 0; l < L; ++l)
+            gsz[l] = d->leaf_sizes_global ? d->leaf_sizes_global[l] : off[l + 1] - off[l];
+    }
+    ix->local_sizes_desc.resize(L);
+    for (uint32_t l = 0; l < L; ++l) ix->local_sizes_desc[l] = off[l + 1] - off[l];
+    std::sort(ix->local_sizes_desc.begin(), ix->local_sizes_desc.end(), std::greater<uint32_t>());
+
+    // packed codes: [n][nw] words, nibble nb of word wi = subspace 8*wi+nb
+    // (PackedCodes4Bit layout, hashes/lut16.rs:43-61, read little-endian)
+    std::vector<uint32_t> words;
+    const uint32_t *code_words = nullptr;
+    const size_t bpp = S / 2;
+    if (d->codes_packed4) {
+        if ((reinterpret_cast<uintptr_t>(d->codes) & 3u) == 0) {
+            code_words = reinterpret_cast<const uint32_t *>(d->codes);
+        } else {
+            words.resize((size_t)n * nw);
+            std::memcpy(words.data(), d->codes, (size_t)n * bpp);
+            code_words = words.data();
+        }
+    } else {
+        words.assign((size_t)n * nw, 0u);
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint8_t *c = d->codes + i * S;
+            uint32_t *w = words.data() + i * nw;
+            for (uint32_t sidx = 0; sidx < S; ++sidx) {
+                if (c[sidx] >= K) {
+                    return bail(fail(SCANN_HIP_INVALID_ARGUMENT, "code value >= num_codes"));
+                }
+                w[sidx >> 3] |= (uint32_t)(c[sidx] & 0x0F) << (4 * (sidx & 7u));
+            }
+        }
+        code_words = words.data();
+    }
+
+    if ((s = upload(ix->d_leaf_off, off.data(), (size_t)(L + 1) * 4)) != SCANN_HIP_OK) return bail(s);
+    if ((s = upload(ix->d_leaf_gsize, gsz.data(), (size_t)L * 4)) != SCANN_HIP_OK) return bail(s);
+    if ((s = upload(ix->d_codes, code_words, (size_t)n * nw * 4)) != SCANN_HIP_OK) return bail(s);
+    if ((s = upload(ix->d_codebook, d->codebook, (size_t)S * K * dsub * 4)) != SCANN_HIP_OK) return bail(s);
+    if (!ah) {
+        if ((s = upload(ix->d_centers, d->centers, (size_t)L * d->dim * 4)) != SCANN_HIP_OK) return bail(s);
+        if ((s = upload(ix->d_leaf_ids, d->leaf_ids, (size_t)n * 4)) != SCANN_HIP_OK) return bail(s);
+    }
+    if (d->data) {
+        if ((s = upload(ix->d_rows, d->data, (size_t)d->n_rows * d->stride * 4)) != SCANN_HIP_OK)
+            return bail(s);
+    }
+
+    TxhIndexDev &t = ix->tx;
+    t.dim = d->dim;
+    t.stride = d->stride;
+    t.L = L;
+    t.S = S;
+    t.K = K;
+    t.dsub = dsub;
+    t.nw = nw;
+    t.n_local = n;
+    t.centers = ah ? nullptr : ix->d_centers.as<float>();
+    t.leaf_off = ix->d_leaf_off.as<uint32_t>();
+    t.leaf_gsize = ix->d_leaf_gsize.as<uint32_t>();
+    t.leaf_ids = ah ? nullptr : ix->d_leaf_ids.as<uint32_t>();
+    t.codes = ix->d_codes.as<uint32_t>();
+    t.rows = d->data ? ix->d_rows.as<float>() : nullptr;
+    // AH mode: CSR row == datapoint index.  Sharded: rows arrive in CSR order.
+    t.rows_csr = (ah || d->data_is_csr_order) ? 1 : 0;
+    t.codebook = ix->d_codebook.as<float>();
+    t.use_residuals = (!ah && d->use_residuals) ? 1 : 0;
+    t.ah_mode = ah ? 1 : 0;
+    ix->default_P = ah ? 1u : std::max(1u, d->partitions_to_search);
+    ix->multiplier = d->pre_reorder_multiplier;
+    *out = ix;
+    return SCANN_HIP_OK;
+}
+
+// ---- per-call parameter resolution --------------------------------------------------
+struct TxhCallParams {
+    uint32_t P, m, k, cap;
+    int exact_reorder;
+};
+
+static uint64_t max_stream(const scann_hip_index *ix, uint32_t P) {
+    uint64_t s = 0;
+    for (uint32_t i = 0; i < P && i < ix->local_sizes_desc.size(); ++i) s += ix->local_sizes_desc[i];
+    return s;
+}
+
+static int resolve_params(const scann_hip_index *ix, uint32_t k, const scann_hip_search_opts *o,
+                          bool full_cap, TxhCallParams *out) {
+    scann_hip_search_opts def;
+    scann_hip_search_opts_default(&def);
+    if (!o) o = &def;
+    uint32_t P = o->partitions_to_search ? o->partitions_to_search : ix->default_P;
+    P = std::min(P, ix->tx.L);  // tree_partitioner.rs:214
+    if (ix->tx.ah_mode) P = 1;
+    if (P > kSampleCap / 2)
+        return fail(SCANN_HIP_UNIMPLEMENTED, "partitions_to_search > 4096");
+    uint32_t m;
+    if (!o->exact_reorder) {
+        m = k;
+    } else if (o->pre_reorder_k) {
+        m = o->pre_reorder_k;
+    } else {
+        const float mf = (float)k * ix->multiplier;  // mod.rs:263 (saturating truncation)
+        m = mf > 0.0f ? (mf >= 4294967295.0f ? 0xFFFFFFFFu : (uint32_t)mf) : 0u;
+    }
+    if (m > kMaxPreReorderK)
+        return fail(SCANN_HIP_UNIMPLEMENTED,
+                    "pre-reorder candidate count " + std::to_string(m) + " exceeds " +
+                        std::to_string(kMaxPreReorderK));
+    if (o->exact_reorder && !ix->tx.rows)  // hasher.rs:194-197
+        return fail(SCANN_HIP_FAILED_PRECONDITION, "Dataset not stored");
+    const uint64_t ms = std::max<uint64_t>(1, max_stream(ix, P));
+    uint64_t cap = ms;
+    if (!full_cap) {
+        const uint64_t room = kSampleCap - P;
+        const uint64_t st = std::max<uint64_t>(1, (ms + room - 1) / room);
+        cap = std::min<uint64_t>(ms, 2ull * m * st + 16ull * st + 256ull);
+    }
+    out->P = P;
+    out->m = m;
+    out->k = k;
+    out->cap = (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFull);
+    out->exact_reorder = o->exact_reorder ? 1 : 0;
+    return SCANN_HIP_OK;
+}
+
+static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallParams &p,
+                                bool own_queries, uint32_t q_stride, bool own_outputs,
+                                TxhWork *w) {
+    TxhWorkspace &s = ix->ws;
+    const TxhIndexDev &t = ix->tx;
+    const uint32_t L = t.L, P = p.P, m = std::max(1u, p.m), k = std::max(1u, p.k);
+    const uint32_t max_slots = nq * P + 3 * L + 4;
+    const uint32_t max_quads = max_slots / 4 + 1;
+    if (own_queries) SCANN_TRY(s.queries.ensure((size_t)nq * q_stride * 4));
+    if (!t.ah_mode) SCANN_TRY(s.cdist.ensure((size_t)nq * L * 4));
+    SCANN_TRY(s.tokens.ensure((size_t)nq * P * 4));
+    SCANN_TRY(s.token_dists.ensure((size_t)nq * P * 4));
+    SCANN_TRY(s.vbase.ensure((size_t)nq * (P + 1) * 4));
+    SCANN_TRY(s.leaf_cnt.ensure((size_t)L * 4));
+    SCANN_TRY(s.leaf_cursor.ensure((size_t)L * 4));
+    SCANN_TRY(s.pair_off.ensure((size_t)(L + 1) * 4));
+    SCANN_TRY(s.tile_off.ensure((size_t)(L + 1) * 4));
+    SCANN_TRY(s.counters.ensure(CNT_N * 4));
+    SCANN_TRY(s.pair_q.ensure((size_t)max_slots * 4));
+    SCANN_TRY(s.pair_leaf.ensure((size_t)max_slots * 4));
+    SCANN_TRY(s.pair_vbase.ensure((size_t)max_slots * 4));
+    SCANN_TRY(s.slot_of.ensure((size_t)nq * P * 4));
+    SCANN_TRY(s.lutq.ensure((size_t)max_quads * t.S * 16 * 4 * 4));
+    SCANN_TRY(s.thr.ensure((size_t)nq * 8));
+    SCANN_TRY(s.cand_cnt.ensure((size_t)nq * 4));
+    SCANN_TRY(s.cand.ensure((size_t)nq * p.cap * 8));
+    SCANN_TRY(s.cand_key.ensure((size_t)nq * m * 8));
+    SCANN_TRY(s.cand_idx.ensure((size_t)nq * m * 4));
+    SCANN_TRY(s.cand_dist.ensure((size_t)nq * m * 4));
+    SCANN_TRY(s.cand_exact.ensure((size_t)nq * m * 4));
+    SCANN_TRY(s.cand_count.ensure((size_t)nq * 4));
+    if (own_outputs) {
+        SCANN_TRY(s.out_idx.ensure((size_t)nq * k * 4));
+        SCANN_TRY(s.out_dist.ensure((size_t)nq * k * 4));
+        SCANN_TRY(s.out_count.ensure((size_t)nq * 4));
+    }
+    w->nq = nq;
+    w->q_stride = q_stride;
+    w->P = P;
+    w->m = p.m;
+    w->k = p.k;
+    w->cap = p.cap;
+    w->exact_reorder = p.exact_reorder;
+    w->queries = s.queries.as<float>();
+    w->cdist = s.cdist.as<float>();
+    w->tokens = s.tokens.as<uint32_t>();
+    w->token_dists = s.token_dists.as<float>();
+    w->vbase = s.vbase.as<uint32_t>();
+    w->leaf_cnt = s.leaf_cnt.as<uint32_t>();
+    w->leaf_cursor = s.leaf_cursor.as<uint32_t>();
+    w->pair_off = s.pair_off.as<uint32_t>();
+    w->tile_off = s.tile_off.as<uint32_t>();
+    w->counters = s.counters.as<uint32_t>();
+    w->pair_q = s.pair_q.as<uint32_t>();
+    w->pair_leaf = s.pair_leaf.as<uint32_t>();
+    w->pair_vbase = s.pair_vbase.as<uint32_t>();
+    w->slot_of = s.slot_of.as<uint32_t>();
+    w->max_slots = max_slots;
+    w->max_quads = max_quads;
+    w->lutq = s.lutq.as<float>();
+    w->thr = s.thr.as<uint64_t>();
+    w->cand_cnt = s.cand_cnt.as<uint32_t>();
+    w->cand = s.cand.as<uint64_t>();
+    w->cand_key = s.cand_key.as<uint64_t>();
+    w->cand_idx = s.cand_idx.as<uint32_t>();
+    w->cand_dist = s.cand_dist.as<float>();
+    w->cand_exact = s.cand_exact.as<float>();
+    w->cand_count = s.cand_count.as<uint32_t>();
+    w->out_idx = s.out_idx.as<uint32_t>();
+    w->out_dist = s.out_dist.as<float>();
+    w->out_count = s.out_count.as<uint32_t>();
+    return SCANN_HIP_OK;
+}
+
+static void fill_empty(uint32_t nq, uint32_t k, uint32_t *out_idx, float *out_dist,
+                       uint32_t *out_count) {
+    for (size_t i = 0; i < (size_t)nq * k; ++i) {
+        if (out_idx) out_idx[i] = 0xFFFFFFFFu;
+        if (out_dist) out_dist[i] = INFINITY;
+    }
+    for (uint32_t i = 0; i < nq; ++i)
+        if (out_count) out_count[i] = 0;
+}
+
+static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t nq,
+                           uint32_t q_stride, uint32_t k, const scann_hip_search_opts *opts,
+                           uint32_t *out_idx, float *out_dist, uint32_t *out_count) {
+    std::lock_guard<std::mutex> lock(ix->mu);
+    SCANN_TRY(set_device(ix->ctx));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        TxhCallParams p;
+        SCANN_TRY(resolve_params(ix, k, opts, /*full_cap=*/attempt == 1, &p));
+        if (p.m == 0) {  // nothing can be kept (reference panics on FastTopNeighbors::new(0))
+            fill_empty(nq, k, out_idx, out_dist, out_count);
+            if (opts && opts->cand_count) std::memset(opts->cand_count, 0, (size_t)nq * 4);
+            return SCANN_HIP_OK;
+        }
+        TxhWork w;
+        SCANN_TRY(ensure_txh_workspace(ix, nq, p, true, q_stride, true, &w));
+        SCANN_HIP_CHECK(hipMemcpyAsync(ix->ws.queries.p, queries, (size_t)nq * q_stride * 4,
+                                       hipMemcpyHostToDevice, ix->stream));
+        SCANN_TRY(txh_launch_search(ix->tx, w, false, ix->stream, ix->timing ? ix->ev0 : nullptr,
+                                    ix->timing ? ix->ev1 : nullptr));
+        ix->timing_valid = ix->timing;
+        ix->timed_kernel = "adc_scan_kernel";
+        uint32_t counters[CNT_N];
+        SCANN_HIP_CHECK(hipMemcpyAsync(counters, w.counters, sizeof(counters), hipMemcpyDeviceToHost,
+                                       ix->stream));
+        SCANN_HIP_CHECK(hipMemcpyAsync(out_idx, w.out_idx, (size_t)nq * k * 4, hipMemcpyDeviceToHost,
+                                       ix->stream));
+        SCANN_HIP_CHECK(hipMemcpyAsync(out_dist, w.out_dist, (size_t)nq * k * 4,
+                                       hipMemcpyDeviceToHost, ix->stream));
+        SCANN_HIP_CHECK(hipMemcpyAsync(out_count, w.out_count, (size_t)nq * 4, hipMemcpyDeviceToHost,
+                                       ix->stream));
+        if (opts) {
+            if (opts->tokens)
+                SCANN_HIP_CHECK(hipMemcpyAsync(opts->tokens, w.tokens, (size_t)nq * p.P * 4,
+                                               hipMemcpyDeviceToHost, ix->stream));
+            if (opts->token_dists)
+                SCANN_HIP_CHECK(hipMemcpyAsync(opts->token_dists, w.token_dists, (size_t)nq * p.P * 4,
+                                               hipMemcpyDeviceToHost, ix->stream));
+            if (opts->cand_idx)
+                SCANN_HIP_CHECK(hipMemcpyAsync(opts->cand_idx, w.cand_idx, (size_t)nq * p.m * 4,
+                                               hipMemcpyDeviceToHost, ix->stream));
+            if (opts->cand_dist)
+                SCANN_HIP_CHECK(hipMemcpyAsync(opts->cand_dist, w.cand_dist, (size_t)nq * p.m * 4,
+                                               hipMemcpyDeviceToHost, ix->stream));
+            if (opts->cand_count)
+                SCANN_HIP_CHECK(hipMemcpyAsync(opts->cand_count, w.cand_count, (size_t)nq * 4,
+                                               hipMemcpyDeviceToHost, ix->stream));
+        }
+        SCANN_HIP_CHECK(hipStreamSynchronize(ix->stream));
+        if (counters[CNT_STATUS] == SCANN_HIP_OK) return SCANN_HIP_OK;
+        if (counters[CNT_STATUS] != SCANN_HIP_RESOURCE_EXHAUSTED || attempt == 1)
+            return fail((int)counters[CNT_STATUS], "device reported a search failure");
+        // candidate buffer overflow: retry once with a buffer that holds the whole stream
+    }
+    return fail(SCANN_HIP_INTERNAL, "unreachable");
+}
+
+int scann_hip_search_batched(scann_hip_index *ix, const float *queries, uint32_t nq,
+                             uint32_t q_stride, uint32_t q_dim, uint32_t k,
+                             const scann_hip_search_opts *opts, uint32_t *out_idx, float *out_dist,
+                             uint32_t *out_count) {
+    if (!ix) return fail(SCANN_HIP_INVALID_ARGUMENT, "index is null");
+    if (nq == 0) return SCANN_HIP_OK;
+    if (!queries || !out_count || (k > 0 && (!out_idx || !out_dist)))
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "null query/output pointer");
+    if (ix->kind == KIND_BF) {
+        if (ix->bf.n == 0) {  // brute_force/searcher.rs:78-80: Ok(empty) before the dim check
+            fill_empty(nq, k, out_idx, out_dist, out_count);
+            return SCANN_HIP_OK;
+        }
+        if (q_dim != ix->bf.dim)  // searcher.rs:83-89
+            return fail(SCANN_HIP_INVALID_ARGUMENT,
+                        "Query dimensionality " + std::to_string(q_dim) +
+                            " does not match dataset dimensionality " + std::to_string(ix->bf.dim));
+        if (q_stride < q_dim) return fail(SCANN_HIP_INVALID_ARGUMENT, "q_stride < q_dim");
+        if (k == 0) {
+            fill_empty(nq, 0, nullptr, nullptr, out_count);
+            return SCANN_HIP_OK;
+        }
+        std::lock_guard<std::mutex> lock(ix->mu);
+        SCANN_TRY(set_device(ix->ctx));
+        int s = bf_search_host(ix->bf, ix->bfw, queries, nq, q_stride, k, out_idx, out_dist, out_count,
+                               ix->stream, ix->timing ? ix->ev0 : nullptr,
+                               ix->timing ? ix->ev1 : nullptr);
+        ix->timing_valid = ix->timing && s == SCANN_HIP_OK;
+        ix->timed_kernel = "bf_mfma_kernel";
+        return s;
+    }
+    if (q_dim != ix->tx.dim)  // tree_x_hybrid/mod.rs:251-253, hashes/hasher.rs:167-171
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "Query dimensionality mismatch");
+    if (q_stride < q_dim) return fail(SCANN_HIP_INVALID_ARGUMENT, "q_stride < q_dim");
+    if (k == 0) {
+        fill_empty(nq, 0, nullptr, nullptr, out_count);
+        return SCANN_HIP_OK;
+    }
+    return txh_search_host(ix, queries, nq, q_stride, k, opts, out_idx, out_dist, out_count);
+}
+
+int scann_hip_index_reserve(scann_hip_index *ix, uint32_t max_nq, uint32_t max_k,
+                            const scann_hip_search_opts *opts) {
+    if (!ix) return fail(SCANN_HIP_INVALID_ARGUMENT, "index is null");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    SCANN_TRY(set_device(ix->ctx));
+    if (ix->kind == KIND_BF) return bf_reserve(ix->bf, ix->bfw, max_nq, max_k);
+    TxhCallParams p;
+    SCANN_TRY(resolve_params(ix, max_k, opts, false, &p));
+    TxhWork w;
+    return ensure_txh_workspace(ix, max_nq, p, false, 0, false, &w);
+}
+
+int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries, uint32_t nq,
+                                    uint32_t q_stride, uint32_t k, const scann_hip_search_opts *opts,
+                                    uint32_t *d_out_idx, float *d_out_dist, uint32_t *d_out_count,
+                                    void *hip_stream) {
+    if (!ix) return fail(SCANN_HIP_INVALID_ARGUMENT, "index is null");
+    if (nq == 0) return SCANN_HIP_OK;
+    if (k == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "k must be > 0 on the device path");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    std::lock_guard<std::mutex> lock(ix->mu);
+    SCANN_TRY(set_device(ix->ctx));
+    if (ix->kind == KIND_BF) {
+        int s = bf_search_device(ix->bf, ix->bfw, d_queries, nq, q_stride, k, d_out_idx, d_out_dist,
+                                 d_out_count, st, ix->timing ? ix->ev0 : nullptr,
+                                 ix->timing ? ix->ev1 : nullptr);
+        ix->timing_valid = ix->timing && s == SCANN_HIP_OK;
+        ix->timed_kernel = "bf_mfma_kernel";
+        return s;
+    }
+    TxhCallParams p;
+    SCANN_TRY(resolve_params(ix, k, opts, false, &p));
+    if (p.m == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "pre-reorder candidate count is 0");
+    TxhWork w;
+    SCANN_TRY(ensure_txh_workspace(ix, nq, p, false, q_stride, false, &w));
+    w.queries = d_queries;
+    w.out_idx = d_out_idx;
+    w.out_dist = d_out_dist;
+    w.out_count = d_out_count;
+    ix->last_work = w;
+    SCANN_TRY(txh_launch_search(ix->tx, w, false, st, ix->timing ? ix->ev0 : nullptr,
+                                ix->timing ? ix->ev1 : nullptr));
+    ix->timing_valid = ix->timing;
+    ix->timed_kernel = "adc_scan_kernel";
+    return SCANN_HIP_OK;
+}
+
+int scann_hip_index_last_device_status(scann_hip_index *ix, void *hip_stream) {
+    if (!ix) return fail(SCANN_HIP_INVALID_ARGUMENT, "index is null");
+    if (ix->kind != KIND_TXH || !ix->ws.counters.p) return SCANN_HIP_OK;
+    SCANN_TRY(set_device(ix->ctx));
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    uint32_t counters[CNT_N];
+    SCANN_HIP_CHECK(hipMemcpyAsync(counters, ix->ws.counters.p, sizeof(counters),
+                                   hipMemcpyDeviceToHost, st));
+    SCANN_HIP_CHECK(hipStreamSynchronize(st));
+    if (counters[CNT_STATUS] != SCANN_HIP_OK)
+        return fail((int)counters[CNT_STATUS],
+                    "candidate buffer overflow on the device path (use the host entry point, "
+                    "which retries with a full-size buffer)");
+    return SCANN_HIP_OK;
+}
+
+// ---- multi-GPU ------------------------------------------------------------------------
+int scann_hip_txh_search_local_device(scann_hip_index *ix, const float *d_queries, uint32_t nq,
+                                      uint32_t q_stride, uint32_t k,
+                                      const scann_hip_search_opts *opts, uint64_t *d_keys,
+                                      uint32_t *d_idx, float *d_exact, uint32_t *d_count,
+                                      void *hip_stream) {
+    if (!ix || ix->kind != KIND_TXH) return fail(SCANN_HIP_INVALID_ARGUMENT, "not a tree index");
+    if (nq == 0) return SCANN_HIP_OK;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    std::lock_guard<std::mutex> lock(ix->mu);
+    SCANN_TRY(set_device(ix->ctx));
+    TxhCallParams p;
+    SCANN_TRY(resolve_params(ix, k, opts, false, &p));
+    if (!p.exact_reorder) return fail(SCANN_HIP_INVALID_ARGUMENT, "local stage needs exact_reorder");
+    if (p.m == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "pre-reorder candidate count is 0");
+    TxhWork w;
+    SCANN_TRY(ensure_txh_workspace(ix, nq, p, false, q_stride, false, &w));
+    w.queries = d_queries;
+    w.cand_key = d_keys;
+    w.cand_idx = d_idx;
+    w.cand_exact = d_exact;
+    w.cand_count = d_count;
+    ix->last_work = w;
+    SCANN_TRY(txh_launch_search(ix->tx, w, true, st, ix->timing ? ix->ev0 : nullptr,
+                                ix->timing ? ix->ev1 : nullptr));
+    ix->timing_valid = ix->timing;
+    ix->timed_kernel = "adc_scan_kernel";
+    return SCANN_HIP_OK;
+}
+
+int scann_hip_txh_merge_device(scann_hip_ctx *ctx, uint32_t world, uint32_t nq, uint32_t m,
+                               uint32_t k, const uint64_t *d_keys, const uint32_t *d_idx,
+                               const float *d_exact, const uint32_t *d_count, uint32_t *d_out_idx,
+                               float *d_out_dist, uint32_t *d_out_count, void *hip_stream) {
+    if (!ctx) return fail(SCANN_HIP_INVALID_ARGUMENT, "ctx is null");
+    SCANN_TRY(set_device(ctx));
+    return txh_launch_merge(world, nq, m, k, d_keys, d_idx, d_exact, d_count, d_out_idx, d_out_dist,
+                            d_out_count, static_cast<hipStream_t>(hip_stream));
+}
+
+int scann_hip_assign_leaves(const uint32_t *sizes, uint32_t L, uint32_t world, uint32_t *owner) {
+    if (!sizes || !owner || world == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "bad arguments");
+    std::vector<uint32_t> order(L);
+    for (uint32_t i = 0; i < L; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](uint32_t a, uint32_t b) { return sizes[a] > sizes[b]; });
+    std::vector<uint64_t> load(world, 0);
+    for (uint32_t i : order) {
+        uint32_t best = 0;
+        for (uint32_t g = 1; g < world; ++g)
+            if (load[g] < load[best]) best = g;
+        owner[i] = best;
+        load[best] += sizes[i];
+    }
+    return SCANN_HIP_OK;
+}
+
+// ---- building blocks ---------------------------------------------------------------------
+int scann_hip_txh_partition(scann_hip_index *ix, const float *queries, uint32_t nq,
+                            uint32_t q_stride, uint32_t q_dim, uint32_t num_partitions,
+                            uint32_t *out_tokens, float *out_dists, uint32_t *out_count) {
+    if (!ix || ix->kind != KIND_TXH) return fail(SCANN_HIP_INVALID_ARGUMENT, "not a tree index");
+    if (ix->tx.ah_mode)  // tree_partitioner.rs:197-198
+        return fail(SCANN_HIP_FAILED_PRECONDITION, "Partitioner not built");
+    if (q_dim != ix->tx.dim) return fail(SCANN_HIP_INVALID_ARGUMENT, "Query dimensionality mismatch");
+    if (nq == 0) return SCANN_HIP_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    SCANN_TRY(set_device(ix->ctx));
+    scann_hip_search_opts o;
+    scann_hip_search_opts_default(&o);
+    o.partitions_to_search = std::max(1u, num_partitions);
+    o.exact_reorder = 0;
+    TxhCallParams p;
+    SCANN_TRY(resolve_params(ix, 1, &o, false, &p));
+    TxhWork w;
+    SCANN_TRY(ensure_txh_workspace(ix, nq, p, true, q_stride, true, &w));
+    SCANN_HIP_CHECK(hipMemcpyAsync(ix->ws.queries.p, queries, (size_t)nq * q_stride * 4,
+                                   hipMemcpyHostToDevice, ix->stream));
+    SCANN_TRY(txh_launch_partition_only(ix->tx, w, ix->stream));
+    const uint32_t P = num_partitions == 0 ? 0 : p.P;
+    if (P) {
+        SCANN_HIP_CHECK(hipMemcpyAsync(out_tokens, w.tokens, (size_t)nq * P * 4, hipMemcpyDeviceToHost,
+                                       ix->stream));
+        SCANN_HIP_CHECK(hipMemcpyAsync(out_dists, w.token_dists, (size_t)nq * P * 4,
+                                       hipMemcpyDeviceToHost, ix->stream));
+    }
+    SCANN_HIP_CHECK(hipStreamSynchronize(ix->stream));
+    if (out_count)
+        for (uint32_t i = 0; i < nq; ++i) out_count[i] = P;
+    return SCANN_HIP_OK;
+}
+
+int scann_hip_lut_from_query(scann_hip_index *ix, const float *queries, uint32_t nq,
+                             uint32_t q_stride, const uint32_t *leaf_for_query, float *out_lut) {
+    if (!ix || ix->kind != KIND_TXH) return fail(SCANN_HIP_INVALID_ARGUMENT, "not a tree index");
+    if (nq == 0) return SCANN_HIP_OK;
+    if (leaf_for_query && ix->tx.ah_mode)
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "no centroids in AsymmetricHasher mode");
+    if (leaf_for_query)
+        for (uint32_t i = 0; i < nq; ++i)
+            if (leaf_for_query[i] >= ix->tx.L)  // mod.rs:304-306
+                return fail(SCANN_HIP_OUT_OF_RANGE, "Invalid partition ID");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    SCANN_TRY(set_device(ix->ctx));
+    DevBuf dq, dl, dout;
+    SCANN_TRY(upload(dq, queries, (size_t)nq * q_stride * 4));
+    if (leaf_for_query) SCANN_TRY(upload(dl, leaf_for_query, (size_t)nq * 4));
+    const size_t ob = (size_t)nq * ix->tx.S * ix->tx.K * 4;
+    SCANN_TRY(dout.ensure(ob));
+    SCANN_TRY(txh_launch_lut_from_query(ix->tx, dq.as<float>(), nq, q_stride,
+                                        leaf_for_query ? dl.as<uint32_t>() : nullptr,
+                                        dout.as<float>(), ix->stream));
+    SCANN_HIP_CHECK(hipMemcpyAsync(out_lut, dout.p, ob, hipMemcpyDeviceToHost, ix->stream));
+    SCANN_HIP_CHECK(hipStreamSynchronize(ix->stream));
+    return SCANN_HIP_OK;
+}
+
+int scann_hip_adc_distances(scann_hip_index *ix, const float *luts, uint32_t nq, float *out_dist) {
+    if (!ix || ix->kind != KIND_TXH) return fail(SCANN_HIP_INVALID_ARGUMENT, "not a tree index");
+    if (nq == 0) return SCANN_HIP_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    SCANN_TRY(set_device(ix->ctx));
+    DevBuf dl, dout;
+    SCANN_TRY(upload(dl, luts, (size_t)nq * ix->tx.S * ix->tx.K * 4));
+    const size_t ob = (size_t)nq * ix->tx.n_local * 4;
+    SCANN_TRY(dout.ensure(ob));
+    SCANN_TRY(txh_launch_adc_distances(ix->tx, dl.as<float>(), nq, dout.as<float>(), ix->stream));
+    SCANN_HIP_CHECK(hipMemcpyAsync(out_dist, dout.p, ob, hipMemcpyDeviceToHost, ix->stream));
+    SCANN_HIP_CHECK(hipStreamSynchronize(ix->stream));
+    return SCANN_HIP_OK;
+}
+
+int scann_hip_lut16_distances_batch(scann_hip_ctx *ctx, const uint8_t *packed, const uint8_t *lut8,
+                                    uint32_t S, uint64_t n, float bias, float multiplier,
+                                    float *out) {
+    if (!ctx) return fail(SCANN_HIP_INVALID_ARGUMENT, "ctx is null");
+    if (n == 0) return SCANN_HIP_OK;
+    if (!packed || !lut8 || !out || S == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "null argument");
+    SCANN_TRY(set_device(ctx));
+    DevBuf dp, dl, dout;
+    SCANN_TRY(upload(dp, packed, (size_t)n * ((S + 1) / 2)));
+    SCANN_TRY(upload(dl, lut8, (size_t)S * 16));
+    SCANN_TRY(dout.ensure((size_t)n * 4));
+    SCANN_TRY(launch_lut16_u8_batch(dp.as<uint8_t>(), dl.as<uint8_t>(), S, n, bias, multiplier,
+                                    dout.as<float>(), nullptr));
+    SCANN_HIP_CHECK(hipMemcpy(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return SCANN_HIP_OK;
+}
+
+int scann_hip_encode(scann_hip_ctx *ctx, const float *codebook, uint32_t S, uint32_t K, uint32_t dsub,
+                     const float *rows, uint64_t n, uint32_t stride, const float *centers,
+                     const uint32_t *leaf_of_row, uint8_t *out_codes) {
+    if (!ctx) return fail(SCANN_HIP_INVALID_ARGUMENT, "ctx is null");
+    if (n == 0) return SCANN_HIP_OK;
+    if (!codebook || !rows || !out_codes || S == 0 || K == 0 || K > 256 || dsub == 0)
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "bad argument");
+    if ((centers == nullptr) != (leaf_of_row == nullptr))
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "centers and leaf_of_row go together");
+    if (stride < S * dsub) return fail(SCANN_HIP_INVALID_ARGUMENT, "stride < dim");
+    SCANN_TRY(set_device(ctx));
+    DevBuf dcb, drows, dcen, dleaf, dout;
+    SCANN_TRY(upload(dcb, codebook, (size_t)S * K * dsub * 4));
+    SCANN_TRY(upload(drows, rows, (size_t)n * stride * 4));
+    if (centers) {
+        uint32_t maxleaf = 0;
+        for (uint64_t i = 0; i < n; ++i) maxleaf = std::max(maxleaf, leaf_of_row[i]);
+        SCANN_TRY(upload(dcen, centers, (size_t)(maxleaf + 1) * S * dsub * 4));
+        SCANN_TRY(upload(dleaf, leaf_of_row, (size_t)n * 4));
+    }
+    SCANN_TRY(dout.ensure((size_t)n * S));
+    SCANN_TRY(launch_encode(dcb.as<float>(), S, K, dsub, drows.as<float>(), n, stride,
+                            centers ? dcen.as<float>() : nullptr,
+                            centers ? dleaf.as<uint32_t>() : nullptr, dout.as<uint8_t>(), nullptr));
+    SCANN_HIP_CHECK(hipMemcpy(out_codes, dout.p, (size_t)n * S, hipMemcpyDeviceToHost));
+    return SCANN_HIP_OK;
+}
+
+int scann_hip_bf_distances(scann_hip_index *ix, const float *queries, uint32_t nq, uint32_t q_stride,
+                           float *out) {
+    if (!ix || ix->kind != KIND_BF) return fail(SCANN_HIP_INVALID_ARGUMENT, "not a brute-force index");
+    if (nq == 0 || ix->bf.n == 0) return SCANN_HIP_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    SCANN_TRY(set_device(ix->ctx));
+    return bf_distances_host(ix->bf, ix->bfw, queries, nq, q_stride, out, ix->stream);
+}
+
+}  // extern "C"

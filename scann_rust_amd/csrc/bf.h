@@ -1,0 +1,36 @@
+// bf.h -- brute-force path (BruteForceSearcher, brute_force/searcher.rs:77-208).
+#pragma once
+#include "common.h"
+
+namespace scann {
+
+struct BfIndexDev {
+    const float *rows;   // [n][stride]
+    uint64_t n;
+    uint32_t dim, stride;
+    int measure;         // scann_hip_measure
+};
+
+struct BfWorkspace {
+    DevBuf queries, sample, thr, cand_cnt, cand, counters, out_idx, out_dist, out_count;
+};
+
+constexpr uint32_t kBfSampleRows = 8192;   // rows of the threshold sample (== LDS sort size)
+
+int bf_reserve(const BfIndexDev &ix, BfWorkspace &w, uint32_t max_nq, uint32_t max_k);
+
+// Host-pointer entry (copies in/out, synchronises).
+int bf_search_host(const BfIndexDev &ix, BfWorkspace &w, const float *queries, uint32_t nq,
+                   uint32_t q_stride, uint32_t k, uint32_t *out_idx, float *out_dist,
+                   uint32_t *out_count, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+
+// Device-pointer entry (enqueue only).
+int bf_search_device(const BfIndexDev &ix, BfWorkspace &w, const float *d_queries, uint32_t nq,
+                     uint32_t q_stride, uint32_t k, uint32_t *d_out_idx, float *d_out_dist,
+                     uint32_t *d_out_count, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+
+// Dense [nq][n] distance matrix to host memory.
+int bf_distances_host(const BfIndexDev &ix, BfWorkspace &w, const float *queries, uint32_t nq,
+                      uint32_t q_stride, float *out, hipStream_t stream);
+
+}  // namespace scann

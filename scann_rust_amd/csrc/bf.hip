@@ -1,0 +1,606 @@
+// bf.hip -- batched brute force (BruteForceSearcher::search_batched,
+// brute_force/searcher.rs:77-208) for gfx950.
+//
+// The reference computes, per (query, row), one_to_many_{squared_l2,dot_product}_avx2
+// (simd/x86.rs:195-346): 8 independent FMA lane chains over 8-float chunks, a fixed
+// horizontal-sum tree (x86.rs:31-44), a non-fused scalar tail, and then pushes every row
+// into a TopK heap (top_k.rs:66-81) whose survivors are the k lexicographically smallest
+// (distance, index) pairs.
+//
+//  * DotProduct, dim % 16 == 0: f32 MFMA (v_mfma_f32_32x32x2_f32).  Each MFMA result is a
+//    k-ordered fmaf chain, so feeding chain j with k = j, 8+j, 16+j, ... reproduces AVX2
+//    lane j exactly; the 8 chains are 8 accumulator tiles combined by the hsum tree.
+//    Distances are therefore bit-identical to the CPU path.
+//  * SquaredL2 / L2 / other dims: VALU kernel with the same 8-chain arithmetic.
+//  * top-k: a strided row sample gives a valid upper bound of the k-th best key; the full
+//    pass keeps only (distance, index) keys <= bound; a per-query LDS sort finishes.
+#include "bf.h"
+
+namespace scann {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr uint32_t kBfSortCap = 8192;
+constexpr uint32_t kBfMaxK = 2048;
+constexpr uint32_t kBfSelectThreads = 1024;
+constexpr uint32_t kBfInvalid = 0xFFFFFFFFu;
+
+enum { BF_CNT_STATUS = 0, BF_CNT_N = 4 };
+
+struct BfPass {
+    const float *queries;   // device [nq][q_stride]
+    uint32_t nq, q_stride;
+    uint32_t nrows;         // virtual rows of this pass
+    uint32_t row_mult;      // real row = virtual row * row_mult
+    int filter;             // 0: store all to out[nq][ld]; 1: threshold filter -> candidates
+    float *out;
+    uint32_t ld;
+    const uint64_t *thr;    // [nq]
+    uint32_t *cand_cnt;     // [nq]
+    uint64_t *cand;         // [nq][cap]
+    uint32_t cap;
+};
+
+__device__ __forceinline__ void bf_emit(const BfPass &p, uint32_t q, uint32_t vrow, float dist,
+                                        float Tf, uint64_t T) {
+    if (!p.filter) {
+        p.out[(size_t)q * p.ld + vrow] = dist;
+    } else if (dist <= Tf) {
+        const uint64_t key = make_key(dist, vrow * p.row_mult);
+        if (key <= T) {
+            const uint32_t pos = atomicAdd(&p.cand_cnt[q], 1u);
+            if (pos < p.cap) p.cand[(size_t)q * p.cap + pos] = key;
+        }
+    }
+}
+
+__device__ __forceinline__ float bf_thr_float(uint64_t T) {
+    const uint32_t hi = (uint32_t)(T >> 32);
+    return hi == 0xFFFFFFFFu ? __builtin_inff() : ordered_to_f32(hi);
+}
+
+// =====================================================================================
+// Generic VALU kernel: any dim, all three measures; one row per thread, QT queries from
+// LDS.  Arithmetic = simd/x86.rs:139-165 / :72-96 lane for lane.
+// =====================================================================================
+constexpr int kBfGenQT = 8;
+
+template <int MEASURE>
+__global__ __launch_bounds__(256) void bf_generic_kernel(BfIndexDev ix, BfPass p) {
+    extern __shared__ __attribute__((aligned(16))) float qs[];  // [kBfGenQT][dimp]
+    const uint32_t dim = ix.dim, dimp = (dim + 3u) & ~3u;
+    const uint32_t q0 = blockIdx.y * kBfGenQT;
+    for (uint32_t i = threadIdx.x; i < kBfGenQT * dimp; i += blockDim.x) {
+        uint32_t qi = i / dimp, j = i - qi * dimp;
+        qs[i] = (q0 + qi < p.nq && j < dim) ? p.queries[(size_t)(q0 + qi) * p.q_stride + j] : 0.0f;
+    }
+    __syncthreads();
+    const uint32_t vrow = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vrow >= p.nrows) return;
+    const float *row = ix.rows + (size_t)vrow * p.row_mult * ix.stride;
+    const uint32_t chunks = dim >> 3;
+    float acc[kBfGenQT][8];
+#pragma unroll
+    for (int qi = 0; qi < kBfGenQT; ++qi)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[qi][j] = 0.0f;
+    const bool vec = ((ix.stride & 3u) == 0) && ((reinterpret_cast<uintptr_t>(ix.rows) & 15u) == 0);
+    for (uint32_t c = 0; c < chunks; ++c) {
+        float x[8];
+        if (vec) {
+            const float4 a = *reinterpret_cast<const float4 *>(row + 8 * c);
+            const float4 b = *reinterpret_cast<const float4 *>(row + 8 * c + 4);
+            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
+            x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = row[8 * c + j];
+        }
+#pragma unroll
+        for (int qi = 0; qi < kBfGenQT; ++qi) {
+            const float *qv = qs + qi * dimp + 8 * c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (MEASURE == SCANN_HIP_DOT_PRODUCT) {
+                    acc[qi][j] = fmaf(qv[j], x[j], acc[qi][j]);
+                } else {
+                    const float d = qv[j] - x[j];
+                    acc[qi][j] = fmaf(d, d, acc[qi][j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int qi = 0; qi < kBfGenQT; ++qi) {
+        if (q0 + qi >= p.nq) continue;
+        const float s0 = acc[qi][0] + acc[qi][4], s1 = acc[qi][1] + acc[qi][5];
+        const float s2 = acc[qi][2] + acc[qi][6], s3 = acc[qi][3] + acc[qi][7];
+        float r = (s0 + s1) + (s2 + s3);
+        for (uint32_t j = chunks * 8; j < dim; ++j) {
+            const float qv = qs[qi * dimp + j];
+            if (MEASURE == SCANN_HIP_DOT_PRODUCT) {
+                r = r + qv * row[j];
+            } else {
+                const float d = qv - row[j];
+                r = r + d * d;
+            }
+        }
+        float dist = r;
+        if (MEASURE == SCANN_HIP_DOT_PRODUCT) dist = -r;
+        if (MEASURE == SCANN_HIP_L2) dist = sqrtf(r);
+        uint64_t T = 0;
+        float Tf = 0.0f;
+        if (p.filter) {
+            T = p.thr[q0 + qi];
+            Tf = bf_thr_float(T);
+        }
+        bf_emit(p, q0 + qi, vrow, dist, Tf, T);
+    }
+}
+
+// =====================================================================================
+// MFMA kernel: DotProduct, dim = 16 * TS.  Block = 4 waves; wave w owns 32 queries
+// (Q fragments resident in VGPRs), all waves share a 32-row X tile staged in LDS
+// (padded rows: conflict-free ds_read_b128).  Operand maps (v_mfma_f32_32x32x2_f32):
+//   A[i = lane & 31][k = lane >> 5] = X[row i][16t + 8h + j]
+//   B[k = lane >> 5][n = lane & 31] = Q[query n][16t + 8h + j]
+//   D[row = (r&3) + 8*(r>>2) + 4h][col = lane & 31]
+// Chain j accumulates k = j, 8+j, 16+j, ... in ascending order == AVX2 lane j.
+// =====================================================================================
+template <int TS>
+__global__ __launch_bounds__(256) void bf_mfma_dot_kernel(BfIndexDev ix, BfPass p, uint32_t nx,
+                                                          uint32_t ny) {
+    constexpr int DIM = TS * 16;
+    constexpr int LDX = DIM + 4;              // padded row (floats)
+    constexpr int V4_PER_ROW = DIM / 4;
+    constexpr int V4_PER_TILE = 32 * V4_PER_ROW;
+    constexpr int STG = (V4_PER_TILE + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [2][32][LDX]
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t h = lane >> 5, li = lane & 31u;
+    // XCD-aware mapping: blocks that share an X tile (same x, all y) sit on one XCD.
+    const uint32_t bid = blockIdx.x, xcd = bid & 7u, slot = bid >> 3;
+    const uint32_t x = xcd + 8u * (slot / ny), y = slot % ny;
+    const uint32_t ntiles = (p.nrows + 31u) / 32u;
+
+    // resident query fragments
+    const uint32_t q = y * 128u + wave * 32u + li;
+    const uint32_t qc = min(q, p.nq - 1u);
+    float qf[TS * 8];
+    {
+        const float *qrow = p.queries + (size_t)qc * p.q_stride;
+#pragma unroll
+        for (int t = 0; t < TS; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[t * 8 + j] = qrow[16 * t + 8 * h + j];
+    }
+    uint64_t T = 0;
+    float Tf = 0.0f;
+    if (p.filter) {
+        T = p.thr[qc];
+        Tf = bf_thr_float(T);
+    }
+    const bool qvalid = q < p.nq;
+
+    float4 stg[STG];
+    auto load_tile = [&](uint32_t tile) {
+#pragma unroll
+        for (int s = 0; s < STG; ++s) {
+            const uint32_t e = tid + s * 256u;
+            if (e < (uint32_t)V4_PER_TILE) {
+                const uint32_t r = e / V4_PER_ROW, c4 = e - r * V4_PER_ROW;
+                const uint32_t vr = min(tile * 32u + r, p.nrows - 1u);
+                stg[s] = *reinterpret_cast<const float4 *>(
+                    ix.rows + (size_t)vr * p.row_mult * ix.stride + 4u * c4);
+            }
+        }
+    };
+    auto store_tile = [&](uint32_t buf) {
+#pragma unroll
+        for (int s = 0; s < STG; ++s) {
+            const uint32_t e = tid + s * 256u;
+            if (e < (uint32_t)V4_PER_TILE) {
+                const uint32_t r = e / V4_PER_ROW, c4 = e - r * V4_PER_ROW;
+                *reinterpret_cast<float4 *>(xs + (size_t)buf * 32 * LDX + r * LDX + 4u * c4) = stg[s];
+            }
+        }
+    };
+
+    uint32_t tile = x;
+    if (tile >= ntiles) return;   // uniform per block
+    load_tile(tile);
+    store_tile(0);
+    __syncthreads();
+    uint32_t buf = 0;
+    for (; tile < ntiles; tile += nx) {
+        const uint32_t next = tile + nx;
+        if (next < ntiles) load_tile(next);
+
+        f32x16 acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        const float *xrow = xs + (size_t)buf * 32 * LDX + li * LDX + 8u * h;
+#pragma unroll
+        for (int t = 0; t < TS; ++t) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(xrow + 16 * t);
+            const float4 a1 = *reinterpret_cast<const float4 *>(xrow + 16 * t + 4);
+            const float xa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j], qf[t * 8 + j], acc[j], 0, 0, 0);
+        }
+        // epilogue: horizontal_sum_f32_avx2 tree, negate, emit
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float s0 = acc[0][r] + acc[4][r], s1 = acc[1][r] + acc[5][r];
+            const float s2 = acc[2][r] + acc[6][r], s3 = acc[3][r] + acc[7][r];
+            const float dist = -((s0 + s1) + (s2 + s3));
+            const uint32_t vrow = tile * 32u + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (qvalid && vrow < p.nrows) bf_emit(p, q, vrow, dist, Tf, T);
+        }
+        if (next < ntiles) store_tile(buf ^ 1u);
+        __syncthreads();
+        buf ^= 1u;
+    }
+}
+
+// =====================================================================================
+// threshold from the sample matrix [nq][ns]; when the sample is the whole dataset
+// (row_mult == 1, ns == n) the sorted sample IS the answer and is written directly.
+// =====================================================================================
+__global__ __launch_bounds__(kBfSelectThreads) void bf_threshold_kernel(
+    const float *__restrict__ sample, uint32_t ns, uint32_t row_mult, uint32_t k, int direct,
+    uint64_t *__restrict__ thr, uint32_t *__restrict__ out_idx, float *__restrict__ out_dist,
+    uint32_t *__restrict__ out_count) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    uint32_t n2 = 1;
+    while (n2 < ns) n2 <<= 1;
+    for (uint32_t i = tid; i < n2; i += nt)
+        skeys[i] = (i < ns) ? make_key(sample[(size_t)q * ns + i], i * row_mult) : SCANN_KEY_MAX;
+    __syncthreads();
+    bitonic_sort_lds(skeys, n2);
+    if (direct) {
+        const uint32_t nout = min(k, ns);
+        for (uint32_t i = tid; i < k; i += nt) {
+            out_idx[(size_t)q * k + i] = (i < nout) ? (uint32_t)skeys[i] : kBfInvalid;
+            out_dist[(size_t)q * k + i] =
+                (i < nout) ? ordered_to_f32((uint32_t)(skeys[i] >> 32)) : __builtin_inff();
+        }
+        if (tid == 0) out_count[q] = nout;
+    } else if (tid == 0) {
+        thr[q] = (ns >= k && k > 0) ? skeys[k - 1] : SCANN_KEY_MAX;
+    }
+}
+
+// In-place stable compaction (keys <= T) by one block.
+__device__ static uint32_t bf_block_compact_le(uint64_t *list, uint32_t cnt, uint64_t T,
+                                               uint32_t *s_wave, uint32_t *s_base) {
+    const uint32_t tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, nw = nt >> 6;
+    if (tid == 0) *s_base = 0;
+    __syncthreads();
+    for (uint32_t b = 0; b < cnt; b += nt) {
+        const uint32_t i = b + tid;
+        uint64_t key = 0;
+        bool keep = false;
+        if (i < cnt) {
+            key = list[i];
+            keep = key <= T;
+        }
+        uint32_t wtot;
+        const uint32_t wpre = wave_prefix_count(keep, &wtot);
+        if ((tid & 63u) == 0) s_wave[wave] = wtot;
+        __syncthreads();
+        uint32_t off = *s_base;
+        for (uint32_t w = 0; w < wave; ++w) off += s_wave[w];
+        if (keep) list[off + wpre] = key;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t t = 0;
+            for (uint32_t w = 0; w < nw; ++w) t += s_wave[w];
+            *s_base += t;
+        }
+        __syncthreads();
+    }
+    return *s_base;
+}
+
+__global__ __launch_bounds__(kBfSelectThreads) void bf_select_kernel(
+    uint32_t k, uint32_t cap, uint32_t *__restrict__ cand_cnt, uint64_t *__restrict__ cand,
+    uint32_t *__restrict__ counters, uint32_t *__restrict__ out_idx, float *__restrict__ out_dist,
+    uint32_t *__restrict__ out_count) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];   // [kBfSortCap]
+    uint32_t *s_wave = reinterpret_cast<uint32_t *>(skeys + kBfSortCap);
+    uint32_t *s_base = s_wave + kBfSelectThreads / 64;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    uint32_t cnt = cand_cnt[q];
+    uint64_t *list = cand + (size_t)q * cap;
+    bool bad = cnt > cap;
+    while (!bad && cnt > kBfSortCap) {
+        const uint32_t stride = (cnt + kBfSortCap / 2 - 1) / (kBfSortCap / 2);
+        const uint32_t ns = (cnt + stride - 1) / stride;
+        uint32_t n2 = 1;
+        while (n2 < ns) n2 <<= 1;
+        for (uint32_t i = tid; i < n2; i += nt)
+            skeys[i] = (i < ns) ? list[(size_t)i * stride] : SCANN_KEY_MAX;
+        __syncthreads();
+        bitonic_sort_lds(skeys, n2);
+        const uint64_t T = (ns >= k) ? skeys[k - 1] : SCANN_KEY_MAX;
+        __syncthreads();
+        const uint32_t nc = bf_block_compact_le(list, cnt, T, s_wave, s_base);
+        __syncthreads();
+        if (nc >= cnt) bad = true; else cnt = nc;
+    }
+    if (bad) {
+        if (tid == 0) {
+            atomicMax(&counters[BF_CNT_STATUS], (uint32_t)SCANN_HIP_RESOURCE_EXHAUSTED);
+            out_count[q] = 0;
+        }
+        return;
+    }
+    uint32_t n2 = 1;
+    while (n2 < cnt) n2 <<= 1;
+    for (uint32_t i = tid; i < n2; i += nt) skeys[i] = (i < cnt) ? list[i] : SCANN_KEY_MAX;
+    __syncthreads();
+    bitonic_sort_lds(skeys, n2);
+    const uint32_t nout = min(k, cnt);
+    for (uint32_t i = tid; i < k; i += nt) {
+        out_idx[(size_t)q * k + i] = (i < nout) ? (uint32_t)skeys[i] : kBfInvalid;
+        out_dist[(size_t)q * k + i] =
+            (i < nout) ? ordered_to_f32((uint32_t)(skeys[i] >> 32)) : __builtin_inff();
+    }
+    if (tid == 0) out_count[q] = nout;
+}
+
+// =====================================================================================
+// host side
+// =====================================================================================
+#define LAUNCH_CHECK()                                                                \
+    do {                                                                              \
+        hipError_t _e = hipGetLastError();                                            \
+        if (_e != hipSuccess)                                                         \
+            return fail(SCANN_HIP_INTERNAL, std::string("kernel launch: ") + hipGetErrorString(_e)); \
+    } while (0)
+
+template <typename F>
+static int set_dyn_lds(F kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        SCANN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)bytes));
+    return SCANN_HIP_OK;
+}
+
+static int g_num_cus = 0;
+static int num_cus() {
+    if (!g_num_cus) {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        g_num_cus = cus;
+    }
+    return g_num_cus;
+}
+
+template <int TS>
+static int launch_mfma(const BfIndexDev &ix, const BfPass &p, hipStream_t st) {
+    const uint32_t ny = ceil_div_u32(p.nq, 128);
+    const uint32_t ntiles = ceil_div_u32(p.nrows, 32);
+    uint32_t want = std::max<uint32_t>(1, (2u * (uint32_t)num_cus()) / ny);
+    want = std::min(want, ntiles);
+    const uint32_t nx = 8u * ceil_div_u32(want, 8);
+    const size_t lds = (size_t)2 * 32 * (TS * 16 + 4) * sizeof(float);
+    SCANN_TRY(set_dyn_lds(bf_mfma_dot_kernel<TS>, lds));
+    hipLaunchKernelGGL(bf_mfma_dot_kernel<TS>, dim3(nx * ny), dim3(256), lds, st, ix, p, nx, ny);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+static bool mfma_eligible(const BfIndexDev &ix) {
+    if (ix.measure != SCANN_HIP_DOT_PRODUCT) return false;
+    if ((ix.stride & 3u) || (reinterpret_cast<uintptr_t>(ix.rows) & 15u)) return false;
+    switch (ix.dim) {
+        case 16: case 32: case 48: case 64: case 96: case 128: case 192: case 256: return true;
+        default: return false;
+    }
+}
+
+static int launch_pass(const BfIndexDev &ix, const BfPass &p, hipStream_t st) {
+    if (p.nq == 0 || p.nrows == 0) return SCANN_HIP_OK;
+    if (mfma_eligible(ix)) {
+        switch (ix.dim / 16) {
+            case 1: return launch_mfma<1>(ix, p, st);
+            case 2: return launch_mfma<2>(ix, p, st);
+            case 3: return launch_mfma<3>(ix, p, st);
+            case 4: return launch_mfma<4>(ix, p, st);
+            case 6: return launch_mfma<6>(ix, p, st);
+            case 8: return launch_mfma<8>(ix, p, st);
+            case 12: return launch_mfma<12>(ix, p, st);
+            case 16: return launch_mfma<16>(ix, p, st);
+        }
+    }
+    const uint32_t dimp = (ix.dim + 3u) & ~3u;
+    const size_t lds = (size_t)kBfGenQT * dimp * sizeof(float);
+    dim3 grid(ceil_div_u32(p.nrows, 256), ceil_div_u32(p.nq, kBfGenQT));
+    switch (ix.measure) {
+        case SCANN_HIP_SQUARED_L2:
+            SCANN_TRY(set_dyn_lds(bf_generic_kernel<SCANN_HIP_SQUARED_L2>, lds));
+            hipLaunchKernelGGL(bf_generic_kernel<SCANN_HIP_SQUARED_L2>, grid, dim3(256), lds, st, ix, p);
+            break;
+        case SCANN_HIP_L2:
+            SCANN_TRY(set_dyn_lds(bf_generic_kernel<SCANN_HIP_L2>, lds));
+            hipLaunchKernelGGL(bf_generic_kernel<SCANN_HIP_L2>, grid, dim3(256), lds, st, ix, p);
+            break;
+        default:
+            SCANN_TRY(set_dyn_lds(bf_generic_kernel<SCANN_HIP_DOT_PRODUCT>, lds));
+            hipLaunchKernelGGL(bf_generic_kernel<SCANN_HIP_DOT_PRODUCT>, grid, dim3(256), lds, st, ix, p);
+            break;
+    }
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+struct BfPlan {
+    uint32_t k, ns, rs, cap;
+    bool direct;
+};
+
+static int make_plan(const BfIndexDev &ix, uint32_t k, bool full_cap, BfPlan *pl) {
+    const uint32_t n = (uint32_t)ix.n;
+    k = std::min(k, n);  // brute_force/searcher.rs:91
+    if (k > kBfMaxK)
+        return fail(SCANN_HIP_UNIMPLEMENTED, "k > " + std::to_string(kBfMaxK) + " on the GPU path");
+    pl->k = k;
+    pl->direct = n <= kBfSampleRows;
+    pl->ns = std::min(n, kBfSampleRows);
+    pl->rs = pl->direct ? 1u : n / kBfSampleRows;
+    const uint64_t cap = full_cap ? n : std::min<uint64_t>(n, 2ull * k * pl->rs + 16ull * pl->rs + 256ull);
+    pl->cap = (uint32_t)cap;
+    return SCANN_HIP_OK;
+}
+
+static int ensure_ws(const BfIndexDev &ix, BfWorkspace &w, uint32_t nq, const BfPlan &pl,
+                     bool own_q, uint32_t q_stride, bool own_out) {
+    (void)ix;
+    if (own_q) SCANN_TRY(w.queries.ensure((size_t)nq * q_stride * 4));
+    SCANN_TRY(w.sample.ensure((size_t)nq * pl.ns * 4));
+    SCANN_TRY(w.thr.ensure((size_t)nq * 8));
+    SCANN_TRY(w.cand_cnt.ensure((size_t)nq * 4));
+    if (!pl.direct) SCANN_TRY(w.cand.ensure((size_t)nq * pl.cap * 8));
+    SCANN_TRY(w.counters.ensure(BF_CNT_N * 4));
+    if (own_out) {
+        SCANN_TRY(w.out_idx.ensure((size_t)nq * std::max(1u, pl.k) * 4));
+        SCANN_TRY(w.out_dist.ensure((size_t)nq * std::max(1u, pl.k) * 4));
+        SCANN_TRY(w.out_count.ensure((size_t)nq * 4));
+    }
+    return SCANN_HIP_OK;
+}
+
+int bf_reserve(const BfIndexDev &ix, BfWorkspace &w, uint32_t max_nq, uint32_t max_k) {
+    if (ix.n == 0) return SCANN_HIP_OK;
+    BfPlan pl;
+    SCANN_TRY(make_plan(ix, max_k, false, &pl));
+    return ensure_ws(ix, w, max_nq, pl, false, 0, false);
+}
+
+// k_out: row pitch of the caller's output arrays (the caller's k, >= pl.k).
+static int enqueue_search(const BfIndexDev &ix, BfWorkspace &w, const BfPlan &pl,
+                          const float *d_queries, uint32_t nq, uint32_t q_stride,
+                          uint32_t *d_out_idx, float *d_out_dist, uint32_t *d_out_count,
+                          hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    SCANN_HIP_CHECK(hipMemsetAsync(w.counters.p, 0, BF_CNT_N * 4, st));
+    BfPass a{};
+    a.queries = d_queries;
+    a.nq = nq;
+    a.q_stride = q_stride;
+    a.nrows = pl.ns;
+    a.row_mult = pl.rs;
+    a.filter = 0;
+    a.out = w.sample.as<float>();
+    a.ld = pl.ns;
+    if (pl.direct && ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
+    SCANN_TRY(launch_pass(ix, a, st));
+    if (pl.direct && ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
+    const size_t lds_thr = (size_t)next_pow2_u32(pl.ns) * 8;
+    SCANN_TRY(set_dyn_lds(bf_threshold_kernel, lds_thr));
+    hipLaunchKernelGGL(bf_threshold_kernel, dim3(nq), dim3(kBfSelectThreads), lds_thr, st,
+                       w.sample.as<float>(), pl.ns, pl.rs, pl.k, pl.direct ? 1 : 0,
+                       w.thr.as<uint64_t>(), d_out_idx, d_out_dist, d_out_count);
+    LAUNCH_CHECK();
+    if (pl.direct) return SCANN_HIP_OK;
+
+    SCANN_HIP_CHECK(hipMemsetAsync(w.cand_cnt.p, 0, (size_t)nq * 4, st));
+    BfPass b = a;
+    b.nrows = (uint32_t)ix.n;
+    b.row_mult = 1;
+    b.filter = 1;
+    b.out = nullptr;
+    b.ld = 0;
+    b.thr = w.thr.as<uint64_t>();
+    b.cand_cnt = w.cand_cnt.as<uint32_t>();
+    b.cand = w.cand.as<uint64_t>();
+    b.cap = pl.cap;
+    if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
+    SCANN_TRY(launch_pass(ix, b, st));
+    if (ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
+    const size_t lds_sel = (size_t)kBfSortCap * 8 + (kBfSelectThreads / 64 + 4) * 4;
+    SCANN_TRY(set_dyn_lds(bf_select_kernel, lds_sel));
+    hipLaunchKernelGGL(bf_select_kernel, dim3(nq), dim3(kBfSelectThreads), lds_sel, st, pl.k, pl.cap,
+                       w.cand_cnt.as<uint32_t>(), w.cand.as<uint64_t>(), w.counters.as<uint32_t>(),
+                       d_out_idx, d_out_dist, d_out_count);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+int bf_search_device(const BfIndexDev &ix, BfWorkspace &w, const float *d_queries, uint32_t nq,
+                     uint32_t q_stride, uint32_t k, uint32_t *d_out_idx, float *d_out_dist,
+                     uint32_t *d_out_count, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    if (ix.n == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "empty dataset on the device path");
+    BfPlan pl;
+    SCANN_TRY(make_plan(ix, k, false, &pl));
+    if (pl.k != k)
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "k > dataset size on the device path (row pitch)");
+    SCANN_TRY(ensure_ws(ix, w, nq, pl, false, q_stride, false));
+    return enqueue_search(ix, w, pl, d_queries, nq, q_stride, d_out_idx, d_out_dist, d_out_count, st,
+                          ev0, ev1);
+}
+
+int bf_search_host(const BfIndexDev &ix, BfWorkspace &w, const float *queries, uint32_t nq,
+                   uint32_t q_stride, uint32_t k, uint32_t *out_idx, float *out_dist,
+                   uint32_t *out_count, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        BfPlan pl;
+        SCANN_TRY(make_plan(ix, k, attempt == 1, &pl));
+        SCANN_TRY(ensure_ws(ix, w, nq, pl, true, q_stride, true));
+        SCANN_HIP_CHECK(hipMemcpyAsync(w.queries.p, queries, (size_t)nq * q_stride * 4,
+                                       hipMemcpyHostToDevice, st));
+        SCANN_TRY(enqueue_search(ix, w, pl, w.queries.as<float>(), nq, q_stride,
+                                 w.out_idx.as<uint32_t>(), w.out_dist.as<float>(),
+                                 w.out_count.as<uint32_t>(), st, ev0, ev1));
+        uint32_t counters[BF_CNT_N];
+        SCANN_HIP_CHECK(hipMemcpyAsync(counters, w.counters.p, sizeof(counters), hipMemcpyDeviceToHost, st));
+        std::vector<uint32_t> ti((size_t)nq * pl.k);
+        std::vector<float> td((size_t)nq * pl.k);
+        SCANN_HIP_CHECK(hipMemcpyAsync(ti.data(), w.out_idx.p, ti.size() * 4, hipMemcpyDeviceToHost, st));
+        SCANN_HIP_CHECK(hipMemcpyAsync(td.data(), w.out_dist.p, td.size() * 4, hipMemcpyDeviceToHost, st));
+        SCANN_HIP_CHECK(hipMemcpyAsync(out_count, w.out_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+        SCANN_HIP_CHECK(hipStreamSynchronize(st));
+        if (counters[BF_CNT_STATUS] == SCANN_HIP_OK) {
+            for (uint32_t q = 0; q < nq; ++q)       // caller's rows have pitch k
+                for (uint32_t i = 0; i < k; ++i) {
+                    out_idx[(size_t)q * k + i] = i < pl.k ? ti[(size_t)q * pl.k + i] : kBfInvalid;
+                    out_dist[(size_t)q * k + i] = i < pl.k ? td[(size_t)q * pl.k + i] : INFINITY;
+                }
+            return SCANN_HIP_OK;
+        }
+        if (counters[BF_CNT_STATUS] != SCANN_HIP_RESOURCE_EXHAUSTED || attempt == 1)
+            return fail((int)counters[BF_CNT_STATUS], "device reported a search failure");
+    }
+    return fail(SCANN_HIP_INTERNAL, "unreachable");
+}
+
+int bf_distances_host(const BfIndexDev &ix, BfWorkspace &w, const float *queries, uint32_t nq,
+                      uint32_t q_stride, float *out, hipStream_t st) {
+    DevBuf dq, dout;
+    (void)w;
+    SCANN_TRY(upload(dq, queries, (size_t)nq * q_stride * 4));
+    SCANN_TRY(dout.ensure((size_t)nq * ix.n * 4));
+    BfPass a{};
+    a.queries = dq.as<float>();
+    a.nq = nq;
+    a.q_stride = q_stride;
+    a.nrows = (uint32_t)ix.n;
+    a.row_mult = 1;
+    a.filter = 0;
+    a.out = dout.as<float>();
+    a.ld = (uint32_t)ix.n;
+    SCANN_TRY(launch_pass(ix, a, st));
+    SCANN_HIP_CHECK(hipMemcpyAsync(out, dout.p, (size_t)nq * ix.n * 4, hipMemcpyDeviceToHost, st));
+    SCANN_HIP_CHECK(hipStreamSynchronize(st));
+    return SCANN_HIP_OK;
+}
+
+}  // namespace scann

@@ -1,0 +1,96 @@
+// txh.h -- device-side views + launchers of the Tree-X-Hybrid / AsymmetricHasher path.
+#pragma once
+#include "common.h"
+
+namespace scann {
+
+// Tunables of the scan decomposition (see DESIGN.md "Leaf scan").
+constexpr uint32_t kScanThreads = 256;
+constexpr uint32_t kScanPPT = 4;                          // points per thread per chunk
+constexpr uint32_t kScanTP = kScanThreads * kScanPPT;     // points per tile chunk
+constexpr uint32_t kScanQuadsPerTile = 32;                // query quads per tile
+constexpr uint32_t kSortCap = 8192;                       // u64 keys sorted in LDS
+constexpr uint32_t kSampleCap = 8192;                     // threshold sample size (keys)
+constexpr uint32_t kMaxPreReorderK = 2048;                // m limit of the LDS select
+constexpr uint32_t kMaxLeavesSelect = 16384;              // L limit of the LDS leaf sort
+constexpr uint32_t kSelectThreads = 1024;
+constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+
+struct TxhIndexDev {
+    uint32_t dim, stride, L, S, K, dsub, nw;
+    uint64_t n_local;
+    const float *centers;         // [L][dim]; nullptr in AsymmetricHasher mode
+    const uint32_t *leaf_off;     // [L+1] local CSR offsets
+    const uint32_t *leaf_gsize;   // [L] global leaf sizes (== local when unsharded)
+    const uint32_t *leaf_ids;     // [n_local] datapoint index of CSR row; nullptr = identity
+    const uint32_t *codes;        // [n_local][nw] packed 4-bit codes, 8 subspaces per word
+    const float *rows;            // re-rank rows; CSR order if rows_csr else by datapoint idx
+    int rows_csr;
+    const float *codebook;        // [S][K][dsub]
+    int use_residuals;
+    int ah_mode;                  // single implicit leaf, no centroid stage
+};
+
+// counters[] slots
+enum { CNT_TOTAL_QUADS = 0, CNT_TOTAL_TILES = 1, CNT_QUEUE_HEAD = 2, CNT_STATUS = 3, CNT_N = 8 };
+
+struct TxhWork {
+    uint32_t nq, q_stride, P, m, k, cap;
+    int exact_reorder;
+    const float *queries;      // device
+    float *cdist;              // [nq][L]
+    uint32_t *tokens;          // [nq][P]
+    float *token_dists;        // [nq][P]
+    uint32_t *vbase;           // [nq][P+1] prefix of global leaf sizes in token order
+    uint32_t *leaf_cnt;        // [L]
+    uint32_t *leaf_cursor;     // [L]
+    uint32_t *pair_off;        // [L+1] (slots, padded to quads)
+    uint32_t *tile_off;        // [L+1]
+    uint32_t *counters;        // [CNT_N]
+    uint32_t *pair_q;          // [max_slots]
+    uint32_t *pair_leaf;       // [max_slots]
+    uint32_t *pair_vbase;      // [max_slots]
+    uint32_t *slot_of;         // [nq][P]
+    uint32_t max_slots, max_quads;
+    float *lutq;               // [max_quads][S][16][4]
+    uint64_t *thr;             // [nq]
+    uint32_t *cand_cnt;        // [nq]
+    uint64_t *cand;            // [nq][cap]
+    uint64_t *cand_key;        // [nq][m] selected merge keys
+    uint32_t *cand_idx;        // [nq][m]
+    float *cand_dist;          // [nq][m] approximate
+    float *cand_exact;         // [nq][m]
+    uint32_t *cand_count;      // [nq]
+    uint32_t *out_idx;         // [nq][k]
+    float *out_dist;           // [nq][k]
+    uint32_t *out_count;       // [nq]
+};
+
+// Enqueue the whole search pipeline on `stream`.  local_only: stop after the local
+// top-m + exact distances (multi-GPU local stage).
+int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only,
+                      hipStream_t stream, hipEvent_t ev_scan_begin, hipEvent_t ev_scan_end);
+
+int txh_launch_partition_only(const TxhIndexDev &ix, const TxhWork &w, hipStream_t stream);
+
+int txh_launch_merge(uint32_t world, uint32_t nq, uint32_t m, uint32_t k,
+                     const uint64_t *d_keys, const uint32_t *d_idx, const float *d_exact,
+                     const uint32_t *d_count, uint32_t *d_out_idx, float *d_out_dist,
+                     uint32_t *d_out_count, hipStream_t stream);
+
+int txh_launch_lut_from_query(const TxhIndexDev &ix, const float *d_queries, uint32_t nq,
+                              uint32_t q_stride, const uint32_t *d_leaf_for_query,
+                              float *d_out_lut, hipStream_t stream);
+
+int txh_launch_adc_distances(const TxhIndexDev &ix, const float *d_luts, uint32_t nq,
+                             float *d_out, hipStream_t stream);
+
+int launch_lut16_u8_batch(const uint8_t *d_packed, const uint8_t *d_lut8, uint32_t S,
+                          uint64_t n, float bias, float mult, float *d_out,
+                          hipStream_t stream);
+
+int launch_encode(const float *d_codebook, uint32_t S, uint32_t K, uint32_t dsub,
+                  const float *d_rows, uint64_t n, uint32_t stride, const float *d_centers,
+                  const uint32_t *d_leaf_of_row, uint8_t *d_out, hipStream_t stream);
+
+}  // namespace scann

@@ -1,0 +1,1119 @@
+// txh.hip -- HIP kernels of the Tree-X-Hybrid / AsymmetricHasher search path (gfx950).
+//
+// Pipeline per query batch (reference: tree_x_hybrid/mod.rs:245-364):
+//   centroid_scores -> select_leaves            TreePartitioner::partition
+//   count/scan/fill worklist                    (groups (query, leaf) pairs by leaf)
+//   lut_build                                   residual + LookupTable::from_query
+//   sample_threshold                            valid upper bound of the m-th best key
+//   adc_scan (dominant, LDS-staged LUT16)       LookupTable::compute_distance + FastTopNeighbors
+//   select_rerank                               merge/sort/truncate + reorder_results
+//
+// All arithmetic that the reference performs in a fixed order is performed in the same
+// order here; this file is compiled with -ffp-contract=off and uses fmaf() only where
+// the reference uses _mm256_fmadd_ps.
+#include "txh.h"
+
+namespace scann {
+
+// =====================================================================================
+// K1: centroid scores.  partitioning/tree_partitioner.rs:175-192: strictly sequential
+// scalar sum of (q_j - c_j)^2, no FMA.  One thread per centroid, QT queries per block
+// broadcast from LDS.
+// =====================================================================================
+constexpr int kCsQT = 16;
+
+__global__ __launch_bounds__(64) void centroid_scores_kernel(
+    const float *__restrict__ centers, uint32_t L, uint32_t dim,
+    const float *__restrict__ queries, uint32_t nq, uint32_t q_stride,
+    float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float qs[];  // [kCsQT][dim]
+    const uint32_t q0 = blockIdx.y * kCsQT;
+    for (uint32_t i = threadIdx.x; i < kCsQT * dim; i += blockDim.x) {
+        uint32_t qi = i / dim, j = i - qi * dim;
+        qs[i] = (q0 + qi < nq) ? queries[(size_t)(q0 + qi) * q_stride + j] : 0.0f;
+    }
+    __syncthreads();
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= L) return;
+    float acc[kCsQT];
+#pragma unroll
+    for (int qi = 0; qi < kCsQT; ++qi) acc[qi] = 0.0f;
+    const float *crow = centers + (size_t)c * dim;
+    if ((dim & 3u) == 0) {
+        for (uint32_t j = 0; j < dim; j += 4) {
+            const float4 cv = *reinterpret_cast<const float4 *>(crow + j);
+#pragma unroll
+            for (int qi = 0; qi < kCsQT; ++qi) {
+                const float4 qv = *reinterpret_cast<const float4 *>(qs + qi * dim + j);
+                float d0 = qv.x - cv.x, d1 = qv.y - cv.y, d2 = qv.z - cv.z, d3 = qv.w - cv.w;
+                float a = acc[qi];
+                a = a + d0 * d0;
+                a = a + d1 * d1;
+                a = a + d2 * d2;
+                a = a + d3 * d3;
+                acc[qi] = a;
+            }
+        }
+    } else {
+        for (uint32_t j = 0; j < dim; ++j) {
+            const float cv = crow[j];
+#pragma unroll
+            for (int qi = 0; qi < kCsQT; ++qi) {
+                float d = qs[qi * dim + j] - cv;
+                acc[qi] = acc[qi] + d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int qi = 0; qi < kCsQT; ++qi)
+        if (q0 + qi < nq) out[(size_t)(q0 + qi) * L + c] = acc[qi];
+}
+
+// =====================================================================================
+// K2: select leaves.  tree_partitioner.rs:206-228: stable sort of ALL L (dist, id) by
+// OrderedFloat(dist), take the first P.  Key = (ordered(dist) << 32 | id) makes the
+// stable order explicit; NaN sorts last as OrderedFloat does.
+// =====================================================================================
+__global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
+    const float *__restrict__ cdist, uint32_t L, uint32_t n_pow2, uint32_t P,
+    const uint32_t *__restrict__ leaf_gsize, uint32_t *__restrict__ tokens,
+    float *__restrict__ token_dists, uint32_t *__restrict__ vbase) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
+    const uint32_t q = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < n_pow2; i += blockDim.x) {
+        uint64_t key = SCANN_KEY_MAX;
+        if (i < L) {
+            float d = cdist[(size_t)q * L + i];
+            uint32_t o = (d != d) ? 0xFFFFFFFFu : f32_to_ordered(d);
+            key = ((uint64_t)o << 32) | i;
+        }
+        skeys[i] = key;
+    }
+    __syncthreads();
+    bitonic_sort_lds(skeys, n_pow2);
+    for (uint32_t r = threadIdx.x; r < P; r += blockDim.x) {
+        uint64_t key = skeys[r];
+        uint32_t id = (uint32_t)key;
+        tokens[(size_t)q * P + r] = id;
+        token_dists[(size_t)q * P + r] = cdist[(size_t)q * L + id];
+    }
+    if (threadIdx.x == 0) {
+        uint32_t vb = 0;
+        for (uint32_t r = 0; r < P; ++r) {
+            vbase[(size_t)q * (P + 1) + r] = vb;
+            vb += leaf_gsize[(uint32_t)skeys[r]];
+        }
+        vbase[(size_t)q * (P + 1) + P] = vb;
+    }
+}
+
+// AsymmetricHasher mode: one implicit leaf (id 0) for every query.
+__global__ void ah_tokens_kernel(uint32_t nq, const uint32_t *__restrict__ leaf_gsize,
+                                 uint32_t *__restrict__ tokens, float *__restrict__ token_dists,
+                                 uint32_t *__restrict__ vbase) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    tokens[q] = 0;
+    token_dists[q] = 0.0f;
+    vbase[2 * q] = 0;
+    vbase[2 * q + 1] = leaf_gsize[0];
+}
+
+// =====================================================================================
+// K3: worklist -- group (query, rank) pairs by leaf so that every leaf's codes are read
+// once per batch and shared by all queries that selected it.
+// =====================================================================================
+__global__ void worklist_count_kernel(uint32_t npairs, const uint32_t *__restrict__ tokens,
+                                      const uint32_t *__restrict__ leaf_off,
+                                      uint32_t *__restrict__ leaf_cnt) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npairs) return;
+    uint32_t leaf = tokens[i];
+    if (leaf_off[leaf + 1] > leaf_off[leaf]) atomicAdd(&leaf_cnt[leaf], 1u);
+}
+
+__global__ __launch_bounds__(1024) void worklist_scan_kernel(
+    uint32_t L, const uint32_t *__restrict__ leaf_cnt, const uint32_t *__restrict__ leaf_off,
+    uint32_t tp, uint32_t quads_per_tile, uint32_t *__restrict__ pair_off,
+    uint32_t *__restrict__ tile_off, uint32_t *__restrict__ counters) {
+    __shared__ uint32_t s_pairs[1024], s_tiles[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (L + 1023) / 1024;
+    const uint32_t b = t * per, e = min(L, b + per);
+    uint32_t sp = 0, stl = 0;
+    for (uint32_t l = b; l < e; ++l) {
+        uint32_t c = leaf_cnt[l];
+        uint32_t pad = (c + 3u) & ~3u;
+        uint32_t sz = leaf_off[l + 1] - leaf_off[l];
+        sp += pad;
+        stl += c ? ((sz + tp - 1) / tp) * ((pad / 4 + quads_per_tile - 1) / quads_per_tile) : 0u;
+    }
+    s_pairs[t] = sp;
+    s_tiles[t] = stl;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+        uint32_t a = 0, c2 = 0;
+        if (t >= off) {
+            a = s_pairs[t - off];
+            c2 = s_tiles[t - off];
+        }
+        __syncthreads();
+        s_pairs[t] += a;
+        s_tiles[t] += c2;
+        __syncthreads();
+    }
+    uint32_t bp = s_pairs[t] - sp, bt = s_tiles[t] - stl;
+    for (uint32_t l = b; l < e; ++l) {
+        uint32_t c = leaf_cnt[l];
+        uint32_t pad = (c + 3u) & ~3u;
+        uint32_t sz = leaf_off[l + 1] - leaf_off[l];
+        pair_off[l] = bp;
+        tile_off[l] = bt;
+        bp += pad;
+        bt += c ? ((sz + tp - 1) / tp) * ((pad / 4 + quads_per_tile - 1) / quads_per_tile) : 0u;
+    }
+    if (t == 1023) {
+        pair_off[L] = s_pairs[1023];
+        tile_off[L] = s_tiles[1023];
+        counters[CNT_TOTAL_QUADS] = s_pairs[1023] / 4;
+        counters[CNT_TOTAL_TILES] = s_tiles[1023];
+    }
+}
+
+__global__ void worklist_fill_kernel(uint32_t nq, uint32_t P, const uint32_t *__restrict__ tokens,
+                                     const uint32_t *__restrict__ vbase,
+                                     const uint32_t *__restrict__ leaf_off,
+                                     const uint32_t *__restrict__ pair_off,
+                                     uint32_t *__restrict__ leaf_cursor,
+                                     uint32_t *__restrict__ pair_q, uint32_t *__restrict__ pair_leaf,
+                                     uint32_t *__restrict__ pair_vbase,
+                                     uint32_t *__restrict__ slot_of) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * P) return;
+    uint32_t q = i / P, r = i - q * P;
+    uint32_t leaf = tokens[i];
+    uint32_t slot = kInvalid;
+    if (leaf_off[leaf + 1] > leaf_off[leaf]) {
+        slot = pair_off[leaf] + atomicAdd(&leaf_cursor[leaf], 1u);
+        pair_q[slot] = q;
+        pair_leaf[slot] = leaf;
+        pair_vbase[slot] = vbase[(size_t)q * (P + 1) + r];
+    }
+    slot_of[i] = slot;
+}
+
+// =====================================================================================
+// K4: LUT build.  tree_x_hybrid/mod.rs:309-319 + hashes/lut.rs:47-70 +
+// hashes/codebook.rs:98-115: q' = q - centroid (if residual); LUT[s][c] = sequential
+// scalar sum over dsub of (q'_j - cb_j)^2.  Output layout is quad-interleaved
+// [quad][s][16][4] so that the scan reads four queries' entries with one ds_read_b128.
+// =====================================================================================
+__global__ __launch_bounds__(256) void lut_build_kernel(
+    TxhIndexDev ix, const float *__restrict__ queries, uint32_t q_stride,
+    const uint32_t *__restrict__ pair_q, const uint32_t *__restrict__ pair_leaf,
+    const uint32_t *__restrict__ counters, float *__restrict__ lutq) {
+    extern __shared__ float qres[];  // [4][dim]
+    const uint32_t quad = blockIdx.x;
+    if (quad >= counters[CNT_TOTAL_QUADS]) return;
+    const uint32_t dim = ix.dim;
+    for (uint32_t i = threadIdx.x; i < 4 * dim; i += blockDim.x) {
+        uint32_t p = i / dim, j = i - p * dim;
+        uint32_t q = pair_q[quad * 4 + p];
+        float v = 0.0f;
+        if (q != kInvalid) {
+            v = queries[(size_t)q * q_stride + j];
+            if (ix.use_residuals) v = v - ix.centers[(size_t)pair_leaf[quad * 4 + p] * dim + j];
+        }
+        qres[i] = v;
+    }
+    __syncthreads();
+    const uint32_t S = ix.S, K = ix.K, dsub = ix.dsub;
+    float4 *out = reinterpret_cast<float4 *>(lutq) + (size_t)quad * S * 16;
+    for (uint32_t e = threadIdx.x; e < S * 16; e += blockDim.x) {
+        uint32_t s = e >> 4, c = e & 15u;
+        float r[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (c < K) {
+            const float *cb = ix.codebook + ((size_t)s * K + c) * dsub;
+            for (uint32_t j = 0; j < dsub; ++j) {
+                float cv = cb[j];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float d = qres[p * dim + s * dsub + j] - cv;
+                    r[p] = r[p] + d * d;
+                }
+            }
+        }
+        out[e] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+// Plain LookupTable::from_query for callers/tests: out [nq][S][K].
+__global__ __launch_bounds__(256) void lut_from_query_kernel(
+    TxhIndexDev ix, const float *__restrict__ queries, uint32_t q_stride,
+    const uint32_t *__restrict__ leaf_for_query, float *__restrict__ out) {
+    extern __shared__ float qres[];  // [dim]
+    const uint32_t q = blockIdx.x, dim = ix.dim;
+    for (uint32_t j = threadIdx.x; j < dim; j += blockDim.x) {
+        float v = queries[(size_t)q * q_stride + j];
+        if (leaf_for_query) v = v - ix.centers[(size_t)leaf_for_query[q] * dim + j];
+        qres[j] = v;
+    }
+    __syncthreads();
+    const uint32_t S = ix.S, K = ix.K, dsub = ix.dsub;
+    for (uint32_t e = threadIdx.x; e < S * K; e += blockDim.x) {
+        uint32_t s = e / K;
+        const float *cb = ix.codebook + (size_t)e * dsub;
+        float r = 0.0f;
+        for (uint32_t j = 0; j < dsub; ++j) {
+            float d = qres[s * dsub + j] - cb[j];
+            r = r + d * d;
+        }
+        out[(size_t)q * S * K + e] = r;
+    }
+}
+
+// Sequential LUT sum for one packed code row against a [S][16] f32 table in LDS.
+// hashes/lut.rs:74-82: sum = 0.0; for s ascending: sum += lut[s][code[s]].
+template <int NW>
+__device__ __forceinline__ float adc_row_sum(const float *lut, const uint32_t *w) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int wi = 0; wi < NW; ++wi) {
+        uint32_t x = w[wi];
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+            uint32_t code = (x >> (4 * nb)) & 15u;
+            acc = acc + lut[(wi * 8 + nb) * 16 + code];
+        }
+    }
+    return acc;
+}
+
+// =====================================================================================
+// K5: threshold from a strided sample.  Any subset's m-th smallest key is an upper bound
+// of the stream's m-th smallest key, so filtering with `key <= thr` keeps every member
+// of the exact top-m; the sample only controls how many extra candidates survive.
+// =====================================================================================
+template <int NW>
+__global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(
+    TxhIndexDev ix, uint32_t P, uint32_t m, const uint32_t *__restrict__ tokens,
+    const uint32_t *__restrict__ vbase, const uint32_t *__restrict__ slot_of,
+    const float *__restrict__ lutq, uint64_t *__restrict__ thr) {
+    constexpr int S = NW * 8;
+    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];      // [kSampleCap]
+    float *slut = reinterpret_cast<float *>(skeys + kSampleCap);          // [S*16]
+    uint32_t *s_total = reinterpret_cast<uint32_t *>(slut + S * 16);      // [4]
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) {
+        uint32_t tot = 0;
+        for (uint32_t r = 0; r < P; ++r) {
+            uint32_t leaf = tokens[(size_t)q * P + r];
+            tot += ix.leaf_off[leaf + 1] - ix.leaf_off[leaf];
+        }
+        s_total[0] = tot;
+    }
+    __syncthreads();
+    const uint32_t total = s_total[0];
+    const uint32_t room = kSampleCap - P;
+    const uint32_t st = max(1u, (total + room - 1) / room);
+    uint32_t base = 0;
+    for (uint32_t r = 0; r < P; ++r) {
+        const uint32_t leaf = tokens[(size_t)q * P + r];
+        const uint32_t lb = ix.leaf_off[leaf];
+        const uint32_t sz = ix.leaf_off[leaf + 1] - lb;
+        if (sz == 0) continue;
+        const uint32_t slot = slot_of[(size_t)q * P + r];
+        const float *src = lutq + (size_t)(slot >> 2) * S * 64 + (slot & 3u);
+        for (uint32_t e = tid; e < S * 16; e += nt) slut[e] = src[(size_t)e * 4];
+        __syncthreads();
+        const uint32_t ns = (sz + st - 1) / st;
+        const uint32_t vb = vbase[(size_t)q * (P + 1) + r];
+        for (uint32_t i = tid; i < ns; i += nt) {
+            const uint32_t j = i * st;
+            uint32_t w[NW];
+#pragma unroll
+            for (int wi = 0; wi < NW; ++wi) w[wi] = ix.codes[(size_t)(lb + j) * NW + wi];
+            skeys[base + i] = make_key(adc_row_sum<NW>(slut, w), vb + j);
+        }
+        base += ns;
+        __syncthreads();
+    }
+    const uint32_t cnt = base;
+    if (m == 0 || cnt < m) {
+        if (tid == 0) thr[q] = SCANN_KEY_MAX;
+        return;
+    }
+    uint32_t n2 = 1;
+    while (n2 < cnt) n2 <<= 1;
+    for (uint32_t i = cnt + tid; i < n2; i += nt) skeys[i] = SCANN_KEY_MAX;
+    __syncthreads();
+    bitonic_sort_lds(skeys, n2);
+    if (tid == 0) thr[q] = skeys[m - 1];
+}
+
+// =====================================================================================
+// K6: ADC scan -- the dominant kernel.  hashes/lut.rs:74-82 driven by the loop at
+// tree_x_hybrid/mod.rs:324-336 / hashes/hasher.rs:179-182.
+//
+// A tile = (leaf, chunk of kScanTP points, group of <= kScanQuadsPerTile query quads).
+// Each lane keeps the packed codes of PPT points in VGPRs (coalesced 16-B loads), and
+// for every quad reads one ds_read_b128 per (point, subspace): the 16-entry table of a
+// subspace is 16 x 16 B = all 64 LDS banks, lanes with equal codes broadcast, so the
+// gather is conflict-free.  Distances are accumulated in subspace order (bit-exact with
+// the reference) and compared with the per-query threshold; survivors are appended to
+// the query's candidate list.  Tiles are pulled from an atomic queue so ragged leaves
+// balance across the 256 CUs.
+// =====================================================================================
+template <int NW, int NP, int BUF>
+__device__ __forceinline__ void scan_quad_compute(const float4 *lut_base,
+                                                  uint32_t (&wlo)[kScanPPT][NW],
+                                                  uint32_t (&whi)[kScanPPT][NW],
+                                                  float (&acc)[4][kScanPPT]) {
+    constexpr int S = NW * 8;
+    const char *lb = reinterpret_cast<const char *>(lut_base + BUF * S * 16);
+    // The byte extractions below are invariant across the quad loop; without this
+    // (instruction-free) barrier LICM hoists all S*NP of them into registers and spills.
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+        for (int wi = 0; wi < NW; ++wi) {
+            asm volatile("" : "+v"(wlo[i][wi]));
+            asm volatile("" : "+v"(whi[i][wi]));
+        }
+    // Software pipeline, one subspace deep: the NP ds_read_b128 of subspace s+1 are in
+    // flight while subspace s is accumulated.  sched_barrier(0) pins the stage order so
+    // the scheduler cannot hoist every gather to the top (256 VGPRs, occupancy 1).
+    float4 v[2][NP];
+    auto issue = [&](int s, int slot) {
+        const int wi = s >> 3, b = (s >> 1) & 3, h = s & 1;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const uint32_t x = h ? whi[i][wi] : wlo[i][wi];
+            const uint32_t off = (x >> (8 * b)) & 0xFFu;  // code * 16
+            v[slot][i] = *reinterpret_cast<const float4 *>(lb + s * 256 + off);
+        }
+    };
+    issue(0, 0);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (s + 1 < S) issue(s + 1, (s + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const float4 t = v[s & 1][i];
+            if (s == 0) {
+                acc[0][i] = t.x; acc[1][i] = t.y; acc[2][i] = t.z; acc[3][i] = t.w;
+            } else {
+                acc[0][i] = acc[0][i] + t.x;
+                acc[1][i] = acc[1][i] + t.y;
+                acc[2][i] = acc[2][i] + t.z;
+                acc[3][i] = acc[3][i] + t.w;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+static_assert(kScanPPT == 4, "adc_scan_kernel's nsub switch assumes 4 points per thread");
+
+struct ScanArgs {
+    const uint32_t *pair_off, *tile_off, *pair_q, *pair_vbase;
+    uint32_t *counters;
+    const float *lutq;
+    const uint64_t *thr;
+    uint32_t *cand_cnt;
+    uint64_t *cand;
+    uint32_t cap;
+};
+
+template <int NW>
+__global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 4 : 2)) void adc_scan_kernel(TxhIndexDev ix, ScanArgs a) {
+    constexpr int S = NW * 8;
+    constexpr int LUT4 = S * 16;                                    // float4 per quad
+    constexpr int STG = (LUT4 + kScanThreads - 1) / kScanThreads;   // staged float4 / thread
+    __shared__ float4 lut_s[2 * LUT4];
+    __shared__ uint32_t tile_sh;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t total_tiles = a.counters[CNT_TOTAL_TILES];
+
+    for (;;) {
+        if (tid == 0) tile_sh = atomicAdd(&a.counters[CNT_QUEUE_HEAD], 1u);
+        __syncthreads();
+        const uint32_t tile = __builtin_amdgcn_readfirstlane(tile_sh);
+        if (tile >= total_tiles) break;
+
+        // leaf = largest l with tile_off[l] <= tile
+        uint32_t lo = 0, hi = ix.L;
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (a.tile_off[mid] <= tile) lo = mid; else hi = mid;
+        }
+        const uint32_t leaf = lo;
+        const uint32_t lb = ix.leaf_off[leaf];
+        const uint32_t size = ix.leaf_off[leaf + 1] - lb;
+        const uint32_t nchunks = (size + kScanTP - 1) / kScanTP;
+        const uint32_t local = tile - a.tile_off[leaf];
+        const uint32_t chunk = local % nchunks, qg = local / nchunks;
+        const uint32_t slot0 = a.pair_off[leaf];
+        const uint32_t nquads = (a.pair_off[leaf + 1] - slot0) >> 2;
+        const uint32_t q0 = qg * kScanQuadsPerTile;
+        const uint32_t q1 = min(q0 + kScanQuadsPerTile, nquads);
+        const uint32_t c0 = chunk * kScanTP;
+        const uint32_t npts = min(kScanTP, size - c0);
+        const uint32_t nsub = (npts + kScanThreads - 1) / kScanThreads;
+
+        // packed codes of this lane's points -> byte-per-subspace form (code * 16)
+        uint32_t wlo[kScanPPT][NW], whi[kScanPPT][NW];
+#pragma unroll
+        for (int i = 0; i < (int)kScanPPT; ++i) {
+            const uint32_t j = c0 + tid + kScanThreads * i;
+            const uint32_t *src = ix.codes + (size_t)(lb + (j < size ? j : 0)) * NW;
+            uint32_t w[NW];
+            if constexpr (NW == 4) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(src);
+                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            } else if constexpr (NW == 2) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(src);
+                w[0] = v.x; w[1] = v.y;
+            } else {
+#pragma unroll
+                for (int wi = 0; wi < NW; ++wi) w[wi] = src[wi];
+            }
+#pragma unroll
+            for (int wi = 0; wi < NW; ++wi) {
+                wlo[i][wi] = (w[wi] & 0x0F0F0F0Fu) << 4;
+                whi[i][wi] = w[wi] & 0xF0F0F0F0u;
+            }
+        }
+
+        const float4 *gl = reinterpret_cast<const float4 *>(a.lutq) +
+                           (size_t)((slot0 >> 2) + q0) * LUT4;
+        // stage the first quad's LUT
+        {
+            float4 r[STG];
+#pragma unroll
+            for (int t = 0; t < STG; ++t) {
+                uint32_t e = tid + t * kScanThreads;
+                if (e < (uint32_t)LUT4) r[t] = gl[e];
+            }
+#pragma unroll
+            for (int t = 0; t < STG; ++t) {
+                uint32_t e = tid + t * kScanThreads;
+                if (e < (uint32_t)LUT4) lut_s[e] = r[t];
+            }
+        }
+        __syncthreads();
+
+        for (uint32_t qd = q0; qd < q1; ++qd) {
+            const uint32_t buf = (qd - q0) & 1u;
+            const bool more = qd + 1 < q1;
+            float4 nx[STG];
+            if (more) {
+                const float4 *g2 = gl + (size_t)(qd + 1 - q0) * LUT4;
+#pragma unroll
+                for (int t = 0; t < STG; ++t) {
+                    uint32_t e = tid + t * kScanThreads;
+                    if (e < (uint32_t)LUT4) nx[t] = g2[e];
+                }
+            }
+
+            float acc[4][kScanPPT];
+            if (buf == 0) {
+                switch (nsub) {
+                    case 1: scan_quad_compute<NW, 1, 0>(lut_s, wlo, whi, acc); break;
+                    case 2: scan_quad_compute<NW, 2, 0>(lut_s, wlo, whi, acc); break;
+                    case 3: scan_quad_compute<NW, 3, 0>(lut_s, wlo, whi, acc); break;
+                    default: scan_quad_compute<NW, 4, 0>(lut_s, wlo, whi, acc); break;
+                }
+            } else {
+                switch (nsub) {
+                    case 1: scan_quad_compute<NW, 1, 1>(lut_s, wlo, whi, acc); break;
+                    case 2: scan_quad_compute<NW, 2, 1>(lut_s, wlo, whi, acc); break;
+                    case 3: scan_quad_compute<NW, 3, 1>(lut_s, wlo, whi, acc); break;
+                    default: scan_quad_compute<NW, 4, 1>(lut_s, wlo, whi, acc); break;
+                }
+            }
+
+            // threshold filter (rarely taken)
+            const uint32_t slot = slot0 + qd * 4;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t pq = a.pair_q[slot + p];
+                if (pq == kInvalid) continue;   // wave-uniform
+                const uint64_t T = a.thr[pq];
+                const uint32_t Thi = (uint32_t)(T >> 32);
+                const float Tf = (Thi == 0xFFFFFFFFu) ? __builtin_inff() : ordered_to_f32(Thi);
+                const uint32_t vb = a.pair_vbase[slot + p];
+#pragma unroll
+                for (int i = 0; i < (int)kScanPPT; ++i) {
+                    if (i < (int)nsub && acc[p][i] <= Tf) {
+                        const uint32_t j = c0 + tid + kScanThreads * i;
+                        if (j < size) {
+                            const uint64_t key = make_key(acc[p][i], vb + j);
+                            if (key <= T) {
+                                const uint32_t pos = atomicAdd(&a.cand_cnt[pq], 1u);
+                                if (pos < a.cap) a.cand[(size_t)pq * a.cap + pos] = key;
+                            }
+                        }
+                    }
+                }
+            }
+
+            if (more) {
+#pragma unroll
+                for (int t = 0; t < STG; ++t) {
+                    uint32_t e = tid + t * kScanThreads;
+                    if (e < (uint32_t)LUT4) lut_s[(buf ^ 1u) * LUT4 + e] = nx[t];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// =====================================================================================
+// K7: select + re-rank.  mod.rs:283-293 and :342-364 for one query per block:
+//   candidates -> exact m best keys (sorted) -> decode -> exact SquaredL2 with the
+//   reference's AVX2 arithmetic (simd/x86.rs:139-165: 8 FMA lane chains, fixed hsum
+//   tree, scalar tail) -> stable sort by exact -> first k.
+// =====================================================================================
+struct SelectArgs {
+    uint32_t P, m, k, cap;
+    int exact_reorder, local_only;
+    const float *queries;
+    uint32_t q_stride;
+    const uint32_t *tokens, *vbase;
+    uint32_t *cand_cnt;
+    uint64_t *cand;
+    uint32_t *counters;
+    uint64_t *cand_key;
+    uint32_t *cand_idx;
+    float *cand_dist, *cand_exact;
+    uint32_t *cand_count;
+    uint32_t *out_idx;
+    float *out_dist;
+    uint32_t *out_count;
+};
+
+// In-place stable compaction of list[0..cnt) keeping keys <= T, by one block.
+__device__ static uint32_t block_compact_le(uint64_t *list, uint32_t cnt, uint64_t T,
+                                            uint32_t *s_wave, uint32_t *s_base) {
+    const uint32_t tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, nw = nt >> 6;
+    if (tid == 0) *s_base = 0;
+    __syncthreads();
+    for (uint32_t b = 0; b < cnt; b += nt) {
+        const uint32_t i = b + tid;
+        uint64_t key = 0;
+        bool keep = false;
+        if (i < cnt) {
+            key = list[i];
+            keep = key <= T;
+        }
+        uint32_t wtot;
+        const uint32_t wpre = wave_prefix_count(keep, &wtot);
+        if ((tid & 63u) == 0) s_wave[wave] = wtot;
+        __syncthreads();
+        uint32_t off = *s_base;
+        for (uint32_t w = 0; w < wave; ++w) off += s_wave[w];
+        if (keep) list[off + wpre] = key;   // off + wpre <= i: never overtakes unread data
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t t = 0;
+            for (uint32_t w = 0; w < nw; ++w) t += s_wave[w];
+            *s_base += t;
+        }
+        __syncthreads();
+    }
+    return *s_base;
+}
+
+__global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexDev ix,
+                                                                       SelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];      // [kSortCap]
+    uint32_t *s_csr = reinterpret_cast<uint32_t *>(skeys + kSortCap);     // [kMaxPreReorderK]
+    uint32_t *s_idx = s_csr + kMaxPreReorderK;                            // [kMaxPreReorderK]
+    uint32_t *s_wave = s_idx + kMaxPreReorderK;                           // [kSelectThreads/64]
+    uint32_t *s_basep = s_wave + kSelectThreads / 64;                     // [4]
+    float *s_q = reinterpret_cast<float *>(s_basep + 4);                  // [dim]
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t m = a.m, k = a.k;
+
+    uint32_t cnt = a.cand_cnt[q];
+    if (cnt > a.cap) {  // candidate buffer overflow: report, never return a wrong row
+        if (tid == 0) {
+            atomicMax(&a.counters[CNT_STATUS], (uint32_t)SCANN_HIP_RESOURCE_EXHAUSTED);
+            a.cand_count[q] = 0;
+            if (!a.local_only) a.out_count[q] = 0;
+        }
+        return;
+    }
+    uint64_t *list = a.cand + (size_t)q * a.cap;
+
+    while (cnt > kSortCap) {  // thin with a sampled bound until the list fits in LDS
+        const uint32_t stride = (cnt + kSortCap / 2 - 1) / (kSortCap / 2);
+        const uint32_t ns = (cnt + stride - 1) / stride;
+        uint32_t n2 = 1;
+        while (n2 < ns) n2 <<= 1;
+        for (uint32_t i = tid; i < n2; i += nt)
+            skeys[i] = (i < ns) ? list[(size_t)i * stride] : SCANN_KEY_MAX;
+        __syncthreads();
+        bitonic_sort_lds(skeys, n2);
+        const uint64_t T = (ns >= m) ? skeys[m - 1] : SCANN_KEY_MAX;
+        __syncthreads();
+        const uint32_t nc = block_compact_le(list, cnt, T, s_wave, s_basep);
+        __syncthreads();
+        if (nc >= cnt) break;  // no progress (cannot happen for m <= kMaxPreReorderK)
+        cnt = nc;
+    }
+    if (cnt > kSortCap) {
+        if (tid == 0) {
+            atomicMax(&a.counters[CNT_STATUS], (uint32_t)SCANN_HIP_RESOURCE_EXHAUSTED);
+            a.cand_count[q] = 0;
+            if (!a.local_only) a.out_count[q] = 0;
+        }
+        return;
+    }
+
+    uint32_t n2 = 1;
+    while (n2 < cnt) n2 <<= 1;
+    for (uint32_t i = tid; i < n2; i += nt) skeys[i] = (i < cnt) ? list[i] : SCANN_KEY_MAX;
+    __syncthreads();
+    bitonic_sort_lds(skeys, n2);
+    const uint32_t nsel = min(m, cnt);   // truncate(pre_reorder_k)  mod.rs:290
+
+    // decode merge key -> (rank, position in leaf) -> CSR row -> datapoint index
+    const uint32_t *vb = a.vbase + (size_t)q * (a.P + 1);
+    for (uint32_t i = tid; i < nsel; i += nt) {
+        const uint64_t key = skeys[i];
+        const uint32_t vpos = (uint32_t)key;
+        uint32_t lo = 0, hi = a.P;
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (vb[mid] <= vpos) lo = mid; else hi = mid;
+        }
+        const uint32_t leaf = a.tokens[(size_t)q * a.P + lo];
+        const uint32_t csr = ix.leaf_off[leaf] + (vpos - vb[lo]);
+        const uint32_t idx = ix.leaf_ids ? ix.leaf_ids[csr] : csr;
+        s_csr[i] = csr;
+        s_idx[i] = idx;
+        const float ad = ordered_to_f32((uint32_t)(key >> 32));
+        a.cand_key[(size_t)q * m + i] = key;
+        a.cand_idx[(size_t)q * m + i] = idx;
+        a.cand_dist[(size_t)q * m + i] = ad;
+    }
+    if (tid == 0) a.cand_count[q] = nsel;
+
+    if (!a.exact_reorder) {  // AsymmetricHasher::search: k best by approximate distance
+        if (!a.local_only) {
+            const uint32_t nout = min(k, nsel);
+            for (uint32_t i = tid; i < k; i += nt) {
+                a.out_idx[(size_t)q * k + i] = (i < nout) ? s_idx[i] : kInvalid;
+                a.out_dist[(size_t)q * k + i] =
+                    (i < nout) ? ordered_to_f32((uint32_t)(skeys[i] >> 32)) : __builtin_inff();
+            }
+            if (tid == 0) a.out_count[q] = nout;
+        }
+        return;
+    }
+
+    // exact SquaredL2, 8 lanes per candidate = the 8 AVX2 lanes of squared_l2_avx2
+    const uint32_t dim = ix.dim;
+    for (uint32_t j = tid; j < dim; j += nt) s_q[j] = a.queries[(size_t)q * a.q_stride + j];
+    __syncthreads();   // also orders the s_csr/s_idx writes above
+    const uint32_t chunks = dim >> 3, lane8 = tid & 7u;
+    const uint32_t nround = (nsel + nt / 8 - 1) / (nt / 8);
+    for (uint32_t rd = 0; rd < nround; ++rd) {
+        const uint32_t c = rd * (nt / 8) + (tid >> 3);
+        const bool act = c < nsel;
+        float accv = 0.0f;
+        const float *row = nullptr;
+        if (act) {
+            row = ix.rows + (size_t)(ix.rows_csr ? s_csr[c] : s_idx[c]) * ix.stride;
+            for (uint32_t i = 0; i < chunks; ++i) {
+                const float diff = s_q[8 * i + lane8] - row[8 * i + lane8];
+                accv = fmaf(diff, diff, accv);        // _mm256_fmadd_ps(diff, diff, sum)
+            }
+        }
+        // horizontal_sum_f32_avx2 (simd/x86.rs:31-44): (lo+hi) -> +movehdup -> +movehl
+        float s = accv + __shfl_down(accv, 4, 8);     // lanes 0..3: v[j] + v[j+4]
+        float t = s + __shfl_down(s, 1, 8);           // lane 0: s0+s1, lane 2: s2+s3
+        float r = t + __shfl_down(t, 2, 8);           // lane 0: (s0+s1) + (s2+s3)
+        if (act && lane8 == 0) {
+            for (uint32_t j = chunks * 8; j < dim; ++j) {   // scalar tail, not fused
+                const float diff = s_q[j] - row[j];
+                r = r + diff * diff;
+            }
+            a.cand_exact[(size_t)q * m + c] = r;
+        }
+    }
+    if (a.local_only) return;
+    __syncthreads();
+
+    // stable sort by exact distance: key = (ordered(exact) << 32 | approx rank)
+    uint32_t m2 = 1;
+    while (m2 < nsel) m2 <<= 1;
+    __syncthreads();
+    for (uint32_t i = tid; i < m2; i += nt)
+        skeys[i] = (i < nsel) ? make_key(a.cand_exact[(size_t)q * m + i], i) : SCANN_KEY_MAX;
+    __syncthreads();
+    bitonic_sort_lds(skeys, m2);
+    const uint32_t nout = min(k, nsel);   // truncate(k)  mod.rs:361
+    for (uint32_t i = tid; i < k; i += nt) {
+        uint32_t oi = kInvalid;
+        float od = __builtin_inff();
+        if (i < nout) {
+            const uint64_t key = skeys[i];
+            oi = s_idx[(uint32_t)key];
+            od = ordered_to_f32((uint32_t)(key >> 32));
+        }
+        a.out_idx[(size_t)q * k + i] = oi;
+        a.out_dist[(size_t)q * k + i] = od;
+    }
+    if (tid == 0) a.out_count[q] = nout;
+}
+
+// =====================================================================================
+// Multi-GPU merge of gathered (key, idx, exact) triples: [world][nq][m].
+// =====================================================================================
+__global__ __launch_bounds__(kSelectThreads) void merge_kernel(
+    uint32_t world, uint32_t nq, uint32_t m, uint32_t k, uint32_t n2max,
+    const uint64_t *__restrict__ keys,
+    const uint32_t *__restrict__ idx, const float *__restrict__ exact,
+    const uint32_t *__restrict__ count, uint32_t *__restrict__ out_idx,
+    float *__restrict__ out_dist, uint32_t *__restrict__ out_count) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];   // [n2max]
+    uint32_t *s_src = reinterpret_cast<uint32_t *>(skeys + n2max);     // [n2max] source slot
+    uint32_t *s_off = s_src + n2max;                                   // [world+1]
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) {
+        uint32_t o = 0;
+        for (uint32_t g = 0; g < world; ++g) {
+            s_off[g] = o;
+            o += count[(size_t)g * nq + q];
+        }
+        s_off[world] = o;
+    }
+    __syncthreads();
+    const uint32_t tot = s_off[world];
+    uint32_t n2 = 1;
+    while (n2 < tot) n2 <<= 1;
+    // The merge key is unique per (query, point): sort keys, then recover payloads by a
+    // second keyed sort on (exact, rank) that looks the source slot up by binary search.
+    for (uint32_t g = 0; g < world; ++g) {
+        const uint32_t c = count[(size_t)g * nq + q];
+        for (uint32_t i = tid; i < c; i += nt)
+            skeys[s_off[g] + i] = keys[((size_t)g * nq + q) * m + i];
+    }
+    for (uint32_t i = tot + tid; i < n2; i += nt) skeys[i] = SCANN_KEY_MAX;
+    __syncthreads();
+    bitonic_sort_lds(skeys, n2);
+    const uint32_t nsel = min(m, tot);
+    // locate each selected key's source (rank g, slot i): every rank's list is sorted.
+    for (uint32_t i = tid; i < nsel; i += nt) {
+        const uint64_t key = skeys[i];
+        uint32_t src = kInvalid;
+        for (uint32_t g = 0; g < world && src == kInvalid; ++g) {
+            const uint64_t *kl = keys + ((size_t)g * nq + q) * m;
+            uint32_t lo = 0, hi = count[(size_t)g * nq + q];
+            while (lo < hi) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (kl[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            if (lo < count[(size_t)g * nq + q] && kl[lo] == key) src = (g * nq + q) * m + lo;
+        }
+        s_src[i] = src;
+    }
+    __syncthreads();
+    uint32_t m2 = 1;
+    while (m2 < nsel) m2 <<= 1;
+    for (uint32_t i = tid; i < m2; i += nt)
+        skeys[i] = (i < nsel) ? make_key(exact[s_src[i]], i) : SCANN_KEY_MAX;
+    __syncthreads();
+    bitonic_sort_lds(skeys, m2);
+    const uint32_t nout = min(k, nsel);
+    for (uint32_t i = tid; i < k; i += nt) {
+        uint32_t oi = kInvalid;
+        float od = __builtin_inff();
+        if (i < nout) {
+            const uint64_t key = skeys[i];
+            oi = idx[s_src[(uint32_t)key]];
+            od = ordered_to_f32((uint32_t)(key >> 32));
+        }
+        out_idx[(size_t)q * k + i] = oi;
+        out_dist[(size_t)q * k + i] = od;
+    }
+    if (tid == 0) out_count[q] = nout;
+}
+
+// =====================================================================================
+// Building blocks exposed through the C ABI
+// =====================================================================================
+// All-pairs ADC distances for explicit f32 LUTs [nq][S][K]: out [nq][n_local].
+template <int NW>
+__global__ __launch_bounds__(256) void adc_distances_kernel(TxhIndexDev ix,
+                                                            const float *__restrict__ luts,
+                                                            float *__restrict__ out) {
+    constexpr int S = NW * 8;
+    __shared__ float slut[S * 16];
+    const uint32_t q = blockIdx.y;
+    for (uint32_t e = threadIdx.x; e < S * 16; e += blockDim.x) {
+        uint32_t s = e >> 4, c = e & 15u;
+        slut[e] = (c < ix.K) ? luts[((size_t)q * S + s) * ix.K + c] : 0.0f;
+    }
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ix.n_local;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t w[NW];
+#pragma unroll
+        for (int wi = 0; wi < NW; ++wi) w[wi] = ix.codes[i * NW + wi];
+        out[(size_t)q * ix.n_local + i] = adc_row_sum<NW>(slut, w);
+    }
+}
+
+// Lut16SimdTables::compute_distances_batch (hashes/lut16_simd.rs:119-141 over
+// simd/dispatch.rs:259-295): u32 sum of u8 table entries, then sum * mult + bias * S.
+__global__ __launch_bounds__(256) void lut16_u8_batch_kernel(
+    const uint8_t *__restrict__ packed, const uint8_t *__restrict__ lut8, uint32_t S,
+    uint64_t n, float bias, float mult, float *__restrict__ out) {
+    extern __shared__ uint8_t s_lut8[];  // [S*16]
+    for (uint32_t e = threadIdx.x; e < S * 16; e += blockDim.x) s_lut8[e] = lut8[e];
+    __syncthreads();
+    const uint32_t bpp = (S + 1) / 2;
+    const float bias_total = bias * (float)S;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint8_t *row = packed + i * bpp;
+        uint32_t sum = 0, sub = 0;
+        for (uint32_t b = 0; b < bpp; ++b) {
+            const uint32_t byte = row[b];
+            if (sub < S) { sum += s_lut8[sub * 16 + (byte & 15u)]; ++sub; }
+            if (sub < S) { sum += s_lut8[sub * 16 + (byte >> 4)]; ++sub; }
+        }
+        const float r = (float)sum * mult;
+        out[i] = r + bias_total;
+    }
+}
+
+// Codebook::encode (hashes/codebook.rs:82-95): per subspace argmin over K with strict '<'.
+__global__ __launch_bounds__(256) void encode_kernel(
+    const float *__restrict__ codebook, uint32_t S, uint32_t K, uint32_t dsub,
+    const float *__restrict__ rows, uint64_t n, uint32_t stride,
+    const float *__restrict__ centers, const uint32_t *__restrict__ leaf_of_row,
+    uint8_t *__restrict__ out) {
+    const uint64_t total = n * S;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = e / S;
+        const uint32_t s = (uint32_t)(e - i * S);
+        const float *x = rows + i * stride + s * dsub;
+        const float *cen = centers ? centers + (size_t)leaf_of_row[i] * (S * dsub) + s * dsub
+                                   : nullptr;
+        float best = __builtin_inff();
+        uint32_t bi = 0;
+        for (uint32_t c = 0; c < K; ++c) {
+            const float *cb = codebook + ((size_t)s * K + c) * dsub;
+            float d = 0.0f;
+            for (uint32_t j = 0; j < dsub; ++j) {
+                float xv = x[j];
+                if (cen) xv = xv - cen[j];
+                const float t = xv - cb[j];
+                d = d + t * t;
+            }
+            if (d < best) {
+                best = d;
+                bi = c;
+            }
+        }
+        out[e] = (uint8_t)bi;
+    }
+}
+
+// =====================================================================================
+// launchers
+// =====================================================================================
+#define LAUNCH_CHECK()                                                                \
+    do {                                                                              \
+        hipError_t _e = hipGetLastError();                                            \
+        if (_e != hipSuccess)                                                         \
+            return fail(SCANN_HIP_INTERNAL, std::string("kernel launch: ") + hipGetErrorString(_e)); \
+    } while (0)
+
+template <typename F>
+static int set_dyn_lds(F kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        SCANN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)bytes));
+    return SCANN_HIP_OK;
+}
+
+static int launch_partition_stage(const TxhIndexDev &ix, const TxhWork &w, hipStream_t st) {
+    if (ix.ah_mode) {
+        hipLaunchKernelGGL(ah_tokens_kernel, dim3(ceil_div_u32(w.nq, 256)), dim3(256), 0, st, w.nq,
+                           ix.leaf_gsize, w.tokens, w.token_dists, w.vbase);
+        LAUNCH_CHECK();
+        return SCANN_HIP_OK;
+    }
+    const size_t lds1 = (size_t)kCsQT * ix.dim * sizeof(float);
+    SCANN_TRY(set_dyn_lds(centroid_scores_kernel, lds1));
+    hipLaunchKernelGGL(centroid_scores_kernel, dim3(ceil_div_u32(ix.L, 64), ceil_div_u32(w.nq, kCsQT)),
+                       dim3(64), lds1, st, ix.centers, ix.L, ix.dim, w.queries, w.nq, w.q_stride,
+                       w.cdist);
+    LAUNCH_CHECK();
+    const uint32_t n2 = next_pow2_u32(ix.L);
+    const size_t lds2 = (size_t)n2 * sizeof(uint64_t);
+    SCANN_TRY(set_dyn_lds(select_leaves_kernel, lds2));
+    hipLaunchKernelGGL(select_leaves_kernel, dim3(w.nq), dim3(kSelectThreads), lds2, st, w.cdist,
+                       ix.L, n2, w.P, ix.leaf_gsize, w.tokens, w.token_dists, w.vbase);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+int txh_launch_partition_only(const TxhIndexDev &ix, const TxhWork &w, hipStream_t st) {
+    return launch_partition_stage(ix, w, st);
+}
+
+template <int NW>
+static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream_t st,
+                              hipEvent_t ev0, hipEvent_t ev1) {
+    constexpr int S = NW * 8;
+    const size_t lds_thr = (size_t)kSampleCap * sizeof(uint64_t) + (size_t)S * 16 * sizeof(float) + 16;
+    SCANN_TRY(set_dyn_lds(sample_threshold_kernel<NW>, lds_thr));
+    hipLaunchKernelGGL(sample_threshold_kernel<NW>, dim3(w.nq), dim3(kSelectThreads), lds_thr, st,
+                       ix, w.P, w.m, w.tokens, w.vbase, w.slot_of, w.lutq, w.thr);
+    LAUNCH_CHECK();
+    ScanArgs a;
+    a.pair_off = w.pair_off; a.tile_off = w.tile_off; a.pair_q = w.pair_q;
+    a.pair_vbase = w.pair_vbase; a.counters = w.counters; a.lutq = w.lutq; a.thr = w.thr;
+    a.cand_cnt = w.cand_cnt; a.cand = w.cand; a.cap = w.cap;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
+    hipLaunchKernelGGL(adc_scan_kernel<NW>, dim3((uint32_t)cus * 8u), dim3(kScanThreads), 0, st, ix, a);
+    LAUNCH_CHECK();
+    if (ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
+    return SCANN_HIP_OK;
+}
+
+int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, hipStream_t st,
+                      hipEvent_t ev0, hipEvent_t ev1) {
+    if (w.nq == 0) return SCANN_HIP_OK;
+    SCANN_HIP_CHECK(hipMemsetAsync(w.leaf_cnt, 0, (size_t)ix.L * 4, st));
+    SCANN_HIP_CHECK(hipMemsetAsync(w.leaf_cursor, 0, (size_t)ix.L * 4, st));
+    SCANN_HIP_CHECK(hipMemsetAsync(w.counters, 0, CNT_N * 4, st));
+    SCANN_HIP_CHECK(hipMemsetAsync(w.cand_cnt, 0, (size_t)w.nq * 4, st));
+    SCANN_HIP_CHECK(hipMemsetAsync(w.pair_q, 0xFF, (size_t)w.max_slots * 4, st));
+    SCANN_TRY(launch_partition_stage(ix, w, st));
+
+    const uint32_t npairs = w.nq * w.P;
+    hipLaunchKernelGGL(worklist_count_kernel, dim3(ceil_div_u32(npairs, 256)), dim3(256), 0, st,
+                       npairs, w.tokens, ix.leaf_off, w.leaf_cnt);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(worklist_scan_kernel, dim3(1), dim3(1024), 0, st, ix.L, w.leaf_cnt,
+                       ix.leaf_off, kScanTP, kScanQuadsPerTile, w.pair_off, w.tile_off, w.counters);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(worklist_fill_kernel, dim3(ceil_div_u32(npairs, 256)), dim3(256), 0, st, w.nq,
+                       w.P, w.tokens, w.vbase, ix.leaf_off, w.pair_off, w.leaf_cursor, w.pair_q,
+                       w.pair_leaf, w.pair_vbase, w.slot_of);
+    LAUNCH_CHECK();
+    const size_t lds_lut = (size_t)4 * ix.dim * sizeof(float);
+    SCANN_TRY(set_dyn_lds(lut_build_kernel, lds_lut));
+    hipLaunchKernelGGL(lut_build_kernel, dim3(w.max_quads), dim3(256), lds_lut, st, ix, w.queries,
+                       w.q_stride, w.pair_q, w.pair_leaf, w.counters, w.lutq);
+    LAUNCH_CHECK();
+
+    switch (ix.nw) {
+        case 1: SCANN_TRY(launch_scan_stages<1>(ix, w, st, ev0, ev1)); break;
+        case 2: SCANN_TRY(launch_scan_stages<2>(ix, w, st, ev0, ev1)); break;
+        case 3: SCANN_TRY(launch_scan_stages<3>(ix, w, st, ev0, ev1)); break;
+        case 4: SCANN_TRY(launch_scan_stages<4>(ix, w, st, ev0, ev1)); break;
+        case 6: SCANN_TRY(launch_scan_stages<6>(ix, w, st, ev0, ev1)); break;
+        case 8: SCANN_TRY(launch_scan_stages<8>(ix, w, st, ev0, ev1)); break;
+        default: return fail(SCANN_HIP_UNIMPLEMENTED, "num_subspaces must be 8,16,24,32,48 or 64");
+    }
+
+    SelectArgs s;
+    s.P = w.P; s.m = w.m; s.k = w.k; s.cap = w.cap;
+    s.exact_reorder = w.exact_reorder; s.local_only = local_only ? 1 : 0;
+    s.queries = w.queries; s.q_stride = w.q_stride; s.tokens = w.tokens; s.vbase = w.vbase;
+    s.cand_cnt = w.cand_cnt; s.cand = w.cand; s.counters = w.counters; s.cand_key = w.cand_key;
+    s.cand_idx = w.cand_idx; s.cand_dist = w.cand_dist; s.cand_exact = w.cand_exact;
+    s.cand_count = w.cand_count; s.out_idx = w.out_idx; s.out_dist = w.out_dist;
+    s.out_count = w.out_count;
+    const size_t lds_sel = (size_t)kSortCap * 8 + (size_t)kMaxPreReorderK * 8 +
+                           (size_t)(kSelectThreads / 64 + 4) * 4 + (size_t)ix.dim * 4;
+    SCANN_TRY(set_dyn_lds(select_rerank_kernel, lds_sel));
+    hipLaunchKernelGGL(select_rerank_kernel, dim3(w.nq), dim3(kSelectThreads), lds_sel, st, ix, s);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+int txh_launch_merge(uint32_t world, uint32_t nq, uint32_t m, uint32_t k, const uint64_t *d_keys,
+                     const uint32_t *d_idx, const float *d_exact, const uint32_t *d_count,
+                     uint32_t *d_out_idx, float *d_out_dist, uint32_t *d_out_count,
+                     hipStream_t st) {
+    if (nq == 0) return SCANN_HIP_OK;
+    if (world == 0 || world > 64) return fail(SCANN_HIP_INVALID_ARGUMENT, "world must be 1..64");
+    const uint32_t n2 = next_pow2_u32(std::max<uint32_t>(1u, world * m));
+    if (n2 > 2 * kSortCap)
+        return fail(SCANN_HIP_UNIMPLEMENTED, "world * pre_reorder_k exceeds the LDS merge capacity");
+    const size_t lds = (size_t)n2 * 12 + (size_t)(world + 1) * 4;
+    SCANN_TRY(set_dyn_lds(merge_kernel, lds));
+    hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kSelectThreads), lds, st, world, nq, m, k, n2, d_keys,
+                       d_idx, d_exact, d_count, d_out_idx, d_out_dist, d_out_count);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+int txh_launch_lut_from_query(const TxhIndexDev &ix, const float *d_queries, uint32_t nq,
+                              uint32_t q_stride, const uint32_t *d_leaf_for_query,
+                              float *d_out_lut, hipStream_t st) {
+    if (nq == 0) return SCANN_HIP_OK;
+    const size_t lds = (size_t)ix.dim * sizeof(float);
+    SCANN_TRY(set_dyn_lds(lut_from_query_kernel, lds));
+    hipLaunchKernelGGL(lut_from_query_kernel, dim3(nq), dim3(256), lds, st, ix, d_queries, q_stride,
+                       d_leaf_for_query, d_out_lut);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+int txh_launch_adc_distances(const TxhIndexDev &ix, const float *d_luts, uint32_t nq, float *d_out,
+                             hipStream_t st) {
+    if (nq == 0 || ix.n_local == 0) return SCANN_HIP_OK;
+    const uint32_t gx = (uint32_t)std::min<uint64_t>(ceil_div_u64(ix.n_local, 256), 4096);
+    dim3 grid(gx, nq);
+    switch (ix.nw) {
+        case 1: hipLaunchKernelGGL(adc_distances_kernel<1>, grid, dim3(256), 0, st, ix, d_luts, d_out); break;
+        case 2: hipLaunchKernelGGL(adc_distances_kernel<2>, grid, dim3(256), 0, st, ix, d_luts, d_out); break;
+        case 3: hipLaunchKernelGGL(adc_distances_kernel<3>, grid, dim3(256), 0, st, ix, d_luts, d_out); break;
+        case 4: hipLaunchKernelGGL(adc_distances_kernel<4>, grid, dim3(256), 0, st, ix, d_luts, d_out); break;
+        case 6: hipLaunchKernelGGL(adc_distances_kernel<6>, grid, dim3(256), 0, st, ix, d_luts, d_out); break;
+        case 8: hipLaunchKernelGGL(adc_distances_kernel<8>, grid, dim3(256), 0, st, ix, d_luts, d_out); break;
+        default: return fail(SCANN_HIP_UNIMPLEMENTED, "num_subspaces must be 8,16,24,32,48 or 64");
+    }
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+int launch_lut16_u8_batch(const uint8_t *d_packed, const uint8_t *d_lut8, uint32_t S, uint64_t n,
+                          float bias, float mult, float *d_out, hipStream_t st) {
+    if (n == 0) return SCANN_HIP_OK;
+    const uint32_t gx = (uint32_t)std::min<uint64_t>(ceil_div_u64(n, 256), 8192);
+    hipLaunchKernelGGL(lut16_u8_batch_kernel, dim3(gx), dim3(256), (size_t)S * 16, st, d_packed, d_lut8,
+                       S, n, bias, mult, d_out);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+int launch_encode(const float *d_codebook, uint32_t S, uint32_t K, uint32_t dsub, const float *d_rows,
+                  uint64_t n, uint32_t stride, const float *d_centers, const uint32_t *d_leaf_of_row,
+                  uint8_t *d_out, hipStream_t st) {
+    if (n == 0) return SCANN_HIP_OK;
+    const uint32_t gx = (uint32_t)std::min<uint64_t>(ceil_div_u64(n * S, 256), 16384);
+    hipLaunchKernelGGL(encode_kernel, dim3(gx), dim3(256), 0, st, d_codebook, S, K, dsub, d_rows, n,
+                       stride, d_centers, d_leaf_of_row, d_out);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+}  // namespace scann

@@ -1,0 +1,348 @@
+"""Raw ctypes binding of libscann_hip.so (include/scann_hip.h).
+
+Plumbing only: numpy arrays in, numpy arrays out.  There is NO fallback: if the
+library is missing or no gfx950 device is present every call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscann_hip.so")
+
+OK, INVALID_ARGUMENT, RESOURCE_EXHAUSTED, FAILED_PRECONDITION = 0, 3, 8, 9
+OUT_OF_RANGE, UNIMPLEMENTED, INTERNAL, UNAVAILABLE = 11, 12, 13, 14
+SQUARED_L2, L2, DOT_PRODUCT = 0, 1, 2
+
+_CODE_NAMES = {
+    0: "Ok", 1: "Cancelled", 2: "Unknown", 3: "InvalidArgument", 4: "DeadlineExceeded",
+    5: "NotFound", 6: "AlreadyExists", 7: "PermissionDenied", 8: "ResourceExhausted",
+    9: "FailedPrecondition", 10: "Aborted", 11: "OutOfRange", 12: "Unimplemented",
+    13: "Internal", 14: "Unavailable", 15: "DataLoss", 16: "Unauthenticated",
+}
+
+EXPORTS = [
+    "scann_hip_init", "scann_hip_shutdown", "scann_hip_last_error", "scann_hip_version",
+    "scann_hip_compute_stride", "scann_hip_bf_create", "scann_hip_txh_create",
+    "scann_hip_search_opts_default", "scann_hip_search_batched", "scann_hip_index_reserve",
+    "scann_hip_search_batched_device", "scann_hip_index_last_device_status",
+    "scann_hip_txh_search_local_device", "scann_hip_txh_merge_device",
+    "scann_hip_assign_leaves", "scann_hip_txh_partition", "scann_hip_lut_from_query",
+    "scann_hip_adc_distances", "scann_hip_lut16_distances_batch", "scann_hip_encode",
+    "scann_hip_bf_distances", "scann_hip_index_size", "scann_hip_index_dimensionality",
+    "scann_hip_index_destroy", "scann_hip_index_enable_timing",
+    "scann_hip_index_last_kernel_ms",
+]
+
+
+class ScannError(RuntimeError):
+    """error.rs:73-147: ScannError { code, message }."""
+
+    def __init__(self, code, message):
+        super().__init__("%s: %s" % (_CODE_NAMES.get(code, str(code)), message))
+        self.code = code
+        self.message = message
+
+
+f32p = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+u8p = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+
+
+class TxhDesc(C.Structure):
+    _fields_ = [
+        ("data", f32p), ("n_rows", C.c_uint64), ("dim", C.c_uint32), ("stride", C.c_uint32),
+        ("data_is_csr_order", C.c_int32),
+        ("centers", f32p), ("num_partitions", C.c_uint32),
+        ("leaf_offsets", u32p), ("leaf_ids", u32p), ("leaf_sizes_global", u32p),
+        ("n_local", C.c_uint64),
+        ("codebook", f32p), ("num_subspaces", C.c_uint32), ("num_codes", C.c_uint32),
+        ("dims_per_subspace", C.c_uint32),
+        ("codes", u8p), ("codes_packed4", C.c_int32), ("use_residuals", C.c_int32),
+        ("partitions_to_search", C.c_uint32), ("pre_reorder_multiplier", C.c_float),
+    ]
+
+
+class SearchOpts(C.Structure):
+    _fields_ = [
+        ("partitions_to_search", C.c_uint32), ("pre_reorder_k", C.c_uint32),
+        ("exact_reorder", C.c_int32),
+        ("tokens", u32p), ("token_dists", f32p),
+        ("cand_idx", u32p), ("cand_dist", f32p), ("cand_count", u32p),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (no GPU needed just to load and look up symbols)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ScannError(UNAVAILABLE, "libscann_hip.so is not built (run "
+                         "`python -m scann_rust_amd.build`); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    L.scann_hip_init.argtypes = [C.c_int, C.POINTER(vp)]
+    L.scann_hip_shutdown.argtypes = [vp]
+    L.scann_hip_shutdown.restype = None
+    L.scann_hip_last_error.restype = C.c_char_p
+    L.scann_hip_version.restype = C.c_char_p
+    L.scann_hip_compute_stride.restype = C.c_uint32
+    L.scann_hip_compute_stride.argtypes = [C.c_uint32]
+    L.scann_hip_bf_create.argtypes = [vp, f32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int,
+                                      C.POINTER(vp)]
+    L.scann_hip_txh_create.argtypes = [vp, C.POINTER(TxhDesc), C.POINTER(vp)]
+    L.scann_hip_search_opts_default.argtypes = [C.POINTER(SearchOpts)]
+    L.scann_hip_search_opts_default.restype = None
+    L.scann_hip_search_batched.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                           C.c_uint32, C.POINTER(SearchOpts), u32p, f32p, u32p]
+    L.scann_hip_index_reserve.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(SearchOpts)]
+    L.scann_hip_search_batched_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                  C.POINTER(SearchOpts), vp, vp, vp, vp]
+    L.scann_hip_index_last_device_status.argtypes = [vp, vp]
+    L.scann_hip_txh_search_local_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                    C.POINTER(SearchOpts), vp, vp, vp, vp, vp]
+    L.scann_hip_txh_merge_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             vp, vp, vp, vp, vp, vp, vp, vp]
+    L.scann_hip_assign_leaves.argtypes = [u32p, C.c_uint32, C.c_uint32, u32p]
+    L.scann_hip_txh_partition.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_uint32, u32p, f32p, u32p]
+    L.scann_hip_lut_from_query.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, u32p, f32p]
+    L.scann_hip_adc_distances.argtypes = [vp, f32p, C.c_uint32, f32p]
+    L.scann_hip_lut16_distances_batch.argtypes = [vp, u8p, u8p, C.c_uint32, C.c_uint64,
+                                                  C.c_float, C.c_float, f32p]
+    L.scann_hip_encode.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p,
+                                   C.c_uint64, C.c_uint32, f32p, u32p, u8p]
+    L.scann_hip_bf_distances.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, f32p]
+    L.scann_hip_index_size.restype = C.c_uint64
+    L.scann_hip_index_size.argtypes = [vp]
+    L.scann_hip_index_dimensionality.restype = C.c_uint32
+    L.scann_hip_index_dimensionality.argtypes = [vp]
+    L.scann_hip_index_destroy.argtypes = [vp]
+    L.scann_hip_index_destroy.restype = None
+    L.scann_hip_index_enable_timing.argtypes = [vp, C.c_int]
+    L.scann_hip_index_enable_timing.restype = None
+    L.scann_hip_index_last_kernel_ms.restype = C.c_float
+    L.scann_hip_index_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_char_p)]
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != OK:
+        raise ScannError(status, (load().scann_hip_last_error() or b"").decode())
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def ptr(a, ty):
+    return a.ctypes.data_as(ty) if a is not None else None
+
+
+_ctx = {}
+
+
+def context(device=0):
+    """Process-wide context per device (scann_hip_init)."""
+    if device not in _ctx:
+        h = vp()
+        check(load().scann_hip_init(device, C.byref(h)))
+        _ctx[device] = h
+    return _ctx[device]
+
+
+def compute_stride(dim):
+    return int(load().scann_hip_compute_stride(dim))
+
+
+def default_opts():
+    o = SearchOpts()
+    load().scann_hip_search_opts_default(C.byref(o))
+    return o
+
+
+class Index:
+    """Owns one scann_hip_index handle."""
+
+    def __init__(self, handle, keep=()):
+        self.h = handle
+        self._keep = keep
+
+    def close(self):
+        if self.h:
+            load().scann_hip_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return int(load().scann_hip_index_size(self.h))
+
+    def dimensionality(self):
+        return int(load().scann_hip_index_dimensionality(self.h))
+
+    def search_batched(self, queries, k, opts=None, q_dim=None, stages=False):
+        q = f32(queries)
+        if q.ndim == 1:
+            q = q[None]
+        nq, qs = q.shape
+        qd = qs if q_dim is None else q_dim
+        out_idx = np.full((nq, max(k, 1)), 0xFFFFFFFF, np.uint32)
+        out_dist = np.full((nq, max(k, 1)), np.inf, np.float32)
+        out_cnt = np.zeros(nq, np.uint32)
+        o = opts if opts is not None else default_opts()
+        extra = None
+        if stages:
+            P = o.partitions_to_search or 4096
+            m = o.pre_reorder_k or 4096
+            tok = np.zeros((nq, P), np.uint32); tokd = np.zeros((nq, P), np.float32)
+            ci = np.zeros((nq, m), np.uint32); cd = np.zeros((nq, m), np.float32)
+            cc = np.zeros(nq, np.uint32)
+            o.tokens, o.token_dists = ptr(tok, u32p), ptr(tokd, f32p)
+            o.cand_idx, o.cand_dist, o.cand_count = ptr(ci, u32p), ptr(cd, f32p), ptr(cc, u32p)
+            extra = (tok, tokd, ci, cd, cc)
+        check(load().scann_hip_search_batched(self.h, ptr(q, f32p), nq, qs, qd, k, C.byref(o),
+                                              ptr(out_idx, u32p), ptr(out_dist, f32p),
+                                              ptr(out_cnt, u32p)))
+        if stages:
+            return out_idx[:, :k], out_dist[:, :k], out_cnt, extra
+        return out_idx[:, :k], out_dist[:, :k], out_cnt
+
+    def enable_timing(self, on=True):
+        load().scann_hip_index_enable_timing(self.h, 1 if on else 0)
+
+    def last_kernel_ms(self):
+        name = C.c_char_p()
+        ms = load().scann_hip_index_last_kernel_ms(self.h, C.byref(name))
+        return float(ms), (name.value or b"").decode()
+
+
+def bf_create(data, n, dim, stride, measure, device=0):
+    d = f32(data)
+    h = vp()
+    check(load().scann_hip_bf_create(context(device), ptr(d, f32p) if n else None, n, dim,
+                                     stride, measure, C.byref(h)))
+    return Index(h)
+
+
+def txh_create(*, data, n_rows, dim, stride, centers, leaf_offsets, leaf_ids, codebook, codes,
+               codes_packed4=False, use_residuals=True, partitions_to_search=10,
+               pre_reorder_multiplier=3.0, leaf_sizes_global=None, data_is_csr_order=False,
+               device=0):
+    d = TxhDesc()
+    keep = []
+
+    def hold(a, dt):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a
+
+    data = hold(data, np.float32)
+    centers = hold(centers, np.float32)
+    leaf_offsets = hold(leaf_offsets, np.uint32)
+    leaf_ids = hold(leaf_ids, np.uint32)
+    leaf_sizes_global = hold(leaf_sizes_global, np.uint32)
+    codebook = hold(codebook, np.float32)
+    codes = hold(codes, np.uint8)
+    d.data = ptr(data, f32p)
+    d.n_rows = n_rows
+    d.dim = dim
+    d.stride = stride
+    d.data_is_csr_order = 1 if data_is_csr_order else 0
+    d.centers = ptr(centers, f32p)
+    d.num_partitions = 0 if centers is None else centers.shape[0]
+    d.leaf_offsets = ptr(leaf_offsets, u32p)
+    d.leaf_ids = ptr(leaf_ids, u32p)
+    d.leaf_sizes_global = ptr(leaf_sizes_global, u32p)
+    d.n_local = codes.shape[0]
+    d.codebook = ptr(codebook, f32p)
+    d.num_subspaces, d.num_codes, d.dims_per_subspace = codebook.shape
+    d.codes = ptr(codes, u8p)
+    d.codes_packed4 = 1 if codes_packed4 else 0
+    d.use_residuals = 1 if use_residuals else 0
+    d.partitions_to_search = partitions_to_search
+    d.pre_reorder_multiplier = pre_reorder_multiplier
+    h = vp()
+    check(load().scann_hip_txh_create(context(device), C.byref(d), C.byref(h)))
+    return Index(h)
+
+
+def txh_partition(index, queries, num_partitions, q_dim=None):
+    q = f32(queries)
+    nq, qs = q.shape
+    tok = np.zeros((nq, max(num_partitions, 1)), np.uint32)
+    dist = np.zeros((nq, max(num_partitions, 1)), np.float32)
+    cnt = np.zeros(nq, np.uint32)
+    check(load().scann_hip_txh_partition(index.h, ptr(q, f32p), nq, qs, qs if q_dim is None else q_dim,
+                                         num_partitions, ptr(tok, u32p), ptr(dist, f32p),
+                                         ptr(cnt, u32p)))
+    return tok, dist, cnt
+
+
+def lut_from_query(index, queries, S, K, leaf_for_query=None):
+    q = f32(queries)
+    nq, qs = q.shape
+    out = np.zeros((nq, S, K), np.float32)
+    lf = None if leaf_for_query is None else np.ascontiguousarray(leaf_for_query, np.uint32)
+    check(load().scann_hip_lut_from_query(index.h, ptr(q, f32p), nq, qs, ptr(lf, u32p),
+                                          ptr(out, f32p)))
+    return out
+
+
+def adc_distances(index, luts):
+    luts = f32(luts)
+    nq = luts.shape[0]
+    out = np.zeros((nq, index.size()), np.float32)
+    check(load().scann_hip_adc_distances(index.h, ptr(luts, f32p), nq, ptr(out, f32p)))
+    return out
+
+
+def lut16_distances_batch(packed, lut8, S, n, bias, mult, device=0):
+    packed = np.ascontiguousarray(packed, np.uint8)
+    lut8 = np.ascontiguousarray(lut8, np.uint8)
+    out = np.zeros(n, np.float32)
+    check(load().scann_hip_lut16_distances_batch(context(device), ptr(packed, u8p), ptr(lut8, u8p),
+                                                 S, n, bias, mult, ptr(out, f32p)))
+    return out
+
+
+def encode(codebook, rows, stride=None, centers=None, leaf_of_row=None, device=0):
+    cb = f32(codebook)
+    rows = f32(rows)
+    n = rows.shape[0]
+    st = rows.shape[1] if stride is None else stride
+    S, K, dsub = cb.shape
+    out = np.zeros((n, S), np.uint8)
+    cen = None if centers is None else f32(centers)
+    lf = None if leaf_of_row is None else np.ascontiguousarray(leaf_of_row, np.uint32)
+    check(load().scann_hip_encode(context(device), ptr(cb, f32p), S, K, dsub, ptr(rows, f32p), n,
+                                  st, ptr(cen, f32p), ptr(lf, u32p), ptr(out, u8p)))
+    return out
+
+
+def bf_distances(index, queries):
+    q = f32(queries)
+    nq, qs = q.shape
+    out = np.zeros((nq, index.size()), np.float32)
+    check(load().scann_hip_bf_distances(index.h, ptr(q, f32p), nq, qs, ptr(out, f32p)))
+    return out
+
+
+def assign_leaves(sizes, world):
+    sizes = np.ascontiguousarray(sizes, np.uint32)
+    owner = np.zeros(sizes.size, np.uint32)
+    check(load().scann_hip_assign_leaves(ptr(sizes, u32p), sizes.size, world, ptr(owner, u32p)))
+    return owner

@@ -1,0 +1,328 @@
+"""GPU parity tests proper: every row of SURVEY.md section 8a through the C ABI
+(libscann_hip.so) against the CPU oracle on the same seeded inputs.
+
+Bars: approximate (LUT-sum) distances, centroid distances, LUTs, codes and exact
+re-rank / brute-force distances are BIT-EXACT (the kernels reproduce the reference's
+operation order); result indices are equal up to exact distance ties."""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from scann_rust_amd import hip, synth, trainer
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+# ---- a2: TreePartitioner::partition ----------------------------------------------------
+@pytest.mark.parametrize("L,dim,P", [(16, 128, 4), (37, 96, 37), (100, 32, 10), (1000, 128, 50),
+                                     (5, 8, 3)])
+def test_partition_bit_exact(L, dim, P):
+    S = 8
+    rows, data, stride, ix, oix, kw = H.make_txh_case(max(4 * L, 512), dim, L, S, seed=3, P=P,
+                                                      kmeans_iters=2, pq_iters=2)
+    index = hip.txh_create(**kw)
+    q = synth.uniform_f32(33, dim, 123)
+    tok, dist, cnt = hip.txh_partition(index, q, P)
+    for i in range(q.shape[0]):
+        ot, od = orc.partition(ix["centers"], q[i], P)
+        assert cnt[i] == ot.size
+        assert np.array_equal(bits(dist[i, :ot.size]), bits(od))
+        assert np.array_equal(tok[i, :ot.size], ot)
+
+
+# ---- a3/a4: residual + LookupTable::from_query ----------------------------------------------
+@pytest.mark.parametrize("dim,S", [(128, 32), (96, 24), (64, 8), (128, 16)])
+def test_lut_from_query_bit_exact(dim, S):
+    rows, data, stride, ix, oix, kw = H.make_txh_case(2048, dim, 8, S, seed=5, kmeans_iters=2,
+                                                      pq_iters=3)
+    index = hip.txh_create(**kw)
+    q = synth.uniform_f32(17, dim, 9)
+    lut = hip.lut_from_query(index, q, S, 16)
+    for i in range(q.shape[0]):
+        assert np.array_equal(bits(lut[i]), bits(orc.lut_from_query(ix["codebook"], q[i])))
+    leaves = (np.arange(17) % 8).astype(np.uint32)
+    lut = hip.lut_from_query(index, q, S, 16, leaf_for_query=leaves)
+    for i in range(q.shape[0]):
+        res = q[i] - ix["centers"][leaves[i]]
+        assert np.array_equal(bits(lut[i]), bits(orc.lut_from_query(ix["codebook"], res)))
+
+
+# ---- a5/a13: LookupTable::compute_distance over packed 4-bit codes ------------------------------
+@pytest.mark.parametrize("dim,S", [(128, 32), (96, 24), (64, 8), (128, 64), (96, 48)])
+def test_adc_distances_bit_exact(dim, S):
+    rows, data, stride, ix, kw = H.make_ah_case(3000, dim, S, seed=11, pq_iters=3)
+    index = hip.txh_create(**kw)
+    q = synth.uniform_f32(5, dim, 77)
+    luts = np.stack([orc.lut_from_query(ix["codebook"], qq) for qq in q])
+    got = hip.adc_distances(index, luts)
+    for i in range(q.shape[0]):
+        want = np.array([orc.lut_distance(luts[i], c) for c in ix["codes"]], np.float32)
+        assert np.array_equal(bits(got[i]), bits(want))
+
+
+# ---- a13: Lut16SimdTables::compute_distances_batch (u8 tables) -------------------------------------
+@pytest.mark.parametrize("S,n", [(2, 4), (16, 1000), (32, 5000), (7, 333)])
+def test_lut16_u8_batch_bit_exact(S, n):
+    rng = np.random.default_rng(S * 1000 + n)
+    tables = rng.random((S, 16), dtype=np.float32) * 3.0
+    lut8, bias, mult = orc.lut16_quantize(tables)
+    codes = rng.integers(0, 16, (n, S), dtype=np.uint8)
+    packed = orc.pack4(codes)
+    got = hip.lut16_distances_batch(packed, lut8, S, n, bias, mult)
+    want = orc.lut16_distances_batch(packed, lut8, S, n, bias, mult)
+    assert np.array_equal(bits(got), bits(want))
+
+
+def test_lut16_reference_vectors():  # src/simd/tests.rs:237-264, src/hashes/lut16_simd.rs:354-375
+    lut = np.zeros((2, 16), np.uint8)
+    lut[0] = np.arange(16)
+    lut[1] = 15 - np.arange(16)
+    got = hip.lut16_distances_batch(np.array([0x00, 0x11, 0x0F, 0xF0], np.uint8), lut, 2, 4, 0.0, 1.0)
+    assert list(got) == [15.0, 15.0, 30.0, 0.0]
+
+
+# ---- a14: Codebook::encode -------------------------------------------------------------------------
+def test_encode_bit_exact():
+    X = synth.uniform_f32(4000, 128, 21)
+    cb = trainer.train_codebook(X, 32, 16, iters=3, seed=4)
+    assert np.array_equal(hip.encode(cb, X), orc.encode_many(cb, X))
+    centers = synth.uniform_f32(6, 128, 8)
+    leaf = (np.arange(4000) % 6).astype(np.uint32)
+    got = hip.encode(cb, X, centers=centers, leaf_of_row=leaf)
+    assert np.array_equal(got, orc.encode_many(cb, X - centers[leaf]))
+
+
+# ---- AsymmetricHasher::search / search_with_reordering ------------------------------------------------
+@pytest.mark.parametrize("n,dim,S,k", [(5000, 128, 32, 10), (20000, 96, 24, 7), (300, 64, 8, 50)])
+def test_ah_search(n, dim, S, k):
+    rows, data, stride, ix, kw = H.make_ah_case(n, dim, S, seed=2, pq_iters=3)
+    index = hip.txh_create(**kw)
+    q = synth.uniform_f32(9, dim, 123)
+    o = hip.default_opts()
+    o.exact_reorder = 0
+    idx, dist, cnt = index.search_batched(q, k, o)
+    for i in range(q.shape[0]):
+        oi, od = orc.ah_search(ix["codebook"], ix["codes"], q[i], k)
+        assert cnt[i] == oi.size
+        H.assert_topk_equal_up_to_ties(idx[i, :cnt[i]], dist[i, :cnt[i]], oi, od, what="ah q%d" % i)
+
+
+@pytest.mark.parametrize("n,dim,S,k,pre_k", [(5000, 128, 32, 10, 100), (20000, 96, 24, 5, 37)])
+def test_ah_search_with_reordering(n, dim, S, k, pre_k):
+    rows, data, stride, ix, kw = H.make_ah_case(n, dim, S, seed=6, pq_iters=3)
+    index = hip.txh_create(**kw)
+    q = synth.uniform_f32(9, dim, 123)
+    o = hip.default_opts()
+    o.pre_reorder_k = pre_k
+    idx, dist, cnt = index.search_batched(q, k, o)
+    for i in range(q.shape[0]):
+        oi, od = orc.ah_search_with_reordering(ix["codebook"], ix["codes"], data, stride, q[i], k, pre_k)
+        assert cnt[i] == oi.size
+        H.assert_topk_equal_up_to_ties(idx[i, :cnt[i]], dist[i, :cnt[i]], oi, od, what="ahr q%d" % i)
+
+
+# ---- TreeXHybridSearcher::search (north-star path), stage by stage ----------------------------------------
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("dim,S", [(128, 32), (96, 24)])
+@pytest.mark.parametrize("P,mult", [(1, 3.0), (4, 3.0), (16, 10.0)])
+def test_txh_search_stages(seed, dim, S, P, mult):
+    n, L, k, nq = 4096, 16, 10, 64
+    rows, data, stride, ix, oix, kw = H.make_txh_case(n, dim, L, S, seed=seed, P=P, mult=mult,
+                                                      kmeans_iters=3, pq_iters=3)
+    index = hip.txh_create(**kw)
+    q = synth.uniform_f32(nq, dim, 123 + seed)
+    m = orc.pre_reorder_k(k, mult)
+    o = hip.default_opts()
+    o.partitions_to_search = P
+    o.pre_reorder_k = m
+    idx, dist, cnt, (tok, tokd, ci, cd, cc) = index.search_batched(q, k, o, stages=True)
+    for i in range(nq):
+        oi, od, otok, otokd, oci, ocd = orc.txh_search(oix, q[i], k, stages=True)
+        assert np.array_equal(tok[i, :P], otok), "tokens q%d" % i
+        assert np.array_equal(bits(tokd[i, :P]), bits(otokd))
+        assert cc[i] == oci.size
+        H.assert_topk_equal_up_to_ties(ci[i, :cc[i]], cd[i, :cc[i]], oci, ocd, what="cand q%d" % i)
+        assert cnt[i] == oi.size
+        H.assert_topk_equal_up_to_ties(idx[i, :cnt[i]], dist[i, :cnt[i]], oi, od, what="final q%d" % i)
+
+
+def test_txh_no_residuals_and_clustered():
+    rows, data, stride, ix, oix, kw = H.make_txh_case(6000, 128, 24, 32, seed=9, P=6, mult=5.0,
+                                                      use_residuals=False, clustered=True,
+                                                      kmeans_iters=3, pq_iters=3)
+    index = hip.txh_create(**kw)
+    q = rows[::200] + np.float32(0.01)
+    idx, dist, cnt = index.search_batched(q, 10)
+    for i in range(q.shape[0]):
+        oi, od = orc.txh_search(oix, q[i], 10)
+        H.assert_topk_equal_up_to_ties(idx[i, :cnt[i]], dist[i, :cnt[i]], oi, od, what="q%d" % i)
+
+
+def test_txh_ragged_and_short_results():
+    """Empty leaves, leaves smaller than m, fewer candidates than k (mod.rs:360-363)."""
+    dim, S = 64, 8
+    rows = synth.uniform_f32(40, dim, 5)
+    centers = synth.uniform_f32(6, dim, 6)
+    assign = np.array([0] * 30 + [2] * 7 + [5] * 3)       # leaves 1, 3, 4 empty
+    built = trainer.build_txh_index(rows, 6, S, centers=centers, assign=assign, pq_iters=2)
+    data, stride = orc.to_strided(rows)
+    oix = orc.TxhIndex(data, stride, dim, built["centers"], built["leaf_off"], built["leaf_ids"],
+                       built["codebook"], built["codes"], partitions_to_search=3,
+                       pre_reorder_multiplier=3.0)
+    index = hip.txh_create(data=data, n_rows=40, dim=dim, stride=stride, centers=built["centers"],
+                           leaf_offsets=built["leaf_off"], leaf_ids=built["leaf_ids"],
+                           codebook=built["codebook"], codes=built["codes"],
+                           partitions_to_search=3, pre_reorder_multiplier=3.0)
+    q = synth.uniform_f32(12, dim, 7)
+    idx, dist, cnt = index.search_batched(q, 10)
+    for i in range(q.shape[0]):
+        oi, od = orc.txh_search(oix, q[i], 10)
+        assert cnt[i] == oi.size
+        H.assert_topk_equal_up_to_ties(idx[i, :cnt[i]], dist[i, :cnt[i]], oi, od, what="q%d" % i)
+
+
+def test_txh_candidate_overflow_retry():
+    """Adversarial order: the strided sample sees only far points, so the first-pass
+    candidate buffer overflows and the host entry retries with a full-size buffer."""
+    dim, S, n = 64, 8, 60000
+    rows = synth.uniform_f32(n, dim, 31)
+    q = synth.uniform_f32(3, dim, 32)
+    cb = trainer.train_codebook(rows, S, 16, iters=3, seed=1)
+    codes = trainer.encode(cb, rows)
+    # order points so that every position divisible by the sample stride is far from q[0]
+    lut = orc.lut_from_query(cb, q[0])
+    d = np.array([orc.lut_distance(lut, c) for c in codes[:n]], np.float32)
+    order = np.argsort(-d, kind="stable")
+    st = -(-n // (8192 - 1))
+    perm = np.empty(n, np.int64)
+    far = list(order[: -(-n // st)])
+    near = list(order[-(-n // st):])
+    fi = ni = 0
+    for pos in range(n):
+        if pos % st == 0:
+            perm[pos] = far[fi]; fi += 1
+        else:
+            perm[pos] = near[ni]; ni += 1
+    rows2, codes2 = rows[perm], codes[perm]
+    data, stride = orc.to_strided(rows2)
+    index = hip.txh_create(data=data, n_rows=n, dim=dim, stride=stride, centers=None,
+                           leaf_offsets=None, leaf_ids=None, codebook=cb, codes=codes2,
+                           use_residuals=False, partitions_to_search=1, pre_reorder_multiplier=1.0)
+    o = hip.default_opts()
+    o.exact_reorder = 0
+    idx, dist, cnt = index.search_batched(q, 10, o)
+    for i in range(3):
+        oi, od = orc.ah_search(cb, codes2, q[i], 10)
+        H.assert_topk_equal_up_to_ties(idx[i], dist[i], oi, od, what="q%d" % i)
+
+
+# ---- brute force -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("measure", [hip.DOT_PRODUCT, hip.SQUARED_L2, hip.L2])
+@pytest.mark.parametrize("n,dim", [(1000, 128), (777, 96), (300, 50), (5000, 32)])
+def test_bf_distances_bit_exact(measure, n, dim):
+    rows = synth.uniform_f32(n, dim, 42)
+    data, stride = orc.to_strided(rows)
+    index = hip.bf_create(data, n, dim, stride, measure)
+    q = synth.uniform_f32(19, dim, 123)
+    got = hip.bf_distances(index, q)
+    for i in range(q.shape[0]):
+        want = orc.one_to_many(q[i], data, stride, n, measure)
+        assert np.array_equal(bits(got[i]), bits(want)), "q%d" % i
+
+
+@pytest.mark.parametrize("measure", [hip.DOT_PRODUCT, hip.SQUARED_L2])
+@pytest.mark.parametrize("n,dim,k,nq", [(10000, 128, 10, 40), (30000, 64, 3, 130), (500, 96, 600, 5)])
+def test_bf_search(measure, n, dim, k, nq):
+    rows = synth.uniform_f32(n, dim, 42)
+    data, stride = orc.to_strided(rows)
+    index = hip.bf_create(data, n, dim, stride, measure)
+    q = synth.uniform_f32(nq, dim, 123)
+    idx, dist, cnt = index.search_batched(q, k)
+    oi, od, oc = orc.bf_search_batched(data, n, dim, stride, measure, q, k)
+    assert np.array_equal(cnt, oc)
+    for i in range(nq):
+        c = cnt[i]
+        H.assert_topk_equal_up_to_ties(idx[i, :c], dist[i, :c], oi[i, :c], od[i, :c], what="bf q%d" % i)
+
+
+def test_bf_reference_vectors():
+    # src/brute_force/searcher.rs:280-376, tests/unit_tests.rs:204-259
+    cube = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1]], np.float32)
+    data, stride = orc.to_strided(cube)
+    index = hip.bf_create(data, 5, 3, stride, hip.SQUARED_L2)
+    idx, dist, cnt = index.search_batched(np.array([[0, 0, 0]], np.float32), 3)
+    assert cnt[0] == 3 and idx[0, 0] == 0 and abs(dist[0, 0]) < 1e-6
+    idx, dist, cnt = index.search_batched(np.array([[0.5, 0.5, 0.5]], np.float32), 5)
+    assert cnt[0] == 5 and np.all(np.diff(dist[0]) >= 0)
+    idx, dist, cnt = index.search_batched(np.array([[0, 0, 0], [1, 1, 1]], np.float32), 2)
+    assert list(cnt) == [2, 2]
+    with pytest.raises(hip.ScannError) as e:      # dimension mismatch -> InvalidArgument
+        index.search_batched(np.array([[1, 2]], np.float32), 5)
+    assert e.value.code == hip.INVALID_ARGUMENT
+    empty = hip.bf_create(np.zeros(0, np.float32), 0, 3, 16, hip.SQUARED_L2)
+    idx, dist, cnt = empty.search_batched(np.array([[1, 2, 3]], np.float32), 5)
+    assert cnt[0] == 0
+    dot = hip.bf_create(*orc.to_strided(np.array([[1, 0], [0, 1], [1, 1]], np.float32))[:1], 3, 2, 16,
+                        hip.DOT_PRODUCT)
+    idx, dist, cnt = dot.search_batched(np.array([[1, 0]], np.float32), 3)
+    assert list(dist[0]) == [-1.0, -1.0, 0.0] and sorted(idx[0, :2].tolist()) == [0, 2]
+
+
+# ---- error behaviour of the boundary ----------------------------------------------------------------
+def test_error_codes():
+    rows, data, stride, ix, oix, kw = H.make_txh_case(600, 64, 4, 8, seed=1, kmeans_iters=2, pq_iters=2)
+    index = hip.txh_create(**kw)
+    with pytest.raises(hip.ScannError) as e:      # tree_x_hybrid/mod.rs:251-253
+        index.search_batched(synth.uniform_f32(2, 32, 1), 5)
+    assert e.value.code == hip.INVALID_ARGUMENT
+    bad = dict(kw)
+    bad["codes"] = kw["codes"][:0]
+    with pytest.raises(hip.ScannError) as e:      # mod.rs:132-134 empty dataset
+        hip.txh_create(**bad)
+    assert e.value.code == hip.INVALID_ARGUMENT
+    bad = dict(kw)
+    bad["codebook"] = np.zeros((7, 16, 9), np.float32)   # 64 % 7 != 0 -> codebook.rs:154-159
+    with pytest.raises(hip.ScannError) as e:
+        hip.txh_create(**bad)
+    assert e.value.code == hip.INVALID_ARGUMENT
+    nostore = dict(kw)
+    nostore["data"] = None                         # hasher.rs:194-197 "Dataset not stored"
+    ns = hip.txh_create(**nostore)
+    with pytest.raises(hip.ScannError) as e:
+        ns.search_batched(synth.uniform_f32(2, 64, 1), 5)
+    assert e.value.code == hip.FAILED_PRECONDITION
+    ah = hip.txh_create(**H.make_ah_case(300, 64, 8, seed=2, pq_iters=2)[4])
+    with pytest.raises(hip.ScannError) as e:      # tree_partitioner.rs:197-198
+        hip.txh_partition(ah, synth.uniform_f32(2, 64, 1), 2)
+    assert e.value.code == hip.FAILED_PRECONDITION
+
+
+# ---- Searcher: Send + Sync (tests/stress_tests.rs:256-297) ---------------------------------------------
+def test_concurrent_queries():
+    rows, data, stride, ix, oix, kw = H.make_txh_case(4096, 64, 16, 8, seed=4, P=4, kmeans_iters=2,
+                                                      pq_iters=2)
+    index = hip.txh_create(**kw)
+    q = synth.uniform_f32(40, 64, 99)
+    want = [orc.txh_search(oix, q[i], 10) for i in range(40)]
+    errs = []
+
+    def worker(t):
+        try:
+            for i in range(t, 40, 4):
+                idx, dist, cnt = index.search_batched(q[i:i + 1], 10)
+                assert cnt[0] == want[i][0].size
+                H.assert_topk_equal_up_to_ties(idx[0, :cnt[0]], dist[0, :cnt[0]], *want[i])
+        except Exception as ex:  # noqa
+            errs.append(ex)
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
