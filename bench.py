@@ -1,0 +1,319 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement of the MI355X ScaNN hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--workload ah|bf_dot|txh] ...
+
+Metric (BASELINE.json): QPS @ recall10@10 + achieved HBM GB/s, 1M x 128 f32.
+Default workload `ah` = BASELINE.json configs[2]: AsymmetricHasher LUT16 (4-bit PQ,
+32 blocks x 16 centres) over 1M x 128 uniform U[0,1) vectors, k = 10, with
+search_with_reordering (exact f32 re-rank of the pre_reorder_k best approximate
+candidates).  A "step" is one search_batched call over one batch of `--batch` queries
+already resident in HBM; value = queries/s of the whole job.
+
+One process per GPU.  N > 1 (launched by torch.distributed.run): the database is sharded
+across ranks (row ranges = leaves of a flat partition), every rank scans its shard for
+all queries, one RCCL all_gather moves (merge key, index, exact distance) triples of the
+per-rank best pre_reorder_k, and every rank merges (strong scaling: total work fixed).
+
+The CPU oracle is used here ONLY as (a) the checker of a few result rows and (b) the
+cpu_baseline leg; the timed path is libscann_hip.so through its C ABI.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--workload", default="ah", choices=["ah", "bf_dot", "txh"])
+    p.add_argument("--n", type=int, default=1_000_000)
+    p.add_argument("--dim", type=int, default=128)
+    p.add_argument("--subspaces", type=int, default=32)
+    p.add_argument("--batch", type=int, default=1024)
+    p.add_argument("--k", type=int, default=10)
+    p.add_argument("--pre-reorder-k", type=int, default=1000)
+    p.add_argument("--leaves", type=int, default=1000)
+    p.add_argument("--partitions-to-search", type=int, default=50)
+    p.add_argument("--dist", default="uniform", choices=["uniform", "clustered"])
+    p.add_argument("--eval-queries", type=int, default=256)
+    p.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-recall", action="store_true")
+    return p.parse_args()
+
+
+def dev_ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from scann_rust_amd import hip, synth, trainer
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    L = hip.load()
+    n, dim, S, K, k, Q = args.n, args.dim, args.subspaces, 16, args.k, args.batch
+    m = args.pre_reorder_k
+    stride = hip.compute_stride(dim)
+    stream = torch.cuda.current_stream().cuda_stream
+    sptr = ctypes.c_void_p(stream)
+
+    # ---------------- data (synthetic, reference-harness shape: U[0,1), seeds 42/123) ----
+    t0 = time.time()
+    lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+    n_loc = hi - lo
+    if args.dist == "uniform":
+        rows = synth.uniform_f32(n_loc, dim, 42, row_offset=lo)
+        queries_all = synth.uniform_f32(max(Q * 4, args.eval_queries), dim, 123)
+    else:
+        if world > 1:
+            raise SystemExit("clustered data is single-GPU only in this round")
+        rows, _ = synth.clustered_f32(n, dim, 7, n_clusters=1000)
+        qsrc, _ = synth.clustered_f32(max(Q * 4, args.eval_queries), dim, 8, n_clusters=1000)
+        queries_all = qsrc
+    data = np.zeros((n_loc, stride), np.float32)
+    data[:, :dim] = rows
+    log("data %.1fs (n_local=%d)" % (time.time() - t0, n_loc))
+
+    workload_name = {"ah": "AsymmetricHasher LUT16 S=%d K=16 + exact re-rank" % S,
+                     "bf_dot": "BruteForceSearcher.search_batched DotProduct (f32 MFMA)",
+                     "txh": "Tree-X-Hybrid L=%d P=%d LUT16 S=%d + exact re-rank"
+                            % (args.leaves, args.partitions_to_search, S)}[args.workload]
+
+    opts = hip.default_opts()
+    index = None
+    algo_bytes_per_query = None
+    flops_per_query = None
+    codebook = codes = None
+    t0 = time.time()
+    if args.workload == "bf_dot":
+        if world > 1:
+            raise SystemExit("bf_dot is single-GPU only in this round")
+        index = hip.bf_create(data, n, dim, stride, hip.DOT_PRODUCT)
+        algo_bytes_per_query = n * dim * 4          # SURVEY.md 8d (per DB pass, B = batch)
+        flops_per_query = 2.0 * n * dim
+    else:
+        # codebook: identical on every rank (trained on a deterministic global sample)
+        if args.dist == "uniform":
+            sel = (synth.splitmix64(0xC0DE, 0, 32768) % np.uint64(n)).astype(np.int64)
+            sample = synth.uniform_rows(sel, dim, 42)
+        else:
+            sample = rows[:: max(1, n // 32768)]
+        if args.workload == "ah":
+            codebook = trainer.train_codebook(sample, S, K, iters=8, seed=42, sample=1 << 30)
+            codes = hip.encode(codebook, data, stride=stride, device=local_rank)
+            if world == 1:
+                index = hip.txh_create(data=data, n_rows=n, dim=dim, stride=stride, centers=None,
+                                       leaf_offsets=None, leaf_ids=None, codebook=codebook,
+                                       codes=codes, use_residuals=False, partitions_to_search=1,
+                                       pre_reorder_multiplier=float(m) / k, device=local_rank)
+            else:
+                # flat partition: leaf g = row range of rank g; all leaves searched
+                sizes = np.array([(n * (g + 1)) // world - (n * g) // world for g in range(world)],
+                                 np.uint32)
+                off = np.zeros(world + 1, np.uint32)
+                off[rank + 1:] = n_loc
+                index = hip.txh_create(
+                    data=data, n_rows=n_loc, dim=dim, stride=stride,
+                    centers=np.zeros((world, dim), np.float32), leaf_offsets=off,
+                    leaf_ids=np.arange(lo, hi, dtype=np.uint32), leaf_sizes_global=sizes,
+                    codebook=codebook, codes=codes, use_residuals=False,
+                    partitions_to_search=world, pre_reorder_multiplier=float(m) / k,
+                    data_is_csr_order=True, device=local_rank)
+            algo_bytes_per_query = n * (S // 2) + S * 16 * 4 + k * 8   # 16 002 128
+        else:
+            raise SystemExit("txh workload is wired in tools/sweep.py; bench default is `ah`")
+        opts.pre_reorder_k = m
+        opts.exact_reorder = 1
+    log("index %.1fs" % (time.time() - t0))
+
+    # ---------------- device buffers (inputs resident in HBM before the timed region) ----
+    nbatches = 4
+    qdev = [torch.from_numpy(np.ascontiguousarray(queries_all[i * Q:(i + 1) * Q])).to(device)
+            for i in range(nbatches)]
+    out_idx = torch.empty((Q, k), dtype=torch.int32, device=device)
+    out_dist = torch.empty((Q, k), dtype=torch.float32, device=device)
+    out_cnt = torch.empty((Q,), dtype=torch.int32, device=device)
+    if world > 1:
+        keys = torch.empty((Q, m), dtype=torch.int64, device=device)
+        cidx = torch.empty((Q, m), dtype=torch.int32, device=device)
+        cex = torch.empty((Q, m), dtype=torch.float32, device=device)
+        ccnt = torch.empty((Q,), dtype=torch.int32, device=device)
+        g_keys = torch.empty((world, Q, m), dtype=torch.int64, device=device)
+        g_idx = torch.empty((world, Q, m), dtype=torch.int32, device=device)
+        g_ex = torch.empty((world, Q, m), dtype=torch.float32, device=device)
+        g_cnt = torch.empty((world, Q), dtype=torch.int32, device=device)
+    hip.check(L.scann_hip_index_reserve(index.h, Q, k, ctypes.byref(opts)))
+
+    def step(i):
+        qd = qdev[i % nbatches]
+        if world == 1:
+            hip.check(L.scann_hip_search_batched_device(index.h, dev_ptr(qd), Q, dim, k,
+                                                        ctypes.byref(opts), dev_ptr(out_idx),
+                                                        dev_ptr(out_dist), dev_ptr(out_cnt), sptr))
+        else:
+            hip.check(L.scann_hip_txh_search_local_device(index.h, dev_ptr(qd), Q, dim, k,
+                                                          ctypes.byref(opts), dev_ptr(keys),
+                                                          dev_ptr(cidx), dev_ptr(cex), dev_ptr(ccnt),
+                                                          sptr))
+            dist.all_gather_into_tensor(g_keys, keys)
+            dist.all_gather_into_tensor(g_idx, cidx)
+            dist.all_gather_into_tensor(g_ex, cex)
+            dist.all_gather_into_tensor(g_cnt, ccnt)
+            hip.check(L.scann_hip_txh_merge_device(hip.context(local_rank), world, Q, m, k,
+                                                   dev_ptr(g_keys), dev_ptr(g_idx), dev_ptr(g_ex),
+                                                   dev_ptr(g_cnt), dev_ptr(out_idx),
+                                                   dev_ptr(out_dist), dev_ptr(out_cnt), sptr))
+
+    # ---------------- warmup, then EXACTLY K timed steps -----------------------------------
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    hip.check(L.scann_hip_index_last_device_status(index.h, sptr))
+    index.enable_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, kernel_name = index.last_kernel_ms()
+    index.enable_timing(False)
+    hip.check(L.scann_hip_index_last_device_status(index.h, sptr))
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    qps = Q * args.steps / elapsed
+
+    # ---------------- recall10@10 (bin/ann_benchmark.rs:427-471 semantics) ------------------
+    recall = None
+    checked = None
+    if not args.no_recall and world == 1 and args.workload != "bf_dot":
+        ne = min(args.eval_queries, queries_all.shape[0])
+        qe = np.ascontiguousarray(queries_all[:ne])
+        gi, gd, gc = index.search_batched(qe, k, opts)
+        bf = hip.bf_create(data, n, dim, stride, hip.SQUARED_L2, device=local_rank)
+        ti, td, tc = bf.search_batched(qe, k)
+        hits = sum(len(set(gi[i].tolist()) & set(ti[i].tolist())) for i in range(ne))
+        recall = hits / float(ne * k)
+        bf.close()
+    if rank == 0 and world == 1:
+        # result rows of the timed path checked against the oracle (checker only)
+        from oracle import pyoracle as orc
+        nchk = 4
+        qe = np.ascontiguousarray(queries_all[:nchk])
+        gi, gd, gc = index.search_batched(qe, k, opts)
+        ok = True
+        for i in range(nchk):
+            if args.workload == "bf_dot":
+                oi, od = orc.bf_search(data, n, dim, stride, orc.DOT_PRODUCT, qe[i], k)
+            else:
+                oi, od = orc.ah_search_with_reordering(codebook, codes, data, stride, qe[i], k, m)
+            ok = ok and np.array_equal(gd[i].view(np.uint32), od.view(np.uint32)) \
+                and sorted(gi[i].tolist()) == sorted(oi.tolist())
+        checked = bool(ok)
+
+    # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N = 1) -------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as orc
+        threads = orc.max_threads()
+        nq0 = min(threads, queries_all.shape[0])
+        qs = np.ascontiguousarray(queries_all[:nq0])
+
+        def run_cpu(qb):
+            t1 = time.perf_counter()
+            if args.workload == "bf_dot":
+                orc.bf_search_batched(data, n, dim, stride, orc.DOT_PRODUCT, qb, k, threads)
+            else:
+                orc.ah_search_batched(codebook, codes, data, stride, qb, k, m, True, threads)
+            return time.perf_counter() - t1
+
+        t_probe = run_cpu(qs)
+        reps = int(max(1, min(64, args.cpu_baseline_seconds / max(t_probe, 1e-3))))
+        nq1 = min(queries_all.shape[0], nq0 * reps)
+        t_run = run_cpu(np.ascontiguousarray(queries_all[:nq1]))
+        cpu = {"value": nq1 / t_run, "unit": "queries/s", "cores": threads, "kind": "port",
+               "sample": "%d queries of the same workload (same index, k, pre_reorder_k), "
+                         "one OpenMP task per query, %.1f s" % (nq1, t_run)}
+
+    if rank == 0:
+        if args.workload == "bf_dot":
+            achieved = flops_per_query * Q / (kernel_ms * 1e-3) / 1e12 if kernel_ms else 0.0
+            roof = {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "kernel": kernel_name, "kernel_ms": kernel_ms,
+                    "algorithmic": "2*N*d flop per query x %d queries per launch" % Q}
+        else:
+            achieved = algo_bytes_per_query * Q / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kernel_name,
+                    "kernel_ms": kernel_ms,
+                    "algorithmic": "%d B per query (N*S/2 codes + S*16*4 LUT + k*8 out) x %d "
+                                   "queries per launch" % (algo_bytes_per_query, Q)}
+        tr = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tr):
+            try:
+                roof["traffic"] = json.load(open(tr)).get(args.workload)
+            except Exception:
+                pass
+        line = {
+            "metric": "QPS @ recall10@10 + achieved HBM GB/s, 1M x 128 f32",
+            "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload_name, "n": n, "dim": dim, "k": k, "batch": Q,
+                       "pre_reorder_k": m if args.workload != "bf_dot" else None,
+                       "distribution": args.dist, "recall10@10": recall,
+                       "oracle_check": checked,
+                       "parallelism": "1 process/GPU, leaf(row-range)-sharded x%d + RCCL all_gather"
+                                      % world if world > 1 else "single GPU"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

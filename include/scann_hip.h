@@ -243,9 +243,10 @@ uint64_t scann_hip_index_size(const scann_hip_index *index);          /* Searche
 uint32_t scann_hip_index_dimensionality(const scann_hip_index *index);/* Searcher::dimensionality */
 void scann_hip_index_destroy(scann_hip_index *index);
 
-/* Kernel timing hook for bench.py: HIP-event time (ms) of the dominant kernel of the
- * last search on `index`, measured on the stream the kernel was launched on
- * (0 if timing was not enabled). */
+/* Kernel timing hook for bench.py: mean HIP-event time (ms) of the dominant kernel over
+ * the search launches issued on `index` since timing was enabled (ring of 64 event pairs
+ * recorded on the stream each kernel was launched on; 0 if timing is off).  Enabling
+ * resets the ring; reading synchronises on the recorded events. */
 void scann_hip_index_enable_timing(scann_hip_index *index, int enable);
 float scann_hip_index_last_kernel_ms(scann_hip_index *index, const char **out_kernel_name);
 

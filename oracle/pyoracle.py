@@ -104,6 +104,9 @@ def lib():
         L.or_ah_search_with_reordering.restype = C.c_int
         L.or_ah_search_with_reordering.argtypes = [f32p, sz, sz, sz, u8p, sz, f32p, sz,
                                                    f32p, sz, sz, sz, u32p, f32p]
+        L.or_ah_search_batched.restype = C.c_int
+        L.or_ah_search_batched.argtypes = [f32p, sz, sz, sz, u8p, sz, f32p, sz, f32p, sz, sz, sz,
+                                           sz, C.c_int, u32p, f32p, u32p, C.c_int]
         L.or_txh_search.restype = C.c_int
         L.or_txh_search.argtypes = [C.POINTER(TxhIndexC), f32p, sz, sz, u32p, f32p,
                                     u32p, f32p, C.POINTER(sz), u32p, f32p, C.POINTER(sz)]
@@ -363,6 +366,26 @@ def ah_search_with_reordering(codebook, codes, data, stride, q, k, pre_k):
     if r < 0:
         raise ValueError("InvalidArgument")
     return oi[:r].copy(), od[:r].copy()
+
+
+def ah_search_batched(codebook, codes, data, stride, queries, k, pre_k=0, reorder=True,
+                      nthreads=0):
+    codebook, pcb = _f(codebook); codes, pc = _u8(codes); queries, pq = _f(queries)
+    pd = None
+    if data is not None:
+        data, pd = _f(data)
+    S, K, dsub = codebook.shape
+    n = codes.shape[0]
+    nq = queries.shape[0]
+    kk = max(k, 1)
+    oi = np.zeros((nq, kk), np.uint32); od = np.zeros((nq, kk), np.float32)
+    oc = np.zeros(nq, np.uint32)
+    r = lib().or_ah_search_batched(pcb, S, K, dsub, pc, n, pd, stride, pq, nq, queries.shape[1],
+                                   k, pre_k, 1 if reorder else 0, oi.ctypes.data_as(u32p),
+                                   od.ctypes.data_as(f32p), oc.ctypes.data_as(u32p), nthreads)
+    if r < 0:
+        raise ValueError("InvalidArgument")
+    return oi[:, :k], od[:, :k], oc
 
 
 # ---- Tree-X-Hybrid --------------------------------------------------------------------------

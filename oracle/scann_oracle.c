@@ -775,6 +775,36 @@ int or_ah_search_with_reordering(const float *codebook, size_t S, size_t K, size
     return (int)r;
 }
 
+/* AsymmetricHasher::search_batched (hasher.rs:232-238) is a plain sequential map in
+ * the reference; nthreads > 1 runs one query per task the way the other searchers'
+ * par_iter does (reported as such by the CPU baseline). */
+int or_ah_search_batched(const float *codebook, size_t S, size_t K, size_t dsub,
+                         const uint8_t *codes, size_t n, const float *data, size_t stride,
+                         const float *queries, size_t nq, size_t q_stride, size_t k,
+                         size_t pre_reorder_k, int reorder, uint32_t *out_idx,
+                         float *out_dist, uint32_t *out_count, int nthreads) {
+    int err = 0;
+    if (nthreads <= 0) nthreads = or_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (long qi = 0; qi < (long)nq; ++qi) {
+        int r;
+        if (reorder)
+            r = or_ah_search_with_reordering(codebook, S, K, dsub, codes, n, data, stride,
+                                             queries + qi * q_stride, S * dsub, k, pre_reorder_k,
+                                             out_idx + qi * k, out_dist + qi * k);
+        else
+            r = or_ah_search(codebook, S, K, dsub, codes, n, queries + qi * q_stride, S * dsub, k,
+                             out_idx + qi * k, out_dist + qi * k);
+        if (r < 0) {
+#pragma omp atomic write
+            err = r;
+            r = 0;
+        }
+        out_count[qi] = (uint32_t)r;
+    }
+    return err;
+}
+
 /* ------------------------------------------------------------------------ */
 /* Tree-X-Hybrid: tree_x_hybrid/mod.rs:245-364                              */
 /* ------------------------------------------------------------------------ */

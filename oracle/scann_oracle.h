@@ -134,6 +134,13 @@ int or_ah_search_with_reordering(const float *codebook, size_t S, size_t K,
                                  size_t pre_reorder_k, uint32_t *out_idx,
                                  float *out_dist);
 
+/* hasher.rs:232-238 (sequential map in the reference; nthreads = tasks per query) */
+int or_ah_search_batched(const float *codebook, size_t S, size_t K, size_t dsub,
+                         const uint8_t *codes, size_t n, const float *data, size_t stride,
+                         const float *queries, size_t nq, size_t q_stride, size_t k,
+                         size_t pre_reorder_k, int reorder, uint32_t *out_idx,
+                         float *out_dist, uint32_t *out_count, int nthreads);
+
 /* ---- Tree-X-Hybrid (tree_x_hybrid/mod.rs:245-364) ----------------------- */
 typedef struct {
     uint32_t n, dim, stride;

@@ -43,9 +43,22 @@ struct scann_hip_index {
     int kind = 0;
     std::mutex mu;  // serialises searches on one handle (callers may be concurrent)
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // ring of HIP event pairs bracketing the dominant kernel of each search launch
+    static constexpr int kEvRing = 64;
+    hipEvent_t evs[kEvRing][2] = {};
+    uint32_t ev_n = 0;      // launches recorded since timing was enabled
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // pair handed to the current launch
     bool timing = false;
     bool timing_valid = false;
+    void next_events() {
+        if (!timing) {
+            ev0 = ev1 = nullptr;
+            return;
+        }
+        ev0 = evs[ev_n % kEvRing][0];
+        ev1 = evs[ev_n % kEvRing][1];
+        ++ev_n;
+    }
     const char *timed_kernel = "";
     DevBuf status_word;
 
@@ -112,8 +125,10 @@ void scann_hip_search_opts_default(scann_hip_search_opts *o) {
 
 static int index_common_init(scann_hip_index *ix) {
     SCANN_HIP_CHECK(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
-    SCANN_HIP_CHECK(hipEventCreate(&ix->ev0));
-    SCANN_HIP_CHECK(hipEventCreate(&ix->ev1));
+    for (int i = 0; i < scann_hip_index::kEvRing; ++i) {
+        SCANN_HIP_CHECK(hipEventCreate(&ix->evs[i][0]));
+        SCANN_HIP_CHECK(hipEventCreate(&ix->evs[i][1]));
+    }
     return SCANN_HIP_OK;
 }
 
@@ -121,8 +136,10 @@ void scann_hip_index_destroy(scann_hip_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->ctx->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    if (ix->ev0) (void)hipEventDestroy(ix->ev0);
-    if (ix->ev1) (void)hipEventDestroy(ix->ev1);
+    for (int i = 0; i < scann_hip_index::kEvRing; ++i) {
+        if (ix->evs[i][0]) (void)hipEventDestroy(ix->evs[i][0]);
+        if (ix->evs[i][1]) (void)hipEventDestroy(ix->evs[i][1]);
+    }
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
 }
@@ -137,16 +154,27 @@ uint32_t scann_hip_index_dimensionality(const scann_hip_index *ix) {
 }
 
 void scann_hip_index_enable_timing(scann_hip_index *ix, int enable) {
-    if (ix) ix->timing = enable != 0;
+    if (!ix) return;
+    ix->timing = enable != 0;
+    ix->ev_n = 0;
+    ix->timing_valid = false;
 }
 
 float scann_hip_index_last_kernel_ms(scann_hip_index *ix, const char **name) {
     if (name) *name = ix ? ix->timed_kernel : "";
-    if (!ix || !ix->timing_valid) return 0.0f;
-    float ms = 0.0f;
-    if (hipEventSynchronize(ix->ev1) != hipSuccess) return 0.0f;
-    if (hipEventElapsedTime(&ms, ix->ev0, ix->ev1) != hipSuccess) return 0.0f;
-    return ms;
+    if (!ix || !ix->timing_valid || ix->ev_n == 0) return 0.0f;
+    const uint32_t cnt = ix->ev_n < (uint32_t)scann_hip_index::kEvRing
+                             ? ix->ev_n : (uint32_t)scann_hip_index::kEvRing;
+    double sum = 0.0;
+    uint32_t ok = 0;
+    for (uint32_t i = 0; i < cnt; ++i) {   // mean over the recorded launches
+        float ms = 0.0f;
+        if (hipEventSynchronize(ix->evs[i][1]) != hipSuccess) continue;
+        if (hipEventElapsedTime(&ms, ix->evs[i][0], ix->evs[i][1]) != hipSuccess) continue;
+        sum += ms;
+        ++ok;
+    }
+    return ok ? (float)(sum / ok) : 0.0f;
 }
 
 // =====================================================================================
@@ -466,8 +494,9 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
         SCANN_TRY(ensure_txh_workspace(ix, nq, p, true, q_stride, true, &w));
         SCANN_HIP_CHECK(hipMemcpyAsync(ix->ws.queries.p, queries, (size_t)nq * q_stride * 4,
                                        hipMemcpyHostToDevice, ix->stream));
-        SCANN_TRY(txh_launch_search(ix->tx, w, false, ix->stream, ix->timing ? ix->ev0 : nullptr,
-                                    ix->timing ? ix->ev1 : nullptr));
+        ix->next_events();
+        SCANN_TRY(txh_launch_search(ix->tx, w, false, ix->stream, ix->ev0,
+                                    ix->ev1));
         ix->timing_valid = ix->timing;
         ix->timed_kernel = "adc_scan_kernel";
         uint32_t counters[CNT_N];
@@ -529,9 +558,10 @@ int scann_hip_search_batched(scann_hip_index *ix, const float *queries, uint32_t
         }
         std::lock_guard<std::mutex> lock(ix->mu);
         SCANN_TRY(set_device(ix->ctx));
+        ix->next_events();
         int s = bf_search_host(ix->bf, ix->bfw, queries, nq, q_stride, k, out_idx, out_dist, out_count,
-                               ix->stream, ix->timing ? ix->ev0 : nullptr,
-                               ix->timing ? ix->ev1 : nullptr);
+                               ix->stream, ix->ev0,
+                               ix->ev1);
         ix->timing_valid = ix->timing && s == SCANN_HIP_OK;
         ix->timed_kernel = "bf_mfma_kernel";
         return s;
@@ -569,9 +599,10 @@ int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries,
     std::lock_guard<std::mutex> lock(ix->mu);
     SCANN_TRY(set_device(ix->ctx));
     if (ix->kind == KIND_BF) {
+        ix->next_events();
         int s = bf_search_device(ix->bf, ix->bfw, d_queries, nq, q_stride, k, d_out_idx, d_out_dist,
-                                 d_out_count, st, ix->timing ? ix->ev0 : nullptr,
-                                 ix->timing ? ix->ev1 : nullptr);
+                                 d_out_count, st, ix->ev0,
+                                 ix->ev1);
         ix->timing_valid = ix->timing && s == SCANN_HIP_OK;
         ix->timed_kernel = "bf_mfma_kernel";
         return s;
@@ -586,8 +617,9 @@ int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries,
     w.out_dist = d_out_dist;
     w.out_count = d_out_count;
     ix->last_work = w;
-    SCANN_TRY(txh_launch_search(ix->tx, w, false, st, ix->timing ? ix->ev0 : nullptr,
-                                ix->timing ? ix->ev1 : nullptr));
+    ix->next_events();
+    SCANN_TRY(txh_launch_search(ix->tx, w, false, st, ix->ev0,
+                                ix->ev1));
     ix->timing_valid = ix->timing;
     ix->timed_kernel = "adc_scan_kernel";
     return SCANN_HIP_OK;
@@ -632,8 +664,9 @@ int scann_hip_txh_search_local_device(scann_hip_index *ix, const float *d_querie
     w.cand_exact = d_exact;
     w.cand_count = d_count;
     ix->last_work = w;
-    SCANN_TRY(txh_launch_search(ix->tx, w, true, st, ix->timing ? ix->ev0 : nullptr,
-                                ix->timing ? ix->ev1 : nullptr));
+    ix->next_events();
+    SCANN_TRY(txh_launch_search(ix->tx, w, true, st, ix->ev0,
+                                ix->ev1));
     ix->timing_valid = ix->timing;
     ix->timed_kernel = "adc_scan_kernel";
     return SCANN_HIP_OK;

@@ -25,14 +25,26 @@ def splitmix64(seed, start, count):
     return z
 
 
-def uniform_f32(n, dim, seed, chunk_rows=1 << 16):
-    """[n, dim] f32, i.i.d. U[0,1) with 24-bit mantissas."""
+def uniform_f32(n, dim, seed, chunk_rows=1 << 16, row_offset=0):
+    """[n, dim] f32, i.i.d. U[0,1) with 24-bit mantissas: rows row_offset .. row_offset+n
+    of the (unbounded) dataset `seed` -- the generator is counter based, so any row range
+    can be produced independently (each rank of a sharded run generates only its rows)."""
     out = np.empty((n, dim), np.float32)
     for r0 in range(0, n, chunk_rows):
         r1 = min(n, r0 + chunk_rows)
-        u = splitmix64(seed, r0 * dim, (r1 - r0) * dim)
+        u = splitmix64(seed, (row_offset + r0) * dim, (r1 - r0) * dim)
         out[r0:r1] = ((u >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)
                       ).reshape(r1 - r0, dim)
+    return out
+
+
+def uniform_rows(rows, dim, seed):
+    """Selected rows (by index) of the dataset uniform_f32(., dim, seed)."""
+    rows = np.asarray(rows, np.int64)
+    out = np.empty((rows.size, dim), np.float32)
+    for i, r in enumerate(rows):
+        u = splitmix64(seed, int(r) * dim, dim)
+        out[i] = (u >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)
     return out
 
 
