@@ -51,7 +51,7 @@ def parse():
     p.add_argument("--subspaces", type=int, default=32)
     p.add_argument("--batch", type=int, default=1024)
     p.add_argument("--k", type=int, default=10)
-    p.add_argument("--pre-reorder-k", type=int, default=1000)
+    p.add_argument("--pre-reorder-k", type=int, default=5000)
     p.add_argument("--leaves", type=int, default=1000)
     p.add_argument("--partitions-to-search", type=int, default=50)
     p.add_argument("--dist", default="uniform", choices=["uniform", "clustered"])

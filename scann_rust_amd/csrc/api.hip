@@ -35,7 +35,7 @@ enum IndexKind { KIND_BF = 1, KIND_TXH = 2 };
 struct TxhWorkspace {
     DevBuf queries, cdist, tokens, token_dists, vbase, leaf_cnt, leaf_cursor, pair_off, tile_off,
         counters, pair_q, pair_leaf, pair_vbase, slot_of, lutq, thr, cand_cnt, cand, cand_key,
-        cand_idx, cand_dist, cand_exact, cand_count, out_idx, out_dist, out_count;
+        cand_idx, cand_dist, cand_exact, cand_row, cand_count, out_idx, out_dist, out_count;
 };
 
 struct scann_hip_index {
@@ -345,6 +345,7 @@ int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_
 struct TxhCallParams {
     uint32_t P, m, k, cap;
     int exact_reorder;
+    int no_threshold;
 };
 
 static uint64_t max_stream(const scann_hip_index *ix, uint32_t P) {
@@ -361,7 +362,7 @@ static int resolve_params(const scann_hip_index *ix, uint32_t k, const scann_hip
     uint32_t P = o->partitions_to_search ? o->partitions_to_search : ix->default_P;
     P = std::min(P, ix->tx.L);  // tree_partitioner.rs:214
     if (ix->tx.ah_mode) P = 1;
-    if (P > kSampleCap / 2)
+    if (P > kMaxPartitionsToSearch)
         return fail(SCANN_HIP_UNIMPLEMENTED, "partitions_to_search > 4096");
     uint32_t m;
     if (!o->exact_reorder) {
@@ -378,18 +379,30 @@ static int resolve_params(const scann_hip_index *ix, uint32_t k, const scann_hip
                         std::to_string(kMaxPreReorderK));
     if (o->exact_reorder && !ix->tx.rows)  // hasher.rs:194-197
         return fail(SCANN_HIP_FAILED_PRECONDITION, "Dataset not stored");
-    const uint64_t ms = std::max<uint64_t>(1, max_stream(ix, P));
+    const uint64_t ms = std::min<uint64_t>(std::max<uint64_t>(1, max_stream(ix, P)), 0xFFFFFFFFull);
     uint64_t cap = ms;
     if (!full_cap) {
-        const uint64_t room = kSampleCap - P;
-        const uint64_t st = std::max<uint64_t>(1, (ms + room - 1) / room);
-        cap = std::min<uint64_t>(ms, 2ull * m * st + 16ull * st + 256ull);
+        // upper bound of the survivors of the sampled threshold for every stride a query of
+        // this batch can get (sample_stride is monotone in the stream length)
+        const uint32_t st_max = sample_stride((uint32_t)ms);
+        cap = std::min<uint64_t>(ms, m);
+        for (uint32_t st = 1; st <= st_max; ++st) {
+            const uint32_t j = sample_rank(m, st);
+            uint64_t bound;
+            if (j == 0)
+                bound = (uint64_t)st * kSampleTarget;
+            else
+                bound = (uint64_t)((double)j + 8.0 * std::sqrt((double)j) + 16.0) * st + 256;
+            cap = std::max(cap, bound);
+        }
+        cap = std::min(cap, ms);
     }
     out->P = P;
     out->m = m;
     out->k = k;
     out->cap = (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFull);
     out->exact_reorder = o->exact_reorder ? 1 : 0;
+    out->no_threshold = full_cap ? 1 : 0;
     return SCANN_HIP_OK;
 }
 
@@ -423,6 +436,7 @@ static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallP
     SCANN_TRY(s.cand_idx.ensure((size_t)nq * m * 4));
     SCANN_TRY(s.cand_dist.ensure((size_t)nq * m * 4));
     SCANN_TRY(s.cand_exact.ensure((size_t)nq * m * 4));
+    SCANN_TRY(s.cand_row.ensure((size_t)nq * m * 4));
     SCANN_TRY(s.cand_count.ensure((size_t)nq * 4));
     if (own_outputs) {
         SCANN_TRY(s.out_idx.ensure((size_t)nq * k * 4));
@@ -436,6 +450,7 @@ static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallP
     w->k = p.k;
     w->cap = p.cap;
     w->exact_reorder = p.exact_reorder;
+    w->no_threshold = p.no_threshold;
     w->queries = s.queries.as<float>();
     w->cdist = s.cdist.as<float>();
     w->tokens = s.tokens.as<uint32_t>();
@@ -460,6 +475,7 @@ static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallP
     w->cand_idx = s.cand_idx.as<uint32_t>();
     w->cand_dist = s.cand_dist.as<float>();
     w->cand_exact = s.cand_exact.as<float>();
+    w->cand_row = s.cand_row.as<uint32_t>();
     w->cand_count = s.cand_count.as<uint32_t>();
     w->out_idx = s.out_idx.as<uint32_t>();
     w->out_dist = s.out_dist.as<float>();
@@ -527,9 +543,11 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
         }
         SCANN_HIP_CHECK(hipStreamSynchronize(ix->stream));
         if (counters[CNT_STATUS] == SCANN_HIP_OK) return SCANN_HIP_OK;
-        if (counters[CNT_STATUS] != SCANN_HIP_RESOURCE_EXHAUSTED || attempt == 1)
+        if ((counters[CNT_STATUS] != SCANN_HIP_RESOURCE_EXHAUSTED &&
+             counters[CNT_STATUS] != SCANN_HIP_ABORTED) || attempt == 1)
             return fail((int)counters[CNT_STATUS], "device reported a search failure");
-        // candidate buffer overflow: retry once with a buffer that holds the whole stream
+        // candidate buffer overflow, or a statistical threshold that kept fewer than m
+        // points: retry once without a threshold and with a buffer for the whole stream
     }
     return fail(SCANN_HIP_INTERNAL, "unreachable");
 }
@@ -636,8 +654,8 @@ int scann_hip_index_last_device_status(scann_hip_index *ix, void *hip_stream) {
     SCANN_HIP_CHECK(hipStreamSynchronize(st));
     if (counters[CNT_STATUS] != SCANN_HIP_OK)
         return fail((int)counters[CNT_STATUS],
-                    "candidate buffer overflow on the device path (use the host entry point, "
-                    "which retries with a full-size buffer)");
+                    "candidate threshold/buffer miss on the device path (use the host entry "
+                    "point, which retries without a threshold and with a full-size buffer)");
     return SCANN_HIP_OK;
 }
 

@@ -9,12 +9,41 @@ constexpr uint32_t kScanThreads = 256;
 constexpr uint32_t kScanPPT = 4;                          // points per thread per chunk
 constexpr uint32_t kScanTP = kScanThreads * kScanPPT;     // points per tile chunk
 constexpr uint32_t kScanQuadsPerTile = 32;                // query quads per tile
-constexpr uint32_t kSortCap = 8192;                       // u64 keys sorted in LDS
-constexpr uint32_t kSampleCap = 8192;                     // threshold sample size (keys)
-constexpr uint32_t kMaxPreReorderK = 2048;                // m limit of the LDS select
+constexpr uint32_t kSortCap = 16384;                      // u64 keys sorted in LDS (select)
+constexpr uint32_t kSampleBuf = 8192;                     // LDS key buffer of the sampler
+constexpr uint32_t kSampleBest = 4096;                    // max rank taken from the sample
+constexpr uint32_t kSampleTarget = 65536;                 // max sample points per query
+constexpr uint32_t kSampleMin = 4096;                     // min sample points per query
+constexpr uint32_t kMaxPreReorderK = 8192;                // m limit of the LDS select
+constexpr uint32_t kMaxPartitionsToSearch = 4096;
 constexpr uint32_t kMaxLeavesSelect = 16384;              // L limit of the LDS leaf sort
 constexpr uint32_t kSelectThreads = 1024;
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+
+// ---- threshold sampling plan (shared by host buffer sizing and the device sampler) ----
+// A query whose selected leaves hold `total` local points is sampled every `st`-th
+// point; the threshold is the j-th smallest sample key.  j == m gives a deterministic
+// bound (any subset's m-th smallest key bounds the stream's m-th smallest); j < m is a
+// 6-sigma statistical bound that select_rerank VERIFIES (>= m survivors, else the host
+// entry retries without a threshold), so results stay exact either way.
+__host__ __device__ static inline uint32_t sample_stride(uint32_t total) {
+    uint32_t ns = total / 16u;
+    if (ns < kSampleMin) ns = kSampleMin;
+    if (ns > kSampleTarget) ns = kSampleTarget;
+    uint32_t st = (total + ns - 1u) / ns;
+    return st ? st : 1u;
+}
+// 0 = use no threshold.
+__host__ __device__ static inline uint32_t sample_rank(uint32_t m, uint32_t st) {
+    if (m == 0) return 0;
+    const float r = (float)m / (float)st;
+    const float s = 0.5f * (6.0f + sqrtf(36.0f + 4.0f * r));
+    const float jp = s * s + 2.0f;
+    uint32_t j = jp >= (float)m ? m : (uint32_t)jp;
+    if (j > m) j = m;
+    if (j == 0) j = 1;
+    return j > kSampleBest ? 0u : j;
+}
 
 struct TxhIndexDev {
     uint32_t dim, stride, L, S, K, dsub, nw;
@@ -37,6 +66,7 @@ enum { CNT_TOTAL_QUADS = 0, CNT_TOTAL_TILES = 1, CNT_QUEUE_HEAD = 2, CNT_STATUS 
 struct TxhWork {
     uint32_t nq, q_stride, P, m, k, cap;
     int exact_reorder;
+    int no_threshold;          // retry mode: keep every scanned point as a candidate
     const float *queries;      // device
     float *cdist;              // [nq][L]
     uint32_t *tokens;          // [nq][P]
@@ -60,6 +90,7 @@ struct TxhWork {
     uint32_t *cand_idx;        // [nq][m]
     float *cand_dist;          // [nq][m] approximate
     float *cand_exact;         // [nq][m]
+    uint32_t *cand_row;        // [nq][m] re-rank row of each candidate
     uint32_t *cand_count;      // [nq]
     uint32_t *out_idx;         // [nq][k]
     float *out_dist;           // [nq][k]

@@ -290,19 +290,21 @@ __device__ __forceinline__ float adc_row_sum(const float *lut, const uint32_t *w
 }
 
 // =====================================================================================
-// K5: threshold from a strided sample.  Any subset's m-th smallest key is an upper bound
-// of the stream's m-th smallest key, so filtering with `key <= thr` keeps every member
-// of the exact top-m; the sample only controls how many extra candidates survive.
+// K5: threshold from a strided sample (plan: sample_stride / sample_rank in txh.h).
+// One block per query streams up to kSampleTarget sampled points through an LDS buffer
+// that keeps the J best keys seen so far: new keys enter only if <= the current J-th
+// best, and the buffer is sorted and cut back to J whenever it could overflow.
 // =====================================================================================
 template <int NW>
 __global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(
-    TxhIndexDev ix, uint32_t P, uint32_t m, const uint32_t *__restrict__ tokens,
-    const uint32_t *__restrict__ vbase, const uint32_t *__restrict__ slot_of,
-    const float *__restrict__ lutq, uint64_t *__restrict__ thr) {
+    TxhIndexDev ix, uint32_t P, uint32_t m, int no_threshold,
+    const uint32_t *__restrict__ tokens, const uint32_t *__restrict__ vbase,
+    const uint32_t *__restrict__ slot_of, const float *__restrict__ lutq,
+    uint64_t *__restrict__ thr) {
     constexpr int S = NW * 8;
-    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];      // [kSampleCap]
-    float *slut = reinterpret_cast<float *>(skeys + kSampleCap);          // [S*16]
-    uint32_t *s_total = reinterpret_cast<uint32_t *>(slut + S * 16);      // [4]
+    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];      // [kSampleBuf]
+    float *slut = reinterpret_cast<float *>(skeys + kSampleBuf);          // [S*16]
+    uint32_t *s_misc = reinterpret_cast<uint32_t *>(slut + S * 16);       // [0]=fill [1]=total
     const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     if (tid == 0) {
         uint32_t tot = 0;
@@ -310,13 +312,37 @@ __global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(
             uint32_t leaf = tokens[(size_t)q * P + r];
             tot += ix.leaf_off[leaf + 1] - ix.leaf_off[leaf];
         }
-        s_total[0] = tot;
+        s_misc[1] = tot;
+        s_misc[0] = 0;
     }
     __syncthreads();
-    const uint32_t total = s_total[0];
-    const uint32_t room = kSampleCap - P;
-    const uint32_t st = max(1u, (total + room - 1) / room);
-    uint32_t base = 0;
+    const uint32_t total = s_misc[1];
+    const uint32_t st = sample_stride(total);
+    const uint32_t J = (no_threshold || total <= m) ? 0u : sample_rank(m, st);
+    if (J == 0) {   // uniform
+        if (tid == 0) thr[q] = SCANN_KEY_MAX;
+        return;
+    }
+    uint32_t B = 2048;
+    while (B < 4 * J && B < kSampleBuf) B <<= 1;       // B >= J + nt always (J <= 4096)
+    uint64_t Tcur = SCANN_KEY_MAX;
+    uint32_t fill = 0;
+
+    auto compact = [&]() {   // sort the buffer, keep the J best; every thread calls
+        uint32_t n2 = 1;
+        while (n2 < fill) n2 <<= 1;
+        for (uint32_t i = fill + tid; i < n2; i += nt) skeys[i] = SCANN_KEY_MAX;
+        __syncthreads();
+        bitonic_sort_lds(skeys, n2);
+        if (fill > J) {
+            fill = J;
+            Tcur = skeys[J - 1];
+        }
+        __syncthreads();
+        if (tid == 0) s_misc[0] = fill;
+        __syncthreads();
+    };
+
     for (uint32_t r = 0; r < P; ++r) {
         const uint32_t leaf = tokens[(size_t)q * P + r];
         const uint32_t lb = ix.leaf_off[leaf];
@@ -328,27 +354,24 @@ __global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(
         __syncthreads();
         const uint32_t ns = (sz + st - 1) / st;
         const uint32_t vb = vbase[(size_t)q * (P + 1) + r];
-        for (uint32_t i = tid; i < ns; i += nt) {
-            const uint32_t j = i * st;
-            uint32_t w[NW];
+        for (uint32_t base = 0; base < ns; base += nt) {
+            if (fill + nt > B) compact();
+            const uint32_t i = base + tid;
+            if (i < ns) {
+                const uint32_t j = i * st;
+                uint32_t w[NW];
 #pragma unroll
-            for (int wi = 0; wi < NW; ++wi) w[wi] = ix.codes[(size_t)(lb + j) * NW + wi];
-            skeys[base + i] = make_key(adc_row_sum<NW>(slut, w), vb + j);
+                for (int wi = 0; wi < NW; ++wi) w[wi] = ix.codes[(size_t)(lb + j) * NW + wi];
+                const uint64_t key = make_key(adc_row_sum<NW>(slut, w), vb + j);
+                if (key <= Tcur) skeys[atomicAdd(&s_misc[0], 1u)] = key;
+            }
+            __syncthreads();
+            fill = s_misc[0];
         }
-        base += ns;
         __syncthreads();
     }
-    const uint32_t cnt = base;
-    if (m == 0 || cnt < m) {
-        if (tid == 0) thr[q] = SCANN_KEY_MAX;
-        return;
-    }
-    uint32_t n2 = 1;
-    while (n2 < cnt) n2 <<= 1;
-    for (uint32_t i = cnt + tid; i < n2; i += nt) skeys[i] = SCANN_KEY_MAX;
-    __syncthreads();
-    bitonic_sort_lds(skeys, n2);
-    if (tid == 0) thr[q] = skeys[m - 1];
+    compact();
+    if (tid == 0) thr[q] = (fill >= J) ? skeys[J - 1] : SCANN_KEY_MAX;
 }
 
 // =====================================================================================
@@ -414,6 +437,8 @@ __device__ __forceinline__ void scan_quad_compute(const float4 *lut_base,
 }
 
 static_assert(kScanPPT == 4, "adc_scan_kernel's nsub switch assumes 4 points per thread");
+constexpr uint32_t kScanStage = 128;   // LDS-staged survivors per (quad, query); <= kScanThreads
+static_assert(kScanStage <= kScanThreads, "the flush copies one survivor per thread");
 
 struct ScanArgs {
     const uint32_t *pair_off, *tile_off, *pair_q, *pair_vbase;
@@ -431,9 +456,18 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 4 : 2)) void adc_scan_kern
     constexpr int LUT4 = S * 16;                                    // float4 per quad
     constexpr int STG = (LUT4 + kScanThreads - 1) / kScanThreads;   // staged float4 / thread
     __shared__ float4 lut_s[2 * LUT4];
+    // Survivors are staged per (quad, query) in LDS and flushed one quad later with ONE
+    // returning global atomic per query, issued before the next quad's gather so its
+    // latency hides under the compute (a per-lane returning atomic stalls the wave ~1 us).
+    __shared__ uint64_t ckey_s[2][4][kScanStage];
+    __shared__ uint32_t ccnt_s[2][4];     // live counters (LDS atomics)
+    __shared__ uint32_t cfrozen_s[4];     // counts of the buffer being flushed
+    __shared__ uint32_t cbase_s[4];       // its global base slots
+    __shared__ uint32_t cq_s[4];          // its query ids
     __shared__ uint32_t tile_sh;
     const uint32_t tid = threadIdx.x;
     const uint32_t total_tiles = a.counters[CNT_TOTAL_TILES];
+    if (tid < 8) ccnt_s[tid >> 2][tid & 3u] = 0;
 
     for (;;) {
         if (tid == 0) tile_sh = atomicAdd(&a.counters[CNT_QUEUE_HEAD], 1u);
@@ -503,9 +537,18 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 4 : 2)) void adc_scan_kern
         }
         __syncthreads();
 
-        for (uint32_t qd = q0; qd < q1; ++qd) {
+        for (uint32_t qd = q0; qd <= q1; ++qd) {   // one extra trip flushes the last quad
             const uint32_t buf = (qd - q0) & 1u;
+            const bool live = qd < q1;
             const bool more = qd + 1 < q1;
+            const bool flush = qd > q0;             // buffer buf^1 holds quad qd-1's survivors
+            // A. reserve global slots for the previous quad's survivors (not waited for yet)
+            uint32_t gbase = 0, gq = kInvalid, gn = 0;
+            if (flush && tid < 4) {
+                gn = min(ccnt_s[buf ^ 1u][tid], kScanStage);
+                gq = a.pair_q[slot0 + (qd - 1) * 4 + tid];
+                if (gn) gbase = atomicAdd(&a.cand_cnt[gq], gn);
+            }
             float4 nx[STG];
             if (more) {
                 const float4 *g2 = gl + (size_t)(qd + 1 - q0) * LUT4;
@@ -516,53 +559,79 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 4 : 2)) void adc_scan_kern
                 }
             }
 
-            float acc[4][kScanPPT];
-            if (buf == 0) {
-                switch (nsub) {
-                    case 1: scan_quad_compute<NW, 1, 0>(lut_s, wlo, whi, acc); break;
-                    case 2: scan_quad_compute<NW, 2, 0>(lut_s, wlo, whi, acc); break;
-                    case 3: scan_quad_compute<NW, 3, 0>(lut_s, wlo, whi, acc); break;
-                    default: scan_quad_compute<NW, 4, 0>(lut_s, wlo, whi, acc); break;
+            if (live) {
+                // B. gather + accumulate
+                float acc[4][kScanPPT];
+                if (buf == 0) {
+                    switch (nsub) {
+                        case 1: scan_quad_compute<NW, 1, 0>(lut_s, wlo, whi, acc); break;
+                        case 2: scan_quad_compute<NW, 2, 0>(lut_s, wlo, whi, acc); break;
+                        case 3: scan_quad_compute<NW, 3, 0>(lut_s, wlo, whi, acc); break;
+                        default: scan_quad_compute<NW, 4, 0>(lut_s, wlo, whi, acc); break;
+                    }
+                } else {
+                    switch (nsub) {
+                        case 1: scan_quad_compute<NW, 1, 1>(lut_s, wlo, whi, acc); break;
+                        case 2: scan_quad_compute<NW, 2, 1>(lut_s, wlo, whi, acc); break;
+                        case 3: scan_quad_compute<NW, 3, 1>(lut_s, wlo, whi, acc); break;
+                        default: scan_quad_compute<NW, 4, 1>(lut_s, wlo, whi, acc); break;
+                    }
                 }
-            } else {
-                switch (nsub) {
-                    case 1: scan_quad_compute<NW, 1, 1>(lut_s, wlo, whi, acc); break;
-                    case 2: scan_quad_compute<NW, 2, 1>(lut_s, wlo, whi, acc); break;
-                    case 3: scan_quad_compute<NW, 3, 1>(lut_s, wlo, whi, acc); break;
-                    default: scan_quad_compute<NW, 4, 1>(lut_s, wlo, whi, acc); break;
-                }
-            }
-
-            // threshold filter (rarely taken)
-            const uint32_t slot = slot0 + qd * 4;
+                // threshold filter: survivors go to the LDS stage of this quad
+                const uint32_t slot = slot0 + qd * 4;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const uint32_t pq = a.pair_q[slot + p];
-                if (pq == kInvalid) continue;   // wave-uniform
-                const uint64_t T = a.thr[pq];
-                const uint32_t Thi = (uint32_t)(T >> 32);
-                const float Tf = (Thi == 0xFFFFFFFFu) ? __builtin_inff() : ordered_to_f32(Thi);
-                const uint32_t vb = a.pair_vbase[slot + p];
+                for (int p = 0; p < 4; ++p) {
+                    const uint32_t pq = a.pair_q[slot + p];
+                    if (pq == kInvalid) continue;   // wave-uniform
+                    const uint64_t T = a.thr[pq];
+                    const uint32_t Thi = (uint32_t)(T >> 32);
+                    const float Tf = (Thi == 0xFFFFFFFFu) ? __builtin_inff() : ordered_to_f32(Thi);
+                    const uint32_t vb = a.pair_vbase[slot + p];
 #pragma unroll
-                for (int i = 0; i < (int)kScanPPT; ++i) {
-                    if (i < (int)nsub && acc[p][i] <= Tf) {
-                        const uint32_t j = c0 + tid + kScanThreads * i;
-                        if (j < size) {
-                            const uint64_t key = make_key(acc[p][i], vb + j);
-                            if (key <= T) {
-                                const uint32_t pos = atomicAdd(&a.cand_cnt[pq], 1u);
-                                if (pos < a.cap) a.cand[(size_t)pq * a.cap + pos] = key;
+                    for (int i = 0; i < (int)kScanPPT; ++i) {
+                        if (i < (int)nsub && acc[p][i] <= Tf) {
+                            const uint32_t j = c0 + tid + kScanThreads * i;
+                            if (j < size) {
+                                const uint64_t key = make_key(acc[p][i], vb + j);
+                                if (key <= T) {
+                                    const uint32_t sl = atomicAdd(&ccnt_s[buf][p], 1u);
+                                    if (sl < kScanStage) {
+                                        ckey_s[buf][p][sl] = key;
+                                    } else {   // stage full: direct (slow) append
+                                        const uint32_t pos = atomicAdd(&a.cand_cnt[pq], 1u);
+                                        if (pos < a.cap) a.cand[(size_t)pq * a.cap + pos] = key;
+                                    }
+                                }
                             }
                         }
                     }
                 }
             }
 
+            // C. publish the flush parameters, reset the flushed buffer's live counters
             if (more) {
 #pragma unroll
                 for (int t = 0; t < STG; ++t) {
                     uint32_t e = tid + t * kScanThreads;
                     if (e < (uint32_t)LUT4) lut_s[(buf ^ 1u) * LUT4 + e] = nx[t];
+                }
+            }
+            if (tid < 4) {
+                cfrozen_s[tid] = gn;
+                cbase_s[tid] = gbase;
+                cq_s[tid] = gq;
+                if (flush) ccnt_s[buf ^ 1u][tid] = 0;
+            }
+            __syncthreads();
+            // D. copy the previous quad's survivors to the per-query candidate lists
+            if (flush) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const uint32_t n_p = cfrozen_s[p];
+                    if (tid < n_p) {
+                        const uint32_t pos = cbase_s[p] + tid;
+                        if (pos < a.cap) a.cand[(size_t)cq_s[p] * a.cap + pos] = ckey_s[buf ^ 1u][p][tid];
+                    }
                 }
             }
             __syncthreads();
@@ -582,12 +651,14 @@ struct SelectArgs {
     const float *queries;
     uint32_t q_stride;
     const uint32_t *tokens, *vbase;
+    const uint64_t *thr;
     uint32_t *cand_cnt;
     uint64_t *cand;
     uint32_t *counters;
     uint64_t *cand_key;
     uint32_t *cand_idx;
     float *cand_dist, *cand_exact;
+    uint32_t *cand_row;
     uint32_t *cand_count;
     uint32_t *out_idx;
     float *out_dist;
@@ -626,12 +697,18 @@ __device__ static uint32_t block_compact_le(uint64_t *list, uint32_t cnt, uint64
     return *s_base;
 }
 
+__device__ static void select_fail(const SelectArgs &a, uint32_t q, uint32_t status) {
+    if (threadIdx.x == 0) {
+        atomicMax(&a.counters[CNT_STATUS], status);
+        a.cand_count[q] = 0;
+        if (!a.local_only) a.out_count[q] = 0;
+    }
+}
+
 __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexDev ix,
                                                                        SelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];      // [kSortCap]
-    uint32_t *s_csr = reinterpret_cast<uint32_t *>(skeys + kSortCap);     // [kMaxPreReorderK]
-    uint32_t *s_idx = s_csr + kMaxPreReorderK;                            // [kMaxPreReorderK]
-    uint32_t *s_wave = s_idx + kMaxPreReorderK;                           // [kSelectThreads/64]
+    uint32_t *s_wave = reinterpret_cast<uint32_t *>(skeys + kSortCap);    // [kSelectThreads/64]
     uint32_t *s_basep = s_wave + kSelectThreads / 64;                     // [4]
     float *s_q = reinterpret_cast<float *>(s_basep + 4);                  // [dim]
     const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -639,17 +716,19 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
 
     uint32_t cnt = a.cand_cnt[q];
     if (cnt > a.cap) {  // candidate buffer overflow: report, never return a wrong row
-        if (tid == 0) {
-            atomicMax(&a.counters[CNT_STATUS], (uint32_t)SCANN_HIP_RESOURCE_EXHAUSTED);
-            a.cand_count[q] = 0;
-            if (!a.local_only) a.out_count[q] = 0;
-        }
+        select_fail(a, q, (uint32_t)SCANN_HIP_RESOURCE_EXHAUSTED);
+        return;
+    }
+    // A statistical threshold (sample rank j < m) must be verified: with >= m survivors
+    // the exact top-m is among them; with fewer the threshold was too tight.
+    if (a.thr[q] != SCANN_KEY_MAX && cnt < m) {
+        select_fail(a, q, (uint32_t)SCANN_HIP_ABORTED);
         return;
     }
     uint64_t *list = a.cand + (size_t)q * a.cap;
 
     while (cnt > kSortCap) {  // thin with a sampled bound until the list fits in LDS
-        const uint32_t stride = (cnt + kSortCap / 2 - 1) / (kSortCap / 2);
+        const uint32_t stride = (cnt + kSortCap - 1) / kSortCap;
         const uint32_t ns = (cnt + stride - 1) / stride;
         uint32_t n2 = 1;
         while (n2 < ns) n2 <<= 1;
@@ -665,11 +744,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
         cnt = nc;
     }
     if (cnt > kSortCap) {
-        if (tid == 0) {
-            atomicMax(&a.counters[CNT_STATUS], (uint32_t)SCANN_HIP_RESOURCE_EXHAUSTED);
-            a.cand_count[q] = 0;
-            if (!a.local_only) a.out_count[q] = 0;
-        }
+        select_fail(a, q, (uint32_t)SCANN_HIP_RESOURCE_EXHAUSTED);
         return;
     }
 
@@ -693,20 +768,19 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
         const uint32_t leaf = a.tokens[(size_t)q * a.P + lo];
         const uint32_t csr = ix.leaf_off[leaf] + (vpos - vb[lo]);
         const uint32_t idx = ix.leaf_ids ? ix.leaf_ids[csr] : csr;
-        s_csr[i] = csr;
-        s_idx[i] = idx;
-        const float ad = ordered_to_f32((uint32_t)(key >> 32));
+        a.cand_row[(size_t)q * m + i] = ix.rows_csr ? csr : idx;
         a.cand_key[(size_t)q * m + i] = key;
         a.cand_idx[(size_t)q * m + i] = idx;
-        a.cand_dist[(size_t)q * m + i] = ad;
+        a.cand_dist[(size_t)q * m + i] = ordered_to_f32((uint32_t)(key >> 32));
     }
     if (tid == 0) a.cand_count[q] = nsel;
 
     if (!a.exact_reorder) {  // AsymmetricHasher::search: k best by approximate distance
         if (!a.local_only) {
+            __syncthreads();
             const uint32_t nout = min(k, nsel);
             for (uint32_t i = tid; i < k; i += nt) {
-                a.out_idx[(size_t)q * k + i] = (i < nout) ? s_idx[i] : kInvalid;
+                a.out_idx[(size_t)q * k + i] = (i < nout) ? a.cand_idx[(size_t)q * m + i] : kInvalid;
                 a.out_dist[(size_t)q * k + i] =
                     (i < nout) ? ordered_to_f32((uint32_t)(skeys[i] >> 32)) : __builtin_inff();
             }
@@ -718,7 +792,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
     // exact SquaredL2, 8 lanes per candidate = the 8 AVX2 lanes of squared_l2_avx2
     const uint32_t dim = ix.dim;
     for (uint32_t j = tid; j < dim; j += nt) s_q[j] = a.queries[(size_t)q * a.q_stride + j];
-    __syncthreads();   // also orders the s_csr/s_idx writes above
+    __syncthreads();   // also orders the cand_row writes above
     const uint32_t chunks = dim >> 3, lane8 = tid & 7u;
     const uint32_t nround = (nsel + nt / 8 - 1) / (nt / 8);
     for (uint32_t rd = 0; rd < nround; ++rd) {
@@ -727,7 +801,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
         float accv = 0.0f;
         const float *row = nullptr;
         if (act) {
-            row = ix.rows + (size_t)(ix.rows_csr ? s_csr[c] : s_idx[c]) * ix.stride;
+            row = ix.rows + (size_t)a.cand_row[(size_t)q * m + c] * ix.stride;
             for (uint32_t i = 0; i < chunks; ++i) {
                 const float diff = s_q[8 * i + lane8] - row[8 * i + lane8];
                 accv = fmaf(diff, diff, accv);        // _mm256_fmadd_ps(diff, diff, sum)
@@ -751,7 +825,6 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
     // stable sort by exact distance: key = (ordered(exact) << 32 | approx rank)
     uint32_t m2 = 1;
     while (m2 < nsel) m2 <<= 1;
-    __syncthreads();
     for (uint32_t i = tid; i < m2; i += nt)
         skeys[i] = (i < nsel) ? make_key(a.cand_exact[(size_t)q * m + i], i) : SCANN_KEY_MAX;
     __syncthreads();
@@ -762,7 +835,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
         float od = __builtin_inff();
         if (i < nout) {
             const uint64_t key = skeys[i];
-            oi = s_idx[(uint32_t)key];
+            oi = a.cand_idx[(size_t)q * m + (uint32_t)key];
             od = ordered_to_f32((uint32_t)(key >> 32));
         }
         a.out_idx[(size_t)q * k + i] = oi;
@@ -772,55 +845,41 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
 }
 
 // =====================================================================================
-// Multi-GPU merge of gathered (key, idx, exact) triples: [world][nq][m].
+// Multi-GPU merge of gathered (key, idx, exact) triples [world][nq][m].  Every rank's
+// list is sorted by key and keys are unique per query, so an element's position in the
+// merged order is the number of smaller keys over all lists (binary searches); no sort
+// of world*m keys is needed.  Then the same stable exact sort as above.
 // =====================================================================================
 __global__ __launch_bounds__(kSelectThreads) void merge_kernel(
-    uint32_t world, uint32_t nq, uint32_t m, uint32_t k, uint32_t n2max,
-    const uint64_t *__restrict__ keys,
-    const uint32_t *__restrict__ idx, const float *__restrict__ exact,
-    const uint32_t *__restrict__ count, uint32_t *__restrict__ out_idx,
-    float *__restrict__ out_dist, uint32_t *__restrict__ out_count) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];   // [n2max]
-    uint32_t *s_src = reinterpret_cast<uint32_t *>(skeys + n2max);     // [n2max] source slot
-    uint32_t *s_off = s_src + n2max;                                   // [world+1]
+    uint32_t world, uint32_t nq, uint32_t m, uint32_t k, uint32_t m2max,
+    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx,
+    const float *__restrict__ exact, const uint32_t *__restrict__ count,
+    uint32_t *__restrict__ out_idx, float *__restrict__ out_dist,
+    uint32_t *__restrict__ out_count) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];   // [m2max]
+    uint32_t *s_src = reinterpret_cast<uint32_t *>(skeys + m2max);     // [m2max]
     const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    if (tid == 0) {
-        uint32_t o = 0;
-        for (uint32_t g = 0; g < world; ++g) {
-            s_off[g] = o;
-            o += count[(size_t)g * nq + q];
-        }
-        s_off[world] = o;
-    }
-    __syncthreads();
-    const uint32_t tot = s_off[world];
-    uint32_t n2 = 1;
-    while (n2 < tot) n2 <<= 1;
-    // The merge key is unique per (query, point): sort keys, then recover payloads by a
-    // second keyed sort on (exact, rank) that looks the source slot up by binary search.
-    for (uint32_t g = 0; g < world; ++g) {
-        const uint32_t c = count[(size_t)g * nq + q];
-        for (uint32_t i = tid; i < c; i += nt)
-            skeys[s_off[g] + i] = keys[((size_t)g * nq + q) * m + i];
-    }
-    for (uint32_t i = tot + tid; i < n2; i += nt) skeys[i] = SCANN_KEY_MAX;
-    __syncthreads();
-    bitonic_sort_lds(skeys, n2);
+    uint32_t tot = 0;
+    for (uint32_t g = 0; g < world; ++g) tot += count[(size_t)g * nq + q];
     const uint32_t nsel = min(m, tot);
-    // locate each selected key's source (rank g, slot i): every rank's list is sorted.
-    for (uint32_t i = tid; i < nsel; i += nt) {
-        const uint64_t key = skeys[i];
-        uint32_t src = kInvalid;
-        for (uint32_t g = 0; g < world && src == kInvalid; ++g) {
-            const uint64_t *kl = keys + ((size_t)g * nq + q) * m;
-            uint32_t lo = 0, hi = count[(size_t)g * nq + q];
-            while (lo < hi) {
-                uint32_t mid = (lo + hi) >> 1;
-                if (kl[mid] < key) lo = mid + 1; else hi = mid;
+    for (uint32_t g = 0; g < world; ++g) {
+        const uint32_t cg = count[(size_t)g * nq + q];
+        const uint64_t *kl = keys + ((size_t)g * nq + q) * m;
+        for (uint32_t i = tid; i < cg; i += nt) {
+            const uint64_t key = kl[i];
+            uint32_t rank = i;                      // smaller keys in its own list
+            for (uint32_t g2 = 0; g2 < world; ++g2) {
+                if (g2 == g) continue;
+                const uint64_t *k2 = keys + ((size_t)g2 * nq + q) * m;
+                uint32_t lo = 0, hi = count[(size_t)g2 * nq + q];
+                while (lo < hi) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if (k2[mid] < key) lo = mid + 1; else hi = mid;
+                }
+                rank += lo;
             }
-            if (lo < count[(size_t)g * nq + q] && kl[lo] == key) src = (g * nq + q) * m + lo;
+            if (rank < nsel) s_src[rank] = (uint32_t)(((size_t)g * nq + q) * m + i);
         }
-        s_src[i] = src;
     }
     __syncthreads();
     uint32_t m2 = 1;
@@ -976,10 +1035,10 @@ template <int NW>
 static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream_t st,
                               hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int S = NW * 8;
-    const size_t lds_thr = (size_t)kSampleCap * sizeof(uint64_t) + (size_t)S * 16 * sizeof(float) + 16;
+    const size_t lds_thr = (size_t)kSampleBuf * sizeof(uint64_t) + (size_t)S * 16 * sizeof(float) + 16;
     SCANN_TRY(set_dyn_lds(sample_threshold_kernel<NW>, lds_thr));
     hipLaunchKernelGGL(sample_threshold_kernel<NW>, dim3(w.nq), dim3(kSelectThreads), lds_thr, st,
-                       ix, w.P, w.m, w.tokens, w.vbase, w.slot_of, w.lutq, w.thr);
+                       ix, w.P, w.m, w.no_threshold, w.tokens, w.vbase, w.slot_of, w.lutq, w.thr);
     LAUNCH_CHECK();
     ScanArgs a;
     a.pair_off = w.pair_off; a.tile_off = w.tile_off; a.pair_q = w.pair_q;
@@ -1036,12 +1095,13 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
     s.P = w.P; s.m = w.m; s.k = w.k; s.cap = w.cap;
     s.exact_reorder = w.exact_reorder; s.local_only = local_only ? 1 : 0;
     s.queries = w.queries; s.q_stride = w.q_stride; s.tokens = w.tokens; s.vbase = w.vbase;
+    s.thr = w.thr; s.cand_row = w.cand_row;
     s.cand_cnt = w.cand_cnt; s.cand = w.cand; s.counters = w.counters; s.cand_key = w.cand_key;
     s.cand_idx = w.cand_idx; s.cand_dist = w.cand_dist; s.cand_exact = w.cand_exact;
     s.cand_count = w.cand_count; s.out_idx = w.out_idx; s.out_dist = w.out_dist;
     s.out_count = w.out_count;
-    const size_t lds_sel = (size_t)kSortCap * 8 + (size_t)kMaxPreReorderK * 8 +
-                           (size_t)(kSelectThreads / 64 + 4) * 4 + (size_t)ix.dim * 4;
+    const size_t lds_sel = (size_t)kSortCap * 8 + (size_t)(kSelectThreads / 64 + 4) * 4 +
+                           (size_t)ix.dim * 4;
     SCANN_TRY(set_dyn_lds(select_rerank_kernel, lds_sel));
     hipLaunchKernelGGL(select_rerank_kernel, dim3(w.nq), dim3(kSelectThreads), lds_sel, st, ix, s);
     LAUNCH_CHECK();
@@ -1054,12 +1114,12 @@ int txh_launch_merge(uint32_t world, uint32_t nq, uint32_t m, uint32_t k, const 
                      hipStream_t st) {
     if (nq == 0) return SCANN_HIP_OK;
     if (world == 0 || world > 64) return fail(SCANN_HIP_INVALID_ARGUMENT, "world must be 1..64");
-    const uint32_t n2 = next_pow2_u32(std::max<uint32_t>(1u, world * m));
-    if (n2 > 2 * kSortCap)
-        return fail(SCANN_HIP_UNIMPLEMENTED, "world * pre_reorder_k exceeds the LDS merge capacity");
-    const size_t lds = (size_t)n2 * 12 + (size_t)(world + 1) * 4;
+    if (m > kMaxPreReorderK)
+        return fail(SCANN_HIP_UNIMPLEMENTED, "pre_reorder_k exceeds the LDS merge capacity");
+    const uint32_t m2 = next_pow2_u32(std::max<uint32_t>(1u, m));
+    const size_t lds = (size_t)m2 * 12;
     SCANN_TRY(set_dyn_lds(merge_kernel, lds));
-    hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kSelectThreads), lds, st, world, nq, m, k, n2, d_keys,
+    hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kSelectThreads), lds, st, world, nq, m, k, m2, d_keys,
                        d_idx, d_exact, d_count, d_out_idx, d_out_dist, d_out_count);
     LAUNCH_CHECK();
     return SCANN_HIP_OK;

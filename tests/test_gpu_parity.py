@@ -200,7 +200,8 @@ def test_txh_candidate_overflow_retry():
     lut = orc.lut_from_query(cb, q[0])
     d = np.array([orc.lut_distance(lut, c) for c in codes[:n]], np.float32)
     order = np.argsort(-d, kind="stable")
-    st = -(-n // (8192 - 1))
+    ns = min(max(n // 16, 4096), 65536)      # sample_stride() of csrc/txh.h
+    st = -(-n // ns)
     perm = np.empty(n, np.int64)
     far = list(order[: -(-n // st)])
     near = list(order[-(-n // st):])

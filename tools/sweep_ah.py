@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--S", type=int, default=32)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--ms", default="10,30,100,300,1000,2048")
+    ap.add_argument("--ms", default="10,100,1000,2048,4096,6000,8192")
     ap.add_argument("--dist", default="uniform")
     ap.add_argument("--steps", type=int, default=5)
     a = ap.parse_args()
