@@ -1,0 +1,67 @@
+"""Host-side leaf sharding for multi-GPU Tree-X-Hybrid.
+
+One process per GPU; rank g owns a subset of the k-means leaves (their codes, ids and
+f32 rows).  Centroids, codebook and the GLOBAL leaf sizes are replicated so every rank
+selects the same leaves and builds identical merge keys; the only exchange is one
+all_gather of (merge key, index, exact distance) triples of each rank's best
+pre_reorder_k candidates.  No reference counterpart (the reference is single-process).
+"""
+import numpy as np
+
+
+def assign_leaves(leaf_sizes, world):
+    """Greedy size-balanced leaf -> rank map (same rule as scann_hip_assign_leaves)."""
+    leaf_sizes = np.asarray(leaf_sizes, np.int64)
+    order = np.argsort(-leaf_sizes, kind="stable")
+    load = np.zeros(world, np.int64)
+    owner = np.zeros(leaf_sizes.size, np.uint32)
+    for l in order:
+        g = int(np.argmin(load))   # first minimum == lowest rank, as in the C loop
+        owner[l] = g
+        load[g] += leaf_sizes[l]
+    return owner
+
+
+def shard_txh_index(ix, data, stride, rank, world, owner=None):
+    """Local view of a trained index for `rank`: kwargs of hip.txh_create.
+
+    ix: dict(centers, leaf_off, leaf_ids, codebook, codes[, use_residuals]) as built by
+    trainer.build_txh_index; data: [n][stride] rows by datapoint index."""
+    leaf_off = np.asarray(ix["leaf_off"], np.int64)
+    L = leaf_off.size - 1
+    sizes = (leaf_off[1:] - leaf_off[:-1]).astype(np.uint32)
+    if owner is None:
+        owner = assign_leaves(sizes, world)
+    mine = owner == rank
+    local_sizes = np.where(mine, sizes, 0).astype(np.uint32)
+    off = np.zeros(L + 1, np.uint32)
+    off[1:] = np.cumsum(local_sizes)
+    sel = np.concatenate([np.arange(leaf_off[l], leaf_off[l + 1]) for l in range(L) if mine[l]]
+                         or [np.zeros(0, np.int64)]).astype(np.int64)
+    ids = np.asarray(ix["leaf_ids"], np.uint32)[sel]
+    return dict(data=np.ascontiguousarray(data[ids]), n_rows=int(ids.size), dim=int(ix["centers"].shape[1]),
+                stride=stride, centers=ix["centers"], leaf_offsets=off, leaf_ids=ids,
+                leaf_sizes_global=sizes, codebook=ix["codebook"],
+                codes=np.ascontiguousarray(np.asarray(ix["codes"])[sel]),
+                use_residuals=bool(ix.get("use_residuals", True)), data_is_csr_order=True)
+
+
+def merge_reference(keys, idx, exact, counts, m, k):
+    """Numpy statement of the merge rule (tree_x_hybrid/mod.rs:283-293, 360-361) on
+    gathered triples [world][nq][m]: stable sort by key -> truncate m -> stable sort by
+    exact -> truncate k.  Used by tests as the CPU model of scann_hip_txh_merge_device."""
+    world, nq, _ = keys.shape
+    out_idx = np.full((nq, k), 0xFFFFFFFF, np.uint32)
+    out_dist = np.full((nq, k), np.inf, np.float32)
+    out_cnt = np.zeros(nq, np.uint32)
+    for q in range(nq):
+        ks = np.concatenate([keys[g, q, :counts[g, q]] for g in range(world)])
+        ii = np.concatenate([idx[g, q, :counts[g, q]] for g in range(world)])
+        ee = np.concatenate([exact[g, q, :counts[g, q]] for g in range(world)])
+        order = np.argsort(ks, kind="stable")[:m]
+        ii, ee = ii[order], ee[order]
+        o2 = np.argsort(ee, kind="stable")[:k]
+        out_cnt[q] = o2.size
+        out_idx[q, :o2.size] = ii[o2]
+        out_dist[q, :o2.size] = ee[o2]
+    return out_idx, out_dist, out_cnt

@@ -327,3 +327,59 @@ def test_concurrent_queries():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs
+
+
+# ---- multi-GPU stages on one GPU: two leaf shards -> local stage x2 -> merge ------------------------------
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_local_plus_merge_equals_single_index(world):
+    import ctypes as C
+    import torch
+    from scann_rust_amd import sharding
+    n, dim, L, S, k, P, m, nq = 6000, 128, 24, 32, 10, 8, 60, 50
+    rows, data, stride, ix, oix, kw = H.make_txh_case(n, dim, L, S, seed=12, P=P, mult=m / k,
+                                                      kmeans_iters=3, pq_iters=3)
+    full = hip.txh_create(**kw)
+    q = synth.uniform_f32(nq, dim, 55)
+    o = hip.default_opts()
+    o.partitions_to_search = P
+    o.pre_reorder_k = m
+    want_idx, want_dist, want_cnt = full.search_batched(q, k, o)
+
+    Lh = hip.load()
+    dev = torch.device("cuda", 0)
+    sptr = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    qd = torch.from_numpy(q).to(dev)
+    g_keys = torch.zeros((world, nq, m), dtype=torch.int64, device=dev)
+    g_idx = torch.zeros((world, nq, m), dtype=torch.int32, device=dev)
+    g_ex = torch.zeros((world, nq, m), dtype=torch.float32, device=dev)
+    g_cnt = torch.zeros((world, nq), dtype=torch.int32, device=dev)
+    shards = []
+    for r in range(world):
+        skw = sharding.shard_txh_index(ix, data, stride, r, world)
+        sh = hip.txh_create(partitions_to_search=P, pre_reorder_multiplier=m / k, **skw)
+        shards.append(sh)
+        hip.check(Lh.scann_hip_txh_search_local_device(
+            sh.h, C.c_void_p(qd.data_ptr()), nq, dim, k, C.byref(o),
+            C.c_void_p(g_keys[r].data_ptr()), C.c_void_p(g_idx[r].data_ptr()),
+            C.c_void_p(g_ex[r].data_ptr()), C.c_void_p(g_cnt[r].data_ptr()), sptr))
+        hip.check(Lh.scann_hip_index_last_device_status(sh.h, sptr))
+    out_idx = torch.zeros((nq, k), dtype=torch.int32, device=dev)
+    out_dist = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+    out_cnt = torch.zeros((nq,), dtype=torch.int32, device=dev)
+    hip.check(Lh.scann_hip_txh_merge_device(hip.context(0), world, nq, m, k,
+                                            C.c_void_p(g_keys.data_ptr()), C.c_void_p(g_idx.data_ptr()),
+                                            C.c_void_p(g_ex.data_ptr()), C.c_void_p(g_cnt.data_ptr()),
+                                            C.c_void_p(out_idx.data_ptr()), C.c_void_p(out_dist.data_ptr()),
+                                            C.c_void_p(out_cnt.data_ptr()), sptr))
+    torch.cuda.synchronize()
+    gi = out_idx.cpu().numpy().view(np.uint32)
+    gd = out_dist.cpu().numpy()
+    gc = out_cnt.cpu().numpy()
+    assert np.array_equal(gc.astype(np.uint32), want_cnt)
+    assert np.array_equal(gd.view(np.uint32), want_dist.view(np.uint32))
+    assert np.array_equal(gi, want_idx)
+    # and the numpy model of the merge agrees with the kernel
+    mi, md, mc = sharding.merge_reference(g_keys.cpu().numpy().view(np.uint64),
+                                          g_idx.cpu().numpy().view(np.uint32), g_ex.cpu().numpy(),
+                                          g_cnt.cpu().numpy(), m, k)
+    assert np.array_equal(mi, gi) and np.array_equal(md.view(np.uint32), gd.view(np.uint32))
