@@ -1,0 +1,491 @@
+// scann.hpp -- C++ host-side mirror of the reference crate's API for the hot path, on top
+// of the C ABI (include/scann_hip.h).  The reference is Rust; the build image has no Rust
+// toolchain, so this header plays the role of the Rust wrappers shown in INTEGRATION.md:
+// same type / method names, argument meaning and error behaviour.
+//
+//   scann::DenseDataset                 data_format/dataset.rs:46-280
+//   scann::BruteForceSearcher           brute_force/searcher.rs:18-208
+//   scann::AsymmetricHasher(+Config)    hashes/hasher.rs:19-258
+//   scann::TreeXHybridSearcher(+Config) tree_x_hybrid/mod.rs:23-418
+//   scann::ScannBuilder / scann::Scann  scann.rs:35-56, 364-426
+//   scann::ScannError / ErrorCode       error.rs:10-147
+//
+// All distance computation and top-k selection runs in libscann_hip.so on the GPU.  Index
+// TRAINING (k-means, PQ codebooks) is host-side C++ here with its own RNG: the reference's
+// StdRng streams are not reproducible and the trained index is an input to
+// the search path.  Encoding uses the GPU (scann_hip_encode, bit-exact with Codebook::encode).
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/scann_hip.h"
+
+namespace scann {
+
+enum class ErrorCode : int {   // error.rs:10-45, declaration order
+    Ok = 0, Cancelled, Unknown, InvalidArgument, DeadlineExceeded, NotFound, AlreadyExists,
+    PermissionDenied, ResourceExhausted, FailedPrecondition, Aborted, OutOfRange, Unimplemented,
+    Internal, Unavailable, DataLoss, Unauthenticated
+};
+
+struct ScannError : std::runtime_error {   // error.rs:73-147
+    ErrorCode code;
+    ScannError(ErrorCode c, const std::string &m) : std::runtime_error(m), code(c) {}
+    static ScannError invalid_argument(const std::string &m) { return {ErrorCode::InvalidArgument, m}; }
+    static ScannError failed_precondition(const std::string &m) { return {ErrorCode::FailedPrecondition, m}; }
+};
+
+inline void check(int status) {
+    if (status != SCANN_HIP_OK) throw ScannError(static_cast<ErrorCode>(status), scann_hip_last_error());
+}
+
+enum class DistanceMeasure : int { SquaredL2 = 0, L2 = 1, DotProduct = 2 };  // distance_measures/mod.rs:32-66
+
+using DatapointIndex = uint32_t;                                   // types.rs:10
+using NNResultsVector = std::vector<std::pair<DatapointIndex, float>>;  // types.rs:17-20
+
+// One context per device, shared by every searcher of the process.
+inline scann_hip_ctx *context(int device = 0) {
+    static scann_hip_ctx *ctxs[64] = {};
+    if (device < 0 || device >= 64) throw ScannError::invalid_argument("device id");
+    if (!ctxs[device]) check(scann_hip_init(device, &ctxs[device]));
+    return ctxs[device];
+}
+
+// data_format/dataset.rs: one row-major buffer, stride = align_up(dim, 16 floats).
+class DenseDataset {
+public:
+    DenseDataset() = default;
+    static DenseDataset from_vecs(const std::vector<std::vector<float>> &vecs) {  // :99-123
+        DenseDataset d;
+        if (vecs.empty()) return d;
+        d.dim_ = static_cast<uint32_t>(vecs[0].size());
+        d.n_ = vecs.size();
+        d.stride_ = scann_hip_compute_stride(d.dim_);
+        d.data_.assign(d.n_ * d.stride_, 0.0f);
+        for (size_t i = 0; i < d.n_; ++i)
+            std::memcpy(&d.data_[i * d.stride_], vecs[i].data(), std::min<size_t>(vecs[i].size(), d.dim_) * 4);
+        return d;
+    }
+    static DenseDataset from_flat(const std::vector<float> &flat, uint32_t dim) {  // :126-174
+        if (dim == 0) throw ScannError::invalid_argument("Dimensionality cannot be 0");
+        if (flat.size() % dim) throw ScannError::invalid_argument("Data length is not a multiple of dimensionality");
+        DenseDataset d;
+        d.dim_ = dim;
+        d.n_ = flat.size() / dim;
+        d.stride_ = scann_hip_compute_stride(dim);
+        d.data_.assign(d.n_ * d.stride_, 0.0f);
+        for (size_t i = 0; i < d.n_; ++i) std::memcpy(&d.data_[i * d.stride_], &flat[i * dim], dim * 4);
+        return d;
+    }
+    bool is_empty() const { return n_ == 0; }
+    size_t size() const { return n_; }
+    uint32_t dimensionality() const { return dim_; }
+    uint32_t stride() const { return stride_; }
+    const float *raw_data() const { return data_.data(); }
+    const float *get(size_t i) const { return &data_[i * stride_]; }
+
+private:
+    std::vector<float> data_;
+    size_t n_ = 0;
+    uint32_t dim_ = 0, stride_ = 0;
+};
+
+namespace detail {
+
+struct IndexHandle {
+    scann_hip_index *h = nullptr;
+    IndexHandle() = default;
+    IndexHandle(const IndexHandle &) = delete;
+    IndexHandle &operator=(const IndexHandle &) = delete;
+    ~IndexHandle() { if (h) scann_hip_index_destroy(h); }
+};
+
+inline std::vector<NNResultsVector> run_search(scann_hip_index *h, const float *q, uint32_t nq,
+                                               uint32_t q_stride, uint32_t q_dim, uint32_t k,
+                                               const scann_hip_search_opts *opts) {
+    std::vector<uint32_t> idx((size_t)nq * std::max(1u, k)), cnt(nq);
+    std::vector<float> dist((size_t)nq * std::max(1u, k));
+    check(scann_hip_search_batched(h, q, nq, q_stride, q_dim, k, opts, idx.data(), dist.data(), cnt.data()));
+    std::vector<NNResultsVector> out(nq);
+    for (uint32_t i = 0; i < nq; ++i)
+        for (uint32_t j = 0; j < cnt[i]; ++j) out[i].emplace_back(idx[(size_t)i * k + j], dist[(size_t)i * k + j]);
+    return out;
+}
+
+inline std::vector<float> flatten(const std::vector<std::vector<float>> &qs, uint32_t *dim_out) {
+    uint32_t d = qs.empty() ? 0 : (uint32_t)qs[0].size();
+    for (auto &q : qs)
+        if (q.size() != d) throw ScannError::invalid_argument("Query dimensionality mismatch");
+    std::vector<float> flat((size_t)qs.size() * std::max(1u, d));
+    for (size_t i = 0; i < qs.size(); ++i) std::memcpy(&flat[i * d], qs[i].data(), d * 4);
+    *dim_out = d;
+    return flat;
+}
+
+// splitmix64: the documented counter-based generator of this build (not rand::StdRng).
+inline uint64_t splitmix(uint64_t &s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Lloyd k-means on rows [n][stride] restricted to columns [c0, c0+d).  Returns centers
+// [k][d] and assignments.  (trees/kmeans.rs:166-414 analogue; own RNG, random init.)
+inline void kmeans(const float *rows, size_t n, size_t stride, size_t c0, size_t d, size_t k,
+                   size_t iters, uint64_t seed, std::vector<float> &centers, std::vector<uint32_t> &assign) {
+    k = std::min(k, n);
+    centers.assign(k * d, 0.0f);
+    assign.assign(n, 0);
+    uint64_t s = seed;
+    std::vector<size_t> pick;
+    while (pick.size() < k) {
+        size_t c = splitmix(s) % n;
+        if (std::find(pick.begin(), pick.end(), c) == pick.end()) pick.push_back(c);
+    }
+    for (size_t c = 0; c < k; ++c) std::memcpy(&centers[c * d], rows + pick[c] * stride + c0, d * 4);
+    std::vector<double> sums(k * d);
+    std::vector<size_t> cnt(k);
+    for (size_t it = 0; it <= iters; ++it) {
+        bool changed = false;
+        for (size_t i = 0; i < n; ++i) {
+            const float *x = rows + i * stride + c0;
+            float best = std::numeric_limits<float>::infinity();
+            uint32_t bi = 0;
+            for (size_t c = 0; c < k; ++c) {
+                float acc = 0.0f;
+                for (size_t j = 0; j < d; ++j) { float t = x[j] - centers[c * d + j]; acc += t * t; }
+                if (acc < best) { best = acc; bi = (uint32_t)c; }
+            }
+            if (assign[i] != bi) { assign[i] = bi; changed = true; }
+        }
+        if (it == iters || (!changed && it > 0)) break;
+        std::fill(sums.begin(), sums.end(), 0.0);
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (size_t i = 0; i < n; ++i) {
+            const float *x = rows + i * stride + c0;
+            for (size_t j = 0; j < d; ++j) sums[assign[i] * d + j] += x[j];
+            ++cnt[assign[i]];
+        }
+        for (size_t c = 0; c < k; ++c)
+            if (cnt[c]) for (size_t j = 0; j < d; ++j) centers[c * d + j] = (float)(sums[c * d + j] / cnt[c]);
+    }
+}
+
+// Codebook::train (hashes/codebook.rs:146-202): per-subspace k-means, seed + s.
+inline std::vector<float> train_codebook(const float *rows, size_t n, size_t stride, uint32_t dim,
+                                         uint32_t S, uint32_t K, uint64_t seed, size_t iters) {
+    if (n == 0) throw ScannError::invalid_argument("Cannot train on empty dataset");
+    if (dim % S != 0)   // codebook.rs:154-159
+        throw ScannError::invalid_argument("Dimensionality " + std::to_string(dim) +
+                                           " must be divisible by num_subspaces " + std::to_string(S));
+    const uint32_t dsub = dim / S;
+    std::vector<float> cb((size_t)S * K * dsub, 0.0f), centers;
+    std::vector<uint32_t> assign;
+    for (uint32_t s = 0; s < S; ++s) {
+        kmeans(rows, n, stride, (size_t)s * dsub, dsub, K, iters, seed + s, centers, assign);
+        const size_t got = centers.size() / dsub;
+        for (uint32_t c = 0; c < K; ++c)
+            std::memcpy(&cb[((size_t)s * K + c) * dsub], &centers[std::min<size_t>(c, got - 1) * dsub], dsub * 4);
+    }
+    return cb;
+}
+
+}  // namespace detail
+
+// ---- BruteForceSearcher (brute_force/searcher.rs:18-208) --------------------------------
+class BruteForceSearcher {
+public:
+    BruteForceSearcher(std::shared_ptr<DenseDataset> dataset, DistanceMeasure measure, int device = 0)
+        : dataset_(std::move(dataset)), measure_(measure) {
+        check(scann_hip_bf_create(context(device), dataset_->raw_data(), dataset_->size(),
+                                  dataset_->dimensionality(), dataset_->stride(), (int)measure, &ix_.h));
+    }
+    BruteForceSearcher(DenseDataset dataset, DistanceMeasure measure, int device = 0)
+        : BruteForceSearcher(std::make_shared<DenseDataset>(std::move(dataset)), measure, device) {}
+
+    NNResultsVector search(const std::vector<float> &query, size_t k) const {   // :77-93
+        return detail::run_search(ix_.h, query.data(), 1, (uint32_t)query.size(), (uint32_t)query.size(),
+                                  (uint32_t)k, nullptr)[0];
+    }
+    std::vector<NNResultsVector> search_batched(const std::vector<std::vector<float>> &queries, size_t k) const {
+        if (queries.empty()) return {};                                          // :175-177
+        uint32_t d;
+        auto flat = detail::flatten(queries, &d);
+        return detail::run_search(ix_.h, flat.data(), (uint32_t)queries.size(), d, d, (uint32_t)k, nullptr);
+    }
+    size_t dataset_size() const { return dataset_->size(); }
+    uint64_t dimensionality() const { return dataset_->dimensionality(); }
+    DistanceMeasure distance_measure() const { return measure_; }
+    const DenseDataset &dataset() const { return *dataset_; }
+
+private:
+    std::shared_ptr<DenseDataset> dataset_;
+    DistanceMeasure measure_;
+    detail::IndexHandle ix_;
+};
+
+// ---- AsymmetricHasher (hashes/hasher.rs) ---------------------------------------------------
+struct AsymmetricHasherConfig {      // hasher.rs:19-69 (default 256 x 8; the GPU path needs K <= 16)
+    size_t num_codes = 256, num_subspaces = 8;
+    uint64_t seed = 42;
+    bool has_seed = false;
+    size_t training_iterations = 25;
+    AsymmetricHasherConfig() = default;
+    AsymmetricHasherConfig(size_t codes, size_t subspaces) : num_codes(codes), num_subspaces(subspaces) {}
+    AsymmetricHasherConfig with_seed(uint64_t s) const { auto c = *this; c.seed = s; c.has_seed = true; return c; }
+};
+
+class AsymmetricHasher {
+public:
+    explicit AsymmetricHasher(AsymmetricHasherConfig config, int device = 0) : config_(config), device_(device) {}
+
+    void build(DenseDataset dataset) {            // hasher.rs:109-134
+        build_impl(dataset, true);
+        dataset_ = std::make_shared<DenseDataset>(std::move(dataset));
+    }
+    void build_no_store(const DenseDataset &dataset) { build_impl(dataset, false); }   // :137-159
+
+    NNResultsVector search(const std::vector<float> &query, size_t k) const {          // :162-185
+        if (!ix_.h) return {};
+        scann_hip_search_opts o;
+        scann_hip_search_opts_default(&o);
+        o.exact_reorder = 0;
+        return detail::run_search(ix_.h, query.data(), 1, (uint32_t)query.size(), (uint32_t)query.size(),
+                                  (uint32_t)k, &o)[0];
+    }
+    NNResultsVector search_with_reordering(const std::vector<float> &query, size_t k, size_t pre_reorder_k) const {
+        if (!stored_) throw ScannError::failed_precondition("Dataset not stored");    // :194-197
+        scann_hip_search_opts o;
+        scann_hip_search_opts_default(&o);
+        o.pre_reorder_k = (uint32_t)pre_reorder_k;
+        return detail::run_search(ix_.h, query.data(), 1, (uint32_t)query.size(), (uint32_t)query.size(),
+                                  (uint32_t)k, &o)[0];
+    }
+    std::vector<NNResultsVector> search_batched(const std::vector<std::vector<float>> &queries, size_t k) const {
+        if (queries.empty() || !ix_.h) return std::vector<NNResultsVector>(queries.size());
+        uint32_t d;
+        auto flat = detail::flatten(queries, &d);
+        scann_hip_search_opts o;
+        scann_hip_search_opts_default(&o);
+        o.exact_reorder = 0;
+        return detail::run_search(ix_.h, flat.data(), (uint32_t)queries.size(), d, d, (uint32_t)k, &o);
+    }
+    size_t num_datapoints() const { return n_; }
+    size_t dimensionality() const { return dim_; }
+    const std::vector<float> &codebook() const { return codebook_; }
+    const std::vector<uint8_t> &encoded_database() const { return codes_; }
+
+private:
+    void build_impl(const DenseDataset &ds, bool store) {
+        if (ds.is_empty()) throw ScannError::invalid_argument("Cannot build from empty dataset");  // :110-112
+        dim_ = ds.dimensionality();
+        n_ = ds.size();
+        const uint32_t S = (uint32_t)config_.num_subspaces, K = (uint32_t)config_.num_codes;
+        codebook_ = detail::train_codebook(ds.raw_data(), n_, ds.stride(), (uint32_t)dim_, S, K,
+                                           config_.seed, config_.training_iterations);
+        codes_.assign(n_ * S, 0);
+        check(scann_hip_encode(context(device_), codebook_.data(), S, K, (uint32_t)dim_ / S, ds.raw_data(), n_,
+                               ds.stride(), nullptr, nullptr, codes_.data()));
+        scann_hip_txh_desc d{};
+        d.data = store ? ds.raw_data() : nullptr;
+        d.n_rows = n_;
+        d.dim = (uint32_t)dim_;
+        d.stride = ds.stride();
+        d.n_local = n_;
+        d.codebook = codebook_.data();
+        d.num_subspaces = S;
+        d.num_codes = K;
+        d.dims_per_subspace = (uint32_t)dim_ / S;
+        d.codes = codes_.data();
+        d.partitions_to_search = 1;
+        d.pre_reorder_multiplier = 1.0f;
+        if (ix_.h) { scann_hip_index_destroy(ix_.h); ix_.h = nullptr; }
+        check(scann_hip_txh_create(context(device_), &d, &ix_.h));
+        stored_ = store;
+    }
+    AsymmetricHasherConfig config_;
+    int device_;
+    std::shared_ptr<DenseDataset> dataset_;
+    std::vector<float> codebook_;
+    std::vector<uint8_t> codes_;
+    size_t n_ = 0, dim_ = 0;
+    bool stored_ = false;
+    detail::IndexHandle ix_;
+};
+
+// ---- TreeXHybridSearcher (tree_x_hybrid/mod.rs) ------------------------------------------------
+struct TreeXHybridConfig {           // mod.rs:23-78
+    size_t num_partitions = 100, partitions_to_search = 10;
+    AsymmetricHasherConfig hash_config;
+    bool use_residuals = true;
+    float pre_reorder_multiplier = 3.0f;
+    bool parallel_partition_search = true;   // no effect: every leaf scan is parallel on the GPU
+    size_t kmeans_iterations = 25;
+    TreeXHybridConfig() = default;
+    TreeXHybridConfig(size_t parts, size_t to_search) : num_partitions(parts), partitions_to_search(to_search) {}
+    TreeXHybridConfig with_hash(AsymmetricHasherConfig c) const { auto t = *this; t.hash_config = c; return t; }
+    TreeXHybridConfig with_residuals(bool r) const { auto t = *this; t.use_residuals = r; return t; }
+    TreeXHybridConfig with_pre_reorder(float m) const { auto t = *this; t.pre_reorder_multiplier = m; return t; }
+};
+
+class TreeXHybridSearcher {
+public:
+    explicit TreeXHybridSearcher(TreeXHybridConfig config, int device = 0) : config_(config), device_(device) {}
+
+    void build(DenseDataset dataset) {     // mod.rs:131-209
+        if (dataset.is_empty()) throw ScannError::invalid_argument("Cannot build from empty dataset");
+        dataset_ = std::make_shared<DenseDataset>(std::move(dataset));
+        const DenseDataset &ds = *dataset_;
+        const size_t n = ds.size(), dim = ds.dimensionality(), st = ds.stride();
+        const uint32_t S = (uint32_t)config_.hash_config.num_subspaces, K = (uint32_t)config_.hash_config.num_codes;
+        if (dim % S != 0)
+            throw ScannError::invalid_argument("Dimensionality " + std::to_string(dim) +
+                                               " must be divisible by num_subspaces " + std::to_string(S));
+        // TreePartitioner::build: flat k-means, seed 42 (tree_partitioner.rs:48-98)
+        std::vector<uint32_t> assign;
+        detail::kmeans(ds.raw_data(), n, st, 0, dim, config_.num_partitions, config_.kmeans_iterations, 42,
+                       centers_, assign);
+        const uint32_t L = (uint32_t)(centers_.size() / dim);
+        leaf_off_.assign(L + 1, 0);
+        for (uint32_t a : assign) ++leaf_off_[a + 1];
+        for (uint32_t l = 0; l < L; ++l) leaf_off_[l + 1] += leaf_off_[l];
+        leaf_ids_.assign(n, 0);
+        {
+            std::vector<uint32_t> cur(leaf_off_.begin(), leaf_off_.end() - 1);
+            for (size_t i = 0; i < n; ++i) leaf_ids_[cur[assign[i]]++] = (uint32_t)i;   // ascending idx per leaf
+        }
+        // residual rows in CSR order (mod.rs:177-189), codebook on residuals (:151-158)
+        std::vector<float> rows(n * dim);
+        std::vector<uint32_t> leaf_of_row(n);
+        for (uint32_t l = 0; l < L; ++l)
+            for (uint32_t r = leaf_off_[l]; r < leaf_off_[l + 1]; ++r) {
+                const float *x = ds.get(leaf_ids_[r]);
+                leaf_of_row[r] = l;
+                for (size_t j = 0; j < dim; ++j)
+                    rows[r * dim + j] = config_.use_residuals ? x[j] - centers_[l * dim + j] : x[j];
+            }
+        codebook_ = detail::train_codebook(rows.data(), n, dim, (uint32_t)dim, S, K, config_.hash_config.seed,
+                                           config_.hash_config.training_iterations);
+        codes_.assign(n * S, 0);
+        check(scann_hip_encode(context(device_), codebook_.data(), S, K, (uint32_t)dim / S, rows.data(), n,
+                               (uint32_t)dim, nullptr, nullptr, codes_.data()));
+        scann_hip_txh_desc d{};
+        d.data = ds.raw_data();
+        d.n_rows = n;
+        d.dim = (uint32_t)dim;
+        d.stride = (uint32_t)st;
+        d.centers = centers_.data();
+        d.num_partitions = L;
+        d.leaf_offsets = leaf_off_.data();
+        d.leaf_ids = leaf_ids_.data();
+        d.n_local = n;
+        d.codebook = codebook_.data();
+        d.num_subspaces = S;
+        d.num_codes = K;
+        d.dims_per_subspace = (uint32_t)dim / S;
+        d.codes = codes_.data();
+        d.use_residuals = config_.use_residuals ? 1 : 0;
+        d.partitions_to_search = (uint32_t)config_.partitions_to_search;
+        d.pre_reorder_multiplier = config_.pre_reorder_multiplier;
+        if (ix_.h) { scann_hip_index_destroy(ix_.h); ix_.h = nullptr; }
+        check(scann_hip_txh_create(context(device_), &d, &ix_.h));
+    }
+
+    NNResultsVector search(const std::vector<float> &query, size_t k) const {   // mod.rs:240-294
+        if (!ix_.h) throw ScannError::failed_precondition("Partitioner not built");
+        return detail::run_search(ix_.h, query.data(), 1, (uint32_t)query.size(), (uint32_t)query.size(),
+                                  (uint32_t)k, nullptr)[0];
+    }
+    std::vector<NNResultsVector> search_batched(const std::vector<std::vector<float>> &queries, size_t k) const {
+        if (!ix_.h) throw ScannError::failed_precondition("Partitioner not built");
+        if (queries.empty()) return {};
+        uint32_t d;
+        auto flat = detail::flatten(queries, &d);
+        return detail::run_search(ix_.h, flat.data(), (uint32_t)queries.size(), d, d, (uint32_t)k, nullptr);
+    }
+    size_t num_partitions() const { return leaf_off_.empty() ? 0 : leaf_off_.size() - 1; }
+    size_t num_datapoints() const { return dataset_ ? dataset_->size() : 0; }
+    size_t dataset_size() const { return num_datapoints(); }
+    uint64_t dimensionality() const { return dataset_ ? dataset_->dimensionality() : 0; }
+    const TreeXHybridConfig &config() const { return config_; }
+
+private:
+    TreeXHybridConfig config_;
+    int device_;
+    std::shared_ptr<DenseDataset> dataset_;
+    std::vector<float> centers_, codebook_;
+    std::vector<uint32_t> leaf_off_, leaf_ids_;
+    std::vector<uint8_t> codes_;
+    detail::IndexHandle ix_;
+};
+
+// ---- Scann facade (scann.rs:35-56, 181-212, 364-426) ---------------------------------------------
+class Scann {
+public:
+    NNResultsVector search(const std::vector<float> &q, size_t k) const {
+        if (txh_) return txh_->search(q, k);
+        if (ah_) return reorder_ ? ah_->search_with_reordering(q, k, reorder_) : ah_->search(q, k);
+        return bf_->search(q, k);
+    }
+    std::vector<NNResultsVector> search_batched(const std::vector<std::vector<float>> &qs, size_t k) const {
+        if (txh_) return txh_->search_batched(qs, k);
+        if (ah_ && !reorder_) return ah_->search_batched(qs, k);
+        if (ah_) { std::vector<NNResultsVector> r; for (auto &q : qs) r.push_back(search(q, k)); return r; }
+        return bf_->search_batched(qs, k);
+    }
+    size_t size() const { return n_; }
+
+private:
+    friend class ScannBuilder;
+    std::unique_ptr<BruteForceSearcher> bf_;
+    std::unique_ptr<AsymmetricHasher> ah_;
+    std::unique_ptr<TreeXHybridSearcher> txh_;
+    size_t reorder_ = 0, n_ = 0;
+};
+
+class ScannBuilder {   // scann.rs:364-426
+public:
+    ScannBuilder &num_neighbors(size_t k) { k_ = k; return *this; }
+    ScannBuilder &distance_measure(DistanceMeasure m) { measure_ = m; return *this; }
+    ScannBuilder &brute_force() { brute_ = true; return *this; }
+    ScannBuilder &tree(size_t num_partitions, size_t to_search) { L_ = num_partitions; P_ = to_search; return *this; }
+    ScannBuilder &hash(size_t num_blocks) { blocks_ = num_blocks; return *this; }
+    ScannBuilder &reorder(size_t n) { reorder_ = n; return *this; }
+    Scann build(DenseDataset dataset) {
+        if (dataset.is_empty()) throw ScannError::invalid_argument("Dataset cannot be empty");  // scann.rs:66-68
+        Scann s;
+        s.n_ = dataset.size();
+        if (brute_ || (!L_ && !blocks_)) {
+            s.bf_.reset(new BruteForceSearcher(std::move(dataset), measure_));
+        } else if (L_) {
+            TreeXHybridConfig c(L_, P_);
+            c.hash_config = AsymmetricHasherConfig(16, blocks_ ? blocks_ : 8);
+            if (reorder_) c.pre_reorder_multiplier = (float)reorder_ / (float)std::max<size_t>(1, k_);
+            s.txh_.reset(new TreeXHybridSearcher(c));
+            s.txh_->build(std::move(dataset));
+        } else {
+            s.ah_.reset(new AsymmetricHasher(AsymmetricHasherConfig(16, blocks_)));
+            s.ah_->build(std::move(dataset));
+            s.reorder_ = reorder_;
+        }
+        return s;
+    }
+
+private:
+    size_t k_ = 10, L_ = 0, P_ = 0, blocks_ = 0, reorder_ = 0;
+    bool brute_ = false;
+    DistanceMeasure measure_ = DistanceMeasure::SquaredL2;
+};
+
+}  // namespace scann
