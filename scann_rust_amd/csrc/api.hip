@@ -34,7 +34,7 @@ enum IndexKind { KIND_BF = 1, KIND_TXH = 2 };
 
 struct TxhWorkspace {
     DevBuf queries, cdist, tokens, token_dists, vbase, leaf_cnt, leaf_cursor, pair_off, tile_off,
-        counters, pair_q, pair_leaf, pair_vbase, slot_of, lutq, thr, cand_cnt, cand, cand_key,
+        counters, pair_q, pair_leaf, pair_vbase, pair_thr, slot_of, lutq, thr, cand_cnt, cand, cand_key,
         cand_idx, cand_dist, cand_exact, cand_row, cand_count, out_idx, out_dist, out_count;
 };
 
@@ -427,6 +427,7 @@ static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallP
     SCANN_TRY(s.pair_q.ensure((size_t)max_slots * 4));
     SCANN_TRY(s.pair_leaf.ensure((size_t)max_slots * 4));
     SCANN_TRY(s.pair_vbase.ensure((size_t)max_slots * 4));
+    SCANN_TRY(s.pair_thr.ensure((size_t)max_slots * 8));
     SCANN_TRY(s.slot_of.ensure((size_t)nq * P * 4));
     SCANN_TRY(s.lutq.ensure((size_t)max_quads * t.S * 16 * 4 * 4));
     SCANN_TRY(s.thr.ensure((size_t)nq * 8));
@@ -464,6 +465,7 @@ static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallP
     w->pair_q = s.pair_q.as<uint32_t>();
     w->pair_leaf = s.pair_leaf.as<uint32_t>();
     w->pair_vbase = s.pair_vbase.as<uint32_t>();
+    w->pair_thr = s.pair_thr.as<uint64_t>();
     w->slot_of = s.slot_of.as<uint32_t>();
     w->max_slots = max_slots;
     w->max_quads = max_quads;

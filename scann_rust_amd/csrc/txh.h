@@ -12,7 +12,7 @@ constexpr uint32_t kScanQuadsPerTile = 32;                // query quads per til
 constexpr uint32_t kSortCap = 16384;                      // u64 keys sorted in LDS (select)
 constexpr uint32_t kSampleBuf = 8192;                     // LDS key buffer of the sampler
 constexpr uint32_t kSampleBest = 4096;                    // max rank taken from the sample
-constexpr uint32_t kSampleTarget = 65536;                 // max sample points per query
+constexpr uint32_t kSampleTarget = 32768;                 // max sample points per query
 constexpr uint32_t kSampleMin = 4096;                     // min sample points per query
 constexpr uint32_t kMaxPreReorderK = 8192;                // m limit of the LDS select
 constexpr uint32_t kMaxPartitionsToSearch = 4096;
@@ -84,6 +84,7 @@ struct TxhWork {
     uint32_t max_slots, max_quads;
     float *lutq;               // [max_quads][S][16][4]
     uint64_t *thr;             // [nq]
+    uint64_t *pair_thr;        // [max_slots] the same bound per (query, leaf) pair slot
     uint32_t *cand_cnt;        // [nq]
     uint64_t *cand;            // [nq][cap]
     uint64_t *cand_key;        // [nq][m] selected merge keys

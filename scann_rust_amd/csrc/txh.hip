@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(
     TxhIndexDev ix, uint32_t P, uint32_t m, int no_threshold,
     const uint32_t *__restrict__ tokens, const uint32_t *__restrict__ vbase,
     const uint32_t *__restrict__ slot_of, const float *__restrict__ lutq,
-    uint64_t *__restrict__ thr) {
+    uint64_t *__restrict__ thr, uint64_t *__restrict__ pair_thr) {
     constexpr int S = NW * 8;
     extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];      // [kSampleBuf]
     float *slut = reinterpret_cast<float *>(skeys + kSampleBuf);          // [S*16]
@@ -319,8 +319,16 @@ __global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(
     const uint32_t total = s_misc[1];
     const uint32_t st = sample_stride(total);
     const uint32_t J = (no_threshold || total <= m) ? 0u : sample_rank(m, st);
+    // the scan reads the bound per (query, leaf) pair slot: no dependent pair_q -> thr load
+    auto publish = [&](uint64_t T) {
+        if (tid == 0) thr[q] = T;
+        for (uint32_t r = tid; r < P; r += nt) {
+            const uint32_t sl = slot_of[(size_t)q * P + r];
+            if (sl != kInvalid) pair_thr[sl] = T;
+        }
+    };
     if (J == 0) {   // uniform
-        if (tid == 0) thr[q] = SCANN_KEY_MAX;
+        publish(SCANN_KEY_MAX);
         return;
     }
     uint32_t B = 2048;
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(
         __syncthreads();
     }
     compact();
-    if (tid == 0) thr[q] = (fill >= J) ? skeys[J - 1] : SCANN_KEY_MAX;
+    publish((fill >= J) ? skeys[J - 1] : SCANN_KEY_MAX);
 }
 
 // =====================================================================================
@@ -444,7 +452,7 @@ struct ScanArgs {
     const uint32_t *pair_off, *tile_off, *pair_q, *pair_vbase;
     uint32_t *counters;
     const float *lutq;
-    const uint64_t *thr;
+    const uint64_t *pair_thr;
     uint32_t *cand_cnt;
     uint64_t *cand;
     uint32_t cap;
@@ -549,13 +557,31 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 4 : 2)) void adc_scan_kern
                 gq = a.pair_q[slot0 + (qd - 1) * 4 + tid];
                 if (gn) gbase = atomicAdd(&a.cand_cnt[gq], gn);
             }
-            float4 nx[STG];
+            // A2. prefetch the next quad's LUT straight into the idle LDS buffer (LDS-DMA:
+            // no VGPR staging; destination = wave-uniform base + lane * 16).
             if (more) {
                 const float4 *g2 = gl + (size_t)(qd + 1 - q0) * LUT4;
 #pragma unroll
                 for (int t = 0; t < STG; ++t) {
-                    uint32_t e = tid + t * kScanThreads;
-                    if (e < (uint32_t)LUT4) nx[t] = g2[e];
+                    const uint32_t e0 = (tid & ~63u) + t * kScanThreads;   // wave-uniform
+                    if (e0 < (uint32_t)LUT4)
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void *)(g2 + e0 + (tid & 63u)),
+                            (__attribute__((address_space(3))) void *)(&lut_s[(buf ^ 1u) * LUT4 + e0]),
+                            16, 0, 0);
+                }
+            }
+            // A3. wave-uniform filter parameters of this quad, fetched ahead of the gather
+            uint32_t f_pq[4], f_vb[4], f_thi[4], f_tlo[4];
+            if (live) {
+                const uint32_t slot = slot0 + qd * 4;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    f_pq[p] = __builtin_amdgcn_readfirstlane(a.pair_q[slot + p]);
+                    f_vb[p] = __builtin_amdgcn_readfirstlane(a.pair_vbase[slot + p]);
+                    const uint64_t T = a.pair_thr[slot + p];
+                    f_thi[p] = __builtin_amdgcn_readfirstlane((uint32_t)(T >> 32));
+                    f_tlo[p] = __builtin_amdgcn_readfirstlane((uint32_t)T);
                 }
             }
 
@@ -578,15 +604,14 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 4 : 2)) void adc_scan_kern
                     }
                 }
                 // threshold filter: survivors go to the LDS stage of this quad
-                const uint32_t slot = slot0 + qd * 4;
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    const uint32_t pq = a.pair_q[slot + p];
+                    const uint32_t pq = f_pq[p];
                     if (pq == kInvalid) continue;   // wave-uniform
-                    const uint64_t T = a.thr[pq];
-                    const uint32_t Thi = (uint32_t)(T >> 32);
+                    const uint64_t T = ((uint64_t)f_thi[p] << 32) | f_tlo[p];
+                    const uint32_t Thi = f_thi[p];
                     const float Tf = (Thi == 0xFFFFFFFFu) ? __builtin_inff() : ordered_to_f32(Thi);
-                    const uint32_t vb = a.pair_vbase[slot + p];
+                    const uint32_t vb = f_vb[p];
 #pragma unroll
                     for (int i = 0; i < (int)kScanPPT; ++i) {
                         if (i < (int)nsub && acc[p][i] <= Tf) {
@@ -609,19 +634,13 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 4 : 2)) void adc_scan_kern
             }
 
             // C. publish the flush parameters, reset the flushed buffer's live counters
-            if (more) {
-#pragma unroll
-                for (int t = 0; t < STG; ++t) {
-                    uint32_t e = tid + t * kScanThreads;
-                    if (e < (uint32_t)LUT4) lut_s[(buf ^ 1u) * LUT4 + e] = nx[t];
-                }
-            }
             if (tid < 4) {
                 cfrozen_s[tid] = gn;
                 cbase_s[tid] = gbase;
                 cq_s[tid] = gq;
                 if (flush) ccnt_s[buf ^ 1u][tid] = 0;
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA prefetch has landed
             __syncthreads();
             // D. copy the previous quad's survivors to the per-query candidate lists
             if (flush) {
@@ -1038,11 +1057,12 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
     const size_t lds_thr = (size_t)kSampleBuf * sizeof(uint64_t) + (size_t)S * 16 * sizeof(float) + 16;
     SCANN_TRY(set_dyn_lds(sample_threshold_kernel<NW>, lds_thr));
     hipLaunchKernelGGL(sample_threshold_kernel<NW>, dim3(w.nq), dim3(kSelectThreads), lds_thr, st,
-                       ix, w.P, w.m, w.no_threshold, w.tokens, w.vbase, w.slot_of, w.lutq, w.thr);
+                       ix, w.P, w.m, w.no_threshold, w.tokens, w.vbase, w.slot_of, w.lutq, w.thr,
+                       w.pair_thr);
     LAUNCH_CHECK();
     ScanArgs a;
     a.pair_off = w.pair_off; a.tile_off = w.tile_off; a.pair_q = w.pair_q;
-    a.pair_vbase = w.pair_vbase; a.counters = w.counters; a.lutq = w.lutq; a.thr = w.thr;
+    a.pair_vbase = w.pair_vbase; a.counters = w.counters; a.lutq = w.lutq; a.pair_thr = w.pair_thr;
     a.cand_cnt = w.cand_cnt; a.cand = w.cand; a.cap = w.cap;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
