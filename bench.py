@@ -46,7 +46,7 @@ def parse():
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--workload", default="ah", choices=["ah", "bf_dot", "txh"])
-    p.add_argument("--n", type=int, default=1_000_000)
+    p.add_argument("--num-points", dest="n", type=int, default=1_000_000)
     p.add_argument("--dim", type=int, default=128)
     p.add_argument("--subspaces", type=int, default=32)
     p.add_argument("--batch", type=int, default=1024)
@@ -59,6 +59,9 @@ def parse():
     p.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-recall", action="store_true")
+    # rehearsal knobs (not used by the driver): gloo collectives / all ranks on one device
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    p.add_argument("--single-device", action="store_true")
     return p.parse_args()
 
 
@@ -78,11 +81,24 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)   # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
+
+    def all_gather(dst, src):
+        if args.backend == "nccl":
+            dist.all_gather_into_tensor(dst, src)
+        else:   # rehearsal path: stage through host memory
+            parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(world)]
+            dist.all_gather(parts, src.cpu())
+            dst.copy_(torch.stack(parts).to(dst.device))
 
     L = hip.load()
     n, dim, S, K, k, Q = args.n, args.dim, args.subspaces, 16, args.k, args.batch
@@ -153,7 +169,8 @@ def main():
                     codebook=codebook, codes=codes, use_residuals=False,
                     partitions_to_search=world, pre_reorder_multiplier=float(m) / k,
                     data_is_csr_order=True, device=local_rank)
-            algo_bytes_per_query = n * (S // 2) + S * 16 * 4 + k * 8   # 16 002 128
+            # 16 002 128 B at N = 1; per launch a rank scans its n_loc points
+            algo_bytes_per_query = n_loc * (S // 2) + S * 16 * 4 + k * 8
         else:
             raise SystemExit("txh workload is wired in tools/sweep.py; bench default is `ah`")
         opts.pre_reorder_k = m
@@ -189,10 +206,10 @@ def main():
                                                           ctypes.byref(opts), dev_ptr(keys),
                                                           dev_ptr(cidx), dev_ptr(cex), dev_ptr(ccnt),
                                                           sptr))
-            dist.all_gather_into_tensor(g_keys, keys)
-            dist.all_gather_into_tensor(g_idx, cidx)
-            dist.all_gather_into_tensor(g_ex, cex)
-            dist.all_gather_into_tensor(g_cnt, ccnt)
+            all_gather(g_keys, keys)
+            all_gather(g_idx, cidx)
+            all_gather(g_ex, cex)
+            all_gather(g_cnt, ccnt)
             hip.check(L.scann_hip_txh_merge_device(hip.context(local_rank), world, Q, m, k,
                                                    dev_ptr(g_keys), dev_ptr(g_idx), dev_ptr(g_ex),
                                                    dev_ptr(g_cnt), dev_ptr(out_idx),
@@ -219,7 +236,8 @@ def main():
     index.enable_timing(False)
     hip.check(L.scann_hip_index_last_device_status(index.h, sptr))
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     qps = Q * args.steps / elapsed
@@ -236,6 +254,22 @@ def main():
         hits = sum(len(set(gi[i].tolist()) & set(ti[i].tolist())) for i in range(ne))
         recall = hits / float(ne * k)
         bf.close()
+    if rank == 0 and world > 1 and args.workload == "ah":
+        # the merged rows of the last timed step, checked against the oracle on the FULL
+        # database (rank 0 regenerates it; checker only)
+        from oracle import pyoracle as orc
+        full = np.zeros((n, stride), np.float32)
+        full[:, :dim] = synth.uniform_f32(n, dim, 42)
+        fcodes = trainer.encode(codebook, full[:, :dim])
+        last = np.ascontiguousarray(queries_all[((args.steps - 1) % nbatches) * Q:][:4])
+        gi = out_idx[:4].cpu().numpy().view(np.uint32)
+        gd = out_dist[:4].cpu().numpy()
+        ok = True
+        for i in range(4):
+            oi, od = orc.ah_search_with_reordering(codebook, fcodes, full, stride, last[i], k, m)
+            ok = ok and np.array_equal(gd[i].view(np.uint32), od.view(np.uint32)) \
+                and sorted(gi[i].tolist()) == sorted(oi.tolist())
+        checked = bool(ok)
     if rank == 0 and world == 1:
         # result rows of the timed path checked against the oracle (checker only)
         from oracle import pyoracle as orc
@@ -288,8 +322,8 @@ def main():
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kernel_name,
                     "kernel_ms": kernel_ms,
-                    "algorithmic": "%d B per query (N*S/2 codes + S*16*4 LUT + k*8 out) x %d "
-                                   "queries per launch" % (algo_bytes_per_query, Q)}
+                    "algorithmic": "%d B per query (N_local*S/2 codes + S*16*4 LUT + k*8 out) x %d "
+                                   "queries per launch (rank 0)" % (algo_bytes_per_query, Q)}
         tr = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr):
             try:
