@@ -139,23 +139,29 @@ __global__ __launch_bounds__(256) void bf_generic_kernel(BfIndexDev ix, BfPass p
 }
 
 // =====================================================================================
-// MFMA kernel: DotProduct, dim = 16 * TS.  Block = 4 waves; wave w owns 32 queries
-// (Q fragments resident in VGPRs), all waves share a 32-row X tile staged in LDS
-// (padded rows: conflict-free ds_read_b128).  Operand maps (v_mfma_f32_32x32x2_f32):
+// MFMA kernel: DotProduct, dim = 16 * TS (dim % 32 == 0).  Block = 4 waves; wave w owns
+// 32 queries (Q fragments resident in VGPRs); all waves share a 32-row X tile that is
+// DMA'd global -> LDS (global_load_lds_dwordx4, no VGPR staging), double-buffered.  The
+// LDS image is linear (DMA writes wave-base + lane*16); bank conflicts of the
+// row-per-lane ds_read_b128 are removed by XOR-swizzling the 16-B chunk index with the
+// row number on the SOURCE address and again on the read.  Two blocks per CU
+// (<= 256 VGPR+AGPR) so one block's epilogue overlaps the other's MFMAs.
+// Operand maps (v_mfma_f32_32x32x2_f32):
 //   A[i = lane & 31][k = lane >> 5] = X[row i][16t + 8h + j]
 //   B[k = lane >> 5][n = lane & 31] = Q[query n][16t + 8h + j]
 //   D[row = (r&3) + 8*(r>>2) + 4h][col = lane & 31]
 // Chain j accumulates k = j, 8+j, 16+j, ... in ascending order == AVX2 lane j.
 // =====================================================================================
 template <int TS>
-__global__ __launch_bounds__(256) void bf_mfma_dot_kernel(BfIndexDev ix, BfPass p, uint32_t nx,
-                                                          uint32_t ny) {
+__global__ __launch_bounds__(256, 2) void bf_mfma_dot_kernel(BfIndexDev ix, BfPass p, uint32_t nx,
+                                                             uint32_t ny) {
     constexpr int DIM = TS * 16;
-    constexpr int LDX = DIM + 4;              // padded row (floats)
-    constexpr int V4_PER_ROW = DIM / 4;
-    constexpr int V4_PER_TILE = 32 * V4_PER_ROW;
-    constexpr int STG = (V4_PER_TILE + 255) / 256;
-    extern __shared__ __attribute__((aligned(16))) float xs[];   // [2][32][LDX]
+    constexpr int CPR = DIM / 4;                       // 16-B chunks per row
+    constexpr uint32_t SW = (CPR % 16 == 0) ? 15u : 7u; // swizzle mask (CPR % 8 == 0)
+    constexpr int TILE_F = 32 * DIM;                   // floats per tile
+    constexpr int DMA_PER_WAVE = DIM / 32;             // 1 KiB wave-instructions per wave
+    static_assert(TS % 2 == 0, "dim must be a multiple of 32");
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [2][32][DIM]
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t h = lane >> 5, li = lane & 31u;
@@ -183,65 +189,75 @@ __global__ __launch_bounds__(256) void bf_mfma_dot_kernel(BfIndexDev ix, BfPass 
     }
     const bool qvalid = q < p.nq;
 
-    float4 stg[STG];
-    auto load_tile = [&](uint32_t tile) {
+    auto dma_tile = [&](uint32_t tile, uint32_t buf) {
 #pragma unroll
-        for (int s = 0; s < STG; ++s) {
-            const uint32_t e = tid + s * 256u;
-            if (e < (uint32_t)V4_PER_TILE) {
-                const uint32_t r = e / V4_PER_ROW, c4 = e - r * V4_PER_ROW;
-                const uint32_t vr = min(tile * 32u + r, p.nrows - 1u);
-                stg[s] = *reinterpret_cast<const float4 *>(
-                    ix.rows + (size_t)vr * p.row_mult * ix.stride + 4u * c4);
-            }
-        }
-    };
-    auto store_tile = [&](uint32_t buf) {
-#pragma unroll
-        for (int s = 0; s < STG; ++s) {
-            const uint32_t e = tid + s * 256u;
-            if (e < (uint32_t)V4_PER_TILE) {
-                const uint32_t r = e / V4_PER_ROW, c4 = e - r * V4_PER_ROW;
-                *reinterpret_cast<float4 *>(xs + (size_t)buf * 32 * LDX + r * LDX + 4u * c4) = stg[s];
-            }
+        for (int t = 0; t < DMA_PER_WAVE; ++t) {
+            const uint32_t gi = wave * DMA_PER_WAVE + t;          // wave-uniform
+            const uint32_t ci = gi * 64u + lane;                  // linear chunk index in the tile
+            const uint32_t r = ci / CPR, pos = ci - r * CPR;
+            const uint32_t vr = min(tile * 32u + r, p.nrows - 1u);
+            const float *src = ix.rows + (size_t)vr * p.row_mult * ix.stride + 4u * (pos ^ (r & SW));
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)src,
+                (__attribute__((address_space(3))) void *)(xs + (size_t)buf * TILE_F + gi * 256u), 16, 0, 0);
         }
     };
 
     uint32_t tile = x;
     if (tile >= ntiles) return;   // uniform per block
-    load_tile(tile);
-    store_tile(0);
+    dma_tile(tile, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     uint32_t buf = 0;
+    const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
+                         0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const uint32_t sw = li & SW;
     for (; tile < ntiles; tile += nx) {
         const uint32_t next = tile + nx;
-        if (next < ntiles) load_tile(next);
+        if (next < ntiles) dma_tile(next, buf ^ 1u);
 
         f32x16 acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-        const float *xrow = xs + (size_t)buf * 32 * LDX + li * LDX + 8u * h;
+        const float *xrow = xs + (size_t)buf * TILE_F + li * DIM;
 #pragma unroll
         for (int t = 0; t < TS; ++t) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(xrow + 16 * t);
-            const float4 a1 = *reinterpret_cast<const float4 *>(xrow + 16 * t + 4);
+            const uint32_t c0 = 4u * t + 2u * h;
+            const float4 a0 = *reinterpret_cast<const float4 *>(xrow + 4u * (c0 ^ sw));
+            const float4 a1 = *reinterpret_cast<const float4 *>(xrow + 4u * ((c0 + 1u) ^ sw));
             const float xa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j], qf[t * 8 + j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j], qf[t * 8 + j], t == 0 ? zero : acc[j],
+                                                              0, 0, 0);
         }
-        // epilogue: horizontal_sum_f32_avx2 tree, negate, emit
+        // epilogue: horizontal_sum_f32_avx2 tree, negate
+        float dist[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float s0 = acc[0][r] + acc[4][r], s1 = acc[1][r] + acc[5][r];
             const float s2 = acc[2][r] + acc[6][r], s3 = acc[3][r] + acc[7][r];
-            const float dist = -((s0 + s1) + (s2 + s3));
-            const uint32_t vrow = tile * 32u + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (qvalid && vrow < p.nrows) bf_emit(p, q, vrow, dist, Tf, T);
+            dist[r] = -((s0 + s1) + (s2 + s3));
         }
-        if (next < ntiles) store_tile(buf ^ 1u);
+        const bool full = tile * 32u + 32u <= p.nrows;
+        if (p.filter) {
+            // one wave-level test per tile; survivors are rare
+            float dmin = dist[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) dmin = fminf(dmin, dist[r]);
+            if (__any(qvalid && (dmin <= Tf || !full))) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t vrow = tile * 32u + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (qvalid && vrow < p.nrows) bf_emit(p, q, vrow, dist[r], Tf, T);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t vrow = tile * 32u + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (qvalid && (full || vrow < p.nrows)) p.out[(size_t)q * p.ld + vrow] = dist[r];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA has landed
         __syncthreads();
         buf ^= 1u;
     }
@@ -389,10 +405,10 @@ template <int TS>
 static int launch_mfma(const BfIndexDev &ix, const BfPass &p, hipStream_t st) {
     const uint32_t ny = ceil_div_u32(p.nq, 128);
     const uint32_t ntiles = ceil_div_u32(p.nrows, 32);
-    uint32_t want = std::max<uint32_t>(1, (2u * (uint32_t)num_cus()) / ny);
+    uint32_t want = std::max<uint32_t>(1, (4u * (uint32_t)num_cus()) / ny);
     want = std::min(want, ntiles);
     const uint32_t nx = 8u * ceil_div_u32(want, 8);
-    const size_t lds = (size_t)2 * 32 * (TS * 16 + 4) * sizeof(float);
+    const size_t lds = (size_t)2 * 32 * (TS * 16) * sizeof(float);
     SCANN_TRY(set_dyn_lds(bf_mfma_dot_kernel<TS>, lds));
     hipLaunchKernelGGL(bf_mfma_dot_kernel<TS>, dim3(nx * ny), dim3(256), lds, st, ix, p, nx, ny);
     LAUNCH_CHECK();
@@ -403,7 +419,7 @@ static bool mfma_eligible(const BfIndexDev &ix) {
     if (ix.measure != SCANN_HIP_DOT_PRODUCT) return false;
     if ((ix.stride & 3u) || (reinterpret_cast<uintptr_t>(ix.rows) & 15u)) return false;
     switch (ix.dim) {
-        case 16: case 32: case 48: case 64: case 96: case 128: case 192: case 256: return true;
+        case 32: case 64: case 96: case 128: case 192: case 256: return true;
         default: return false;
     }
 }
@@ -412,9 +428,7 @@ static int launch_pass(const BfIndexDev &ix, const BfPass &p, hipStream_t st) {
     if (p.nq == 0 || p.nrows == 0) return SCANN_HIP_OK;
     if (mfma_eligible(ix)) {
         switch (ix.dim / 16) {
-            case 1: return launch_mfma<1>(ix, p, st);
             case 2: return launch_mfma<2>(ix, p, st);
-            case 3: return launch_mfma<3>(ix, p, st);
             case 4: return launch_mfma<4>(ix, p, st);
             case 6: return launch_mfma<6>(ix, p, st);
             case 8: return launch_mfma<8>(ix, p, st);

@@ -64,10 +64,11 @@ def normal_f32(n, dim, seed, chunk_rows=1 << 16):
 
 def clustered_f32(n, dim, seed, n_clusters=1000, sigma_frac=0.1):
     """Mixture of n_clusters isotropic Gaussians (second
-    distribution): centres U[0,1)^dim, sigma = sigma_frac * typical inter-centre
-    distance (sqrt(dim/6)).  Returns (points, assignment)."""
+    distribution): centres U[0,1)^dim, |noise| ~ sigma_frac * typical
+    inter-centre distance sqrt(dim/6) (per-dimension sigma = sigma_frac / sqrt(6)).  Returns (points, assignment)."""
     centres = uniform_f32(n_clusters, dim, seed ^ 0x5EED)
-    sigma = np.float32(sigma_frac * np.sqrt(dim / 6.0))
+    # total sigma = sigma_frac * sqrt(dim/6); per dimension divide by sqrt(dim)
+    sigma = np.float32(sigma_frac * np.sqrt(1.0 / 6.0))
     a = (splitmix64(seed ^ 0xA551, 0, n) % np.uint64(n_clusters)).astype(np.int64)
     pts = centres[a] + sigma * normal_f32(n, dim, seed)
     return pts.astype(np.float32), a
