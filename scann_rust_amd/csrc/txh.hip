@@ -729,7 +729,6 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
     extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];      // [kSortCap]
     uint32_t *s_wave = reinterpret_cast<uint32_t *>(skeys + kSortCap);    // [kSelectThreads/64]
     uint32_t *s_basep = s_wave + kSelectThreads / 64;                     // [4]
-    float *s_q = reinterpret_cast<float *>(s_basep + 4);                  // [dim]
     const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const uint32_t m = a.m, k = a.k;
 
@@ -808,59 +807,88 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
         return;
     }
 
-    // exact SquaredL2, 8 lanes per candidate = the 8 AVX2 lanes of squared_l2_avx2
+    // exact re-rank and the final sort run in rerank_kernel / final_sort_kernel
+}
+
+// =====================================================================================
+// K8: exact re-rank.  tree_x_hybrid/mod.rs:350-358 -> squared_l2_avx2
+// (simd/x86.rs:139-165): 8 lanes per candidate are the 8 AVX2 FMA lane chains (chunk
+// order), combined by the fixed hsum tree (x86.rs:31-44) with DPP shuffles, plus the
+// non-fused scalar tail.  32 candidates per 256-thread block, grid over (candidates,
+// queries): the random row gathers are spread over the whole chip.
+// =====================================================================================
+__global__ __launch_bounds__(256) void rerank_kernel(TxhIndexDev ix, const float *__restrict__ queries,
+                                                     uint32_t q_stride, uint32_t m,
+                                                     const uint32_t *__restrict__ cand_row,
+                                                     const uint32_t *__restrict__ cand_count,
+                                                     float *__restrict__ cand_exact) {
+    extern __shared__ __attribute__((aligned(16))) float s_q[];   // [dim]
+    const uint32_t q = blockIdx.y, tid = threadIdx.x;
+    const uint32_t nsel = cand_count[q];
+    const uint32_t c0 = blockIdx.x * 32u;
+    if (c0 >= nsel) return;   // uniform
     const uint32_t dim = ix.dim;
-    for (uint32_t j = tid; j < dim; j += nt) s_q[j] = a.queries[(size_t)q * a.q_stride + j];
-    __syncthreads();   // also orders the cand_row writes above
+    for (uint32_t j = tid; j < dim; j += blockDim.x) s_q[j] = queries[(size_t)q * q_stride + j];
+    __syncthreads();
     const uint32_t chunks = dim >> 3, lane8 = tid & 7u;
-    const uint32_t nround = (nsel + nt / 8 - 1) / (nt / 8);
-    for (uint32_t rd = 0; rd < nround; ++rd) {
-        const uint32_t c = rd * (nt / 8) + (tid >> 3);
-        const bool act = c < nsel;
-        float accv = 0.0f;
-        const float *row = nullptr;
-        if (act) {
-            row = ix.rows + (size_t)a.cand_row[(size_t)q * m + c] * ix.stride;
-            for (uint32_t i = 0; i < chunks; ++i) {
-                const float diff = s_q[8 * i + lane8] - row[8 * i + lane8];
+    const uint32_t c = c0 + (tid >> 3);
+    const bool act = c < nsel;
+    float accv = 0.0f;
+    const float *row = ix.rows;
+    if (act) row = ix.rows + (size_t)cand_row[(size_t)q * m + c] * ix.stride;
+    for (uint32_t i0 = 0; i0 < chunks; i0 += 8) {   // 8 independent loads in flight per lane
+        float xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = (act && i0 + u < chunks) ? row[8 * (i0 + u) + lane8] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u < chunks) {
+                const float diff = s_q[8 * (i0 + u) + lane8] - xv[u];
                 accv = fmaf(diff, diff, accv);        // _mm256_fmadd_ps(diff, diff, sum)
             }
         }
-        // horizontal_sum_f32_avx2 (simd/x86.rs:31-44): (lo+hi) -> +movehdup -> +movehl
-        float s = accv + __shfl_down(accv, 4, 8);     // lanes 0..3: v[j] + v[j+4]
-        float t = s + __shfl_down(s, 1, 8);           // lane 0: s0+s1, lane 2: s2+s3
-        float r = t + __shfl_down(t, 2, 8);           // lane 0: (s0+s1) + (s2+s3)
-        if (act && lane8 == 0) {
-            for (uint32_t j = chunks * 8; j < dim; ++j) {   // scalar tail, not fused
-                const float diff = s_q[j] - row[j];
-                r = r + diff * diff;
-            }
-            a.cand_exact[(size_t)q * m + c] = r;
-        }
     }
-    if (a.local_only) return;
-    __syncthreads();
+    // horizontal_sum_f32_avx2: (lo+hi) -> +movehdup -> +movehl
+    float s = accv + __shfl_down(accv, 4, 8);     // lanes 0..3: v[j] + v[j+4]
+    float t = s + __shfl_down(s, 1, 8);           // lane 0: s0+s1, lane 2: s2+s3
+    float r = t + __shfl_down(t, 2, 8);           // lane 0: (s0+s1) + (s2+s3)
+    if (act && lane8 == 0) {
+        for (uint32_t j = chunks * 8; j < dim; ++j) {   // scalar tail, not fused
+            const float diff = s_q[j] - row[j];
+            r = r + diff * diff;
+        }
+        cand_exact[(size_t)q * m + c] = r;
+    }
+}
 
-    // stable sort by exact distance: key = (ordered(exact) << 32 | approx rank)
+// K9: stable sort by exact distance (key = ordered(exact) << 32 | approx rank), first k.
+// tree_x_hybrid/mod.rs:360-361.
+__global__ __launch_bounds__(kSelectThreads) void final_sort_kernel(
+    uint32_t m, uint32_t k, const uint32_t *__restrict__ cand_count,
+    const uint32_t *__restrict__ cand_idx, const float *__restrict__ cand_exact,
+    uint32_t *__restrict__ out_idx, float *__restrict__ out_dist, uint32_t *__restrict__ out_count) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t nsel = cand_count[q];
     uint32_t m2 = 1;
     while (m2 < nsel) m2 <<= 1;
     for (uint32_t i = tid; i < m2; i += nt)
-        skeys[i] = (i < nsel) ? make_key(a.cand_exact[(size_t)q * m + i], i) : SCANN_KEY_MAX;
+        skeys[i] = (i < nsel) ? make_key(cand_exact[(size_t)q * m + i], i) : SCANN_KEY_MAX;
     __syncthreads();
     bitonic_sort_lds(skeys, m2);
-    const uint32_t nout = min(k, nsel);   // truncate(k)  mod.rs:361
+    const uint32_t nout = min(k, nsel);   // truncate(k)
     for (uint32_t i = tid; i < k; i += nt) {
         uint32_t oi = kInvalid;
         float od = __builtin_inff();
         if (i < nout) {
             const uint64_t key = skeys[i];
-            oi = a.cand_idx[(size_t)q * m + (uint32_t)key];
+            oi = cand_idx[(size_t)q * m + (uint32_t)key];
             od = ordered_to_f32((uint32_t)(key >> 32));
         }
-        a.out_idx[(size_t)q * k + i] = oi;
-        a.out_dist[(size_t)q * k + i] = od;
+        out_idx[(size_t)q * k + i] = oi;
+        out_dist[(size_t)q * k + i] = od;
     }
-    if (tid == 0) a.out_count[q] = nout;
+    if (tid == 0) out_count[q] = nout;
 }
 
 // =====================================================================================
@@ -1120,10 +1148,21 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
     s.cand_idx = w.cand_idx; s.cand_dist = w.cand_dist; s.cand_exact = w.cand_exact;
     s.cand_count = w.cand_count; s.out_idx = w.out_idx; s.out_dist = w.out_dist;
     s.out_count = w.out_count;
-    const size_t lds_sel = (size_t)kSortCap * 8 + (size_t)(kSelectThreads / 64 + 4) * 4 +
-                           (size_t)ix.dim * 4;
+    const size_t lds_sel = (size_t)kSortCap * 8 + (size_t)(kSelectThreads / 64 + 4) * 4;
     SCANN_TRY(set_dyn_lds(select_rerank_kernel, lds_sel));
     hipLaunchKernelGGL(select_rerank_kernel, dim3(w.nq), dim3(kSelectThreads), lds_sel, st, ix, s);
+    LAUNCH_CHECK();
+    if (!w.exact_reorder) return SCANN_HIP_OK;
+    const size_t lds_rr = (size_t)ix.dim * 4;
+    SCANN_TRY(set_dyn_lds(rerank_kernel, lds_rr));
+    hipLaunchKernelGGL(rerank_kernel, dim3(ceil_div_u32(w.m, 32), w.nq), dim3(256), lds_rr, st, ix,
+                       w.queries, w.q_stride, w.m, w.cand_row, w.cand_count, w.cand_exact);
+    LAUNCH_CHECK();
+    if (local_only) return SCANN_HIP_OK;
+    const size_t lds_fs = (size_t)next_pow2_u32(std::max(1u, w.m)) * 8;
+    SCANN_TRY(set_dyn_lds(final_sort_kernel, lds_fs));
+    hipLaunchKernelGGL(final_sort_kernel, dim3(w.nq), dim3(kSelectThreads), lds_fs, st, w.m, w.k,
+                       w.cand_count, w.cand_idx, w.cand_exact, w.out_idx, w.out_dist, w.out_count);
     LAUNCH_CHECK();
     return SCANN_HIP_OK;
 }

@@ -76,3 +76,28 @@ def recall_at_k(retrieved, gt, k):
     for r, g in zip(retrieved, gt):
         tot += len(set(r[:k].tolist()) & set(g[:k].tolist())) / float(k)
     return tot / len(retrieved)
+
+
+def check_txh_query(oix, query, k, got_idx, got_dist, got_tok, got_tokd, got_ci, got_cd, what=""):
+    """Stage-aware parity check of one Tree-X-Hybrid query against the oracle.
+
+    tokens / centre distances: bit-exact.  Candidates: the sorted approximate distances
+    must be bitwise identical; memberships may differ only inside ties of the approximate
+    distance (FastTopNeighbors' slot-order tie behaviour is not reproduced: SURVEY 8c "up
+    to distance ties").  Final rows: equal to the oracle's if the candidate sets agree,
+    otherwise equal to the oracle's exact re-rank OF THE GPU's candidate list."""
+    oi, od, otok, otokd, oci, ocd = orc.txh_search(oix, query, k, stages=True)
+    P = otok.size
+    assert np.array_equal(got_tok[:P], otok), "%s tokens" % what
+    assert np.array_equal(np.asarray(got_tokd[:P], np.float32).view(np.uint32), otokd.view(np.uint32))
+    assert got_ci.size == oci.size, "%s candidate count %d vs %d" % (what, got_ci.size, oci.size)
+    assert np.array_equal(np.asarray(got_cd, np.float32).view(np.uint32), ocd.view(np.uint32)), \
+        "%s approximate distances differ" % what
+    assert_topk_equal_up_to_ties(got_ci, got_cd, oci, ocd, what=what + " cand")
+    if sorted(got_ci.tolist()) == sorted(oci.tolist()):
+        assert got_idx.size == oi.size
+        assert_topk_equal_up_to_ties(got_idx, got_dist, oi, od, what=what + " final")
+    else:
+        ri, rd = orc.reorder(oix.data, oix.stride, oix.dim, query, got_ci, k)
+        assert got_idx.size == ri.size
+        assert_topk_equal_up_to_ties(got_idx, got_dist, ri, rd, what=what + " final(gpu cands)")

@@ -144,13 +144,8 @@ def test_txh_search_stages(seed, dim, S, P, mult):
     o.pre_reorder_k = m
     idx, dist, cnt, (tok, tokd, ci, cd, cc) = index.search_batched(q, k, o, stages=True)
     for i in range(nq):
-        oi, od, otok, otokd, oci, ocd = orc.txh_search(oix, q[i], k, stages=True)
-        assert np.array_equal(tok[i, :P], otok), "tokens q%d" % i
-        assert np.array_equal(bits(tokd[i, :P]), bits(otokd))
-        assert cc[i] == oci.size
-        H.assert_topk_equal_up_to_ties(ci[i, :cc[i]], cd[i, :cc[i]], oci, ocd, what="cand q%d" % i)
-        assert cnt[i] == oi.size
-        H.assert_topk_equal_up_to_ties(idx[i, :cnt[i]], dist[i, :cnt[i]], oi, od, what="final q%d" % i)
+        H.check_txh_query(oix, q[i], k, idx[i, :cnt[i]], dist[i, :cnt[i]], tok[i], tokd[i],
+                          ci[i, :cc[i]], cd[i, :cc[i]], what="q%d" % i)
 
 
 def test_txh_no_residuals_and_clustered():
@@ -159,10 +154,13 @@ def test_txh_no_residuals_and_clustered():
                                                       kmeans_iters=3, pq_iters=3)
     index = hip.txh_create(**kw)
     q = rows[::200] + np.float32(0.01)
-    idx, dist, cnt = index.search_batched(q, 10)
-    for i in range(q.shape[0]):
-        oi, od = orc.txh_search(oix, q[i], 10)
-        H.assert_topk_equal_up_to_ties(idx[i, :cnt[i]], dist[i, :cnt[i]], oi, od, what="q%d" % i)
+    o = hip.default_opts()
+    o.partitions_to_search = 6
+    o.pre_reorder_k = 50
+    idx, dist, cnt, (tok, tokd, ci, cd, cc) = index.search_batched(q, 10, o, stages=True)
+    for i in range(q.shape[0]):   # tight clusters + global codebook: many approximate ties
+        H.check_txh_query(oix, q[i], 10, idx[i, :cnt[i]], dist[i, :cnt[i]], tok[i], tokd[i],
+                          ci[i, :cc[i]], cd[i, :cc[i]], what="q%d" % i)
 
 
 def test_txh_ragged_and_short_results():
