@@ -1,0 +1,103 @@
+"""Full-size (BASELINE.json: 1M x 128) checks through size-independent properties, plus
+oracle spot checks on a few queries (the oracle needs ~0.1-1 s per query at this size).
+
+Properties: ascending distances; exact re-rank distances of the returned indices are
+bit-identical to the oracle's AVX2 arithmetic; batch-split invariance (a query's row does
+not depend on which batch it travelled in); idempotence; monotone recall in
+pre_reorder_k; no point outside the result beats the k-th distance (sampled)."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from scann_rust_amd import hip, synth, trainer
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+N, DIM, S, K = 1_000_000, 128, 32, 10
+
+
+@pytest.fixture(scope="module")
+def big():
+    rows = synth.uniform_f32(N, DIM, 42)
+    stride = hip.compute_stride(DIM)
+    data = np.ascontiguousarray(rows)          # dim 128 == stride 128
+    assert stride == DIM
+    sample = rows[:: N // 32768]
+    cb = trainer.train_codebook(sample, S, 16, iters=6, seed=42, sample=1 << 30)
+    codes = hip.encode(cb, data, stride=stride)
+    q = synth.uniform_f32(64, DIM, 123)
+    return dict(rows=rows, data=data, stride=stride, cb=cb, codes=codes, q=q)
+
+
+def test_encode_full_size_matches_oracle_sample(big):
+    sel = np.arange(0, N, 9973)
+    assert np.array_equal(big["codes"][sel], orc.encode_many(big["cb"], big["rows"][sel]))
+
+
+def test_ah_lut16_1m_properties_and_oracle(big):
+    index = hip.txh_create(data=big["data"], n_rows=N, dim=DIM, stride=big["stride"], centers=None,
+                           leaf_offsets=None, leaf_ids=None, codebook=big["cb"], codes=big["codes"],
+                           use_residuals=False, partitions_to_search=1, pre_reorder_multiplier=1.0)
+    q = big["q"]
+    o = hip.default_opts()
+    o.pre_reorder_k = 400
+    idx, dist, cnt = index.search_batched(q, K, o)
+    assert np.all(cnt == K)
+    assert np.all(np.diff(dist, axis=1) >= 0)                       # ascending
+    for i in range(q.shape[0]):                                      # exact distances, bit for bit
+        for j in range(K):
+            assert np.float32(orc.squared_l2_avx2(q[i], big["rows"][idx[i, j]])) == dist[i, j]
+        assert len(set(idx[i].tolist())) == K
+    # batch-split invariance + idempotence
+    parts = [index.search_batched(q[a:a + 8], K, o) for a in range(0, 64, 8)]
+    assert np.array_equal(np.concatenate([p[0] for p in parts]), idx)
+    assert np.array_equal(np.concatenate([p[1] for p in parts]).view(np.uint32), dist.view(np.uint32))
+    idx2, dist2, _ = index.search_batched(q, K, o)
+    assert np.array_equal(idx2, idx) and np.array_equal(dist2.view(np.uint32), dist.view(np.uint32))
+    # oracle spot check: AsymmetricHasher::search_with_reordering on the same index
+    for i in range(3):
+        oi, od = orc.ah_search_with_reordering(big["cb"], big["codes"], big["data"], big["stride"],
+                                               q[i], K, 400)
+        H.assert_topk_equal_up_to_ties(idx[i], dist[i], oi, od, what="q%d" % i)
+    # approximate top-k without re-ordering (AsymmetricHasher::search)
+    o2 = hip.default_opts()
+    o2.exact_reorder = 0
+    aidx, adist, _ = index.search_batched(q[:2], K, o2)
+    for i in range(2):
+        oi, od = orc.ah_search(big["cb"], big["codes"], q[i], K)
+        H.assert_topk_equal_up_to_ties(aidx[i], adist[i], oi, od, what="approx q%d" % i)
+    # recall is monotone in pre_reorder_k (candidate sets are nested)
+    bf = hip.bf_create(big["data"], N, DIM, big["stride"], hip.SQUARED_L2)
+    ti, td, _ = bf.search_batched(q, K)
+    prev = -1.0
+    for m in (10, 100, 1000, 5000):
+        o.pre_reorder_k = m
+        gi, _, _ = index.search_batched(q, K, o)
+        rec = H.recall_at_k(gi, ti, K)
+        assert rec >= prev - 1e-9
+        prev = rec
+    assert prev > 0.9
+
+
+@pytest.mark.parametrize("measure", [hip.DOT_PRODUCT, hip.SQUARED_L2])
+def test_brute_force_1m_properties_and_oracle(big, measure):
+    index = hip.bf_create(big["data"], N, DIM, big["stride"], measure)
+    q = big["q"][:40]
+    idx, dist, cnt = index.search_batched(q, K)
+    assert np.all(cnt == K) and np.all(np.diff(dist, axis=1) >= 0)
+    # oracle on 2 full queries (TopK over all 1M rows)
+    for i in range(2):
+        oi, od = orc.bf_search(big["data"], N, DIM, big["stride"], measure, q[i], K)
+        H.assert_topk_equal_up_to_ties(idx[i], dist[i], oi, od, what="bf q%d" % i)
+    # returned distances are the oracle's arithmetic, and no sampled outsider beats the k-th
+    sel = np.arange(7, N, 4099)
+    for i in range(q.shape[0]):
+        want = orc.one_to_many(q[i], big["rows"][idx[i]].ravel(), DIM, K, measure)
+        assert np.array_equal(want.view(np.uint32), dist[i].view(np.uint32))
+        other = orc.one_to_many(q[i], big["rows"][sel].ravel(), DIM, sel.size, measure)
+        inside = np.isin(sel, idx[i])
+        assert np.all(other[~inside] >= dist[i, -1])
+    # batch-split invariance
+    a, b, _ = index.search_batched(q[:5], K)
+    assert np.array_equal(a, idx[:5]) and np.array_equal(b.view(np.uint32), dist[:5].view(np.uint32))
