@@ -184,62 +184,84 @@ def main():
     out_idx = torch.empty((Q, k), dtype=torch.int32, device=device)
     out_dist = torch.empty((Q, k), dtype=torch.float32, device=device)
     out_cnt = torch.empty((Q,), dtype=torch.int32, device=device)
+    # Sharded runs: a rank sends its m_local best candidates.  A random row-range shard holds
+    # Binomial(m, 1/world) of the global best m, so m_local = m/world + 6 sigma + 16 suffices;
+    # the merge kernel VERIFIES it (status Aborted -> the whole measurement is repeated with
+    # m_local = m, which is exact by construction).
+    m_local = m
     if world > 1:
-        keys = torch.empty((Q, m), dtype=torch.int64, device=device)
-        cidx = torch.empty((Q, m), dtype=torch.int32, device=device)
-        cex = torch.empty((Q, m), dtype=torch.float32, device=device)
-        ccnt = torch.empty((Q,), dtype=torch.int32, device=device)
-        g_keys = torch.empty((world, Q, m), dtype=torch.int64, device=device)
-        g_idx = torch.empty((world, Q, m), dtype=torch.int32, device=device)
-        g_ex = torch.empty((world, Q, m), dtype=torch.float32, device=device)
-        g_cnt = torch.empty((world, Q), dtype=torch.int32, device=device)
-    hip.check(L.scann_hip_index_reserve(index.h, Q, k, ctypes.byref(opts)))
+        m_local = min(m, int(m / world + 6.0 * (m / world) ** 0.5 + 16))
+    elapsed = kernel_ms = 0.0
+    kernel_name = ""
+    while True:
+        lopts = hip.default_opts()
+        lopts.pre_reorder_k = m_local if world > 1 else opts.pre_reorder_k
+        lopts.exact_reorder = opts.exact_reorder
+        if world > 1:
+            keys = torch.empty((Q, m_local), dtype=torch.int64, device=device)
+            cidx = torch.empty((Q, m_local), dtype=torch.int32, device=device)
+            cex = torch.empty((Q, m_local), dtype=torch.float32, device=device)
+            ccnt = torch.empty((Q,), dtype=torch.int32, device=device)
+            g_keys = torch.empty((world, Q, m_local), dtype=torch.int64, device=device)
+            g_idx = torch.empty((world, Q, m_local), dtype=torch.int32, device=device)
+            g_ex = torch.empty((world, Q, m_local), dtype=torch.float32, device=device)
+            g_cnt = torch.empty((world, Q), dtype=torch.int32, device=device)
+            mstatus = torch.zeros((1,), dtype=torch.int32, device=device)
+        hip.check(L.scann_hip_index_reserve(index.h, Q, k, ctypes.byref(lopts)))
 
-    def step(i):
-        qd = qdev[i % nbatches]
-        if world == 1:
-            hip.check(L.scann_hip_search_batched_device(index.h, dev_ptr(qd), Q, dim, k,
-                                                        ctypes.byref(opts), dev_ptr(out_idx),
-                                                        dev_ptr(out_dist), dev_ptr(out_cnt), sptr))
-        else:
-            hip.check(L.scann_hip_txh_search_local_device(index.h, dev_ptr(qd), Q, dim, k,
-                                                          ctypes.byref(opts), dev_ptr(keys),
-                                                          dev_ptr(cidx), dev_ptr(cex), dev_ptr(ccnt),
-                                                          sptr))
-            all_gather(g_keys, keys)
-            all_gather(g_idx, cidx)
-            all_gather(g_ex, cex)
-            all_gather(g_cnt, ccnt)
-            hip.check(L.scann_hip_txh_merge_device(hip.context(local_rank), world, Q, m, k,
-                                                   dev_ptr(g_keys), dev_ptr(g_idx), dev_ptr(g_ex),
-                                                   dev_ptr(g_cnt), dev_ptr(out_idx),
-                                                   dev_ptr(out_dist), dev_ptr(out_cnt), sptr))
+        def step(i):
+            qd = qdev[i % nbatches]
+            if world == 1:
+                hip.check(L.scann_hip_search_batched_device(index.h, dev_ptr(qd), Q, dim, k,
+                                                            ctypes.byref(lopts), dev_ptr(out_idx),
+                                                            dev_ptr(out_dist), dev_ptr(out_cnt), sptr))
+            else:
+                hip.check(L.scann_hip_txh_search_local_device(index.h, dev_ptr(qd), Q, dim, k,
+                                                              ctypes.byref(lopts), dev_ptr(keys),
+                                                              dev_ptr(cidx), dev_ptr(cex),
+                                                              dev_ptr(ccnt), sptr))
+                all_gather(g_keys, keys)
+                all_gather(g_idx, cidx)
+                all_gather(g_ex, cex)
+                all_gather(g_cnt, ccnt)
+                hip.check(L.scann_hip_txh_merge_device(hip.context(local_rank), world, Q, m_local, m,
+                                                       k, dev_ptr(g_keys), dev_ptr(g_idx),
+                                                       dev_ptr(g_ex), dev_ptr(g_cnt), dev_ptr(out_idx),
+                                                       dev_ptr(out_dist), dev_ptr(out_cnt),
+                                                       dev_ptr(mstatus), sptr))
 
-    # ---------------- warmup, then EXACTLY K timed steps -----------------------------------
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    hip.check(L.scann_hip_index_last_device_status(index.h, sptr))
-    index.enable_timing(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, kernel_name = index.last_kernel_ms()
-    index.enable_timing(False)
-    hip.check(L.scann_hip_index_last_device_status(index.h, sptr))
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # ---------------- warmup, then EXACTLY K timed steps -------------------------------
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        hip.check(L.scann_hip_index_last_device_status(index.h, sptr))
+        index.enable_timing(True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        kernel_ms, kernel_name = index.last_kernel_ms()
+        index.enable_timing(False)
+        hip.check(L.scann_hip_index_last_device_status(index.h, sptr))
+        if world > 1:
+            t = torch.tensor([elapsed, float(mstatus.item())], dtype=torch.float64,
+                             device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0].item())
+            if t[1].item() != 0 and m_local < m:
+                log("a shard's m_local=%d list was too short; repeating with m_local=m" % m_local)
+                m_local = m
+                continue
+            if t[1].item() != 0:
+                raise SystemExit("merge reported status %d" % int(t[1].item()))
+        break
     qps = Q * args.steps / elapsed
 
     # ---------------- recall10@10 (bin/ann_benchmark.rs:427-471 semantics) ------------------
@@ -338,6 +360,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name, "n": n, "dim": dim, "k": k, "batch": Q,
                        "pre_reorder_k": m if args.workload != "bf_dot" else None,
+                       "pre_reorder_k_per_rank": m_local if world > 1 else None,
                        "distribution": args.dist, "recall10@10": recall,
                        "oracle_check": checked,
                        "parallelism": "1 process/GPU, leaf(row-range)-sharded x%d + RCCL all_gather"

@@ -192,14 +192,18 @@ int scann_hip_txh_search_local_device(scann_hip_index *index, const float *d_que
                                       const scann_hip_search_opts *opts, uint64_t *d_keys,
                                       uint32_t *d_idx, float *d_exact, uint32_t *d_count,
                                       void *hip_stream);
-/* Merge stage on the gathered triples of `world` ranks ([world][nq][m] each):
+/* Merge stage on the gathered triples of `world` ranks ([world][nq][m_local] each):
  * stable sort by key -> truncate m -> stable sort by exact -> truncate k
- * (mod.rs:289-290, 360-361). */
-int scann_hip_txh_merge_device(scann_hip_ctx *ctx, uint32_t world, uint32_t nq, uint32_t m,
-                               uint32_t k, const uint64_t *d_keys, const uint32_t *d_idx,
-                               const float *d_exact, const uint32_t *d_count,
-                               uint32_t *d_out_idx, float *d_out_dist, uint32_t *d_out_count,
-                               void *hip_stream);
+ * (mod.rs:289-290, 360-361).  m_local is the per-rank pre_reorder_k of the local stage.
+ * m_local == m is exact by construction.  m_local < m (a random shard holds ~m/world of the
+ * global best m) is verified: if a truncated rank could have held more members,
+ * *d_status (caller-zeroed device word, may be NULL) is raised to Aborted and the caller
+ * re-runs with m_local = m. */
+int scann_hip_txh_merge_device(scann_hip_ctx *ctx, uint32_t world, uint32_t nq, uint32_t m_local,
+                               uint32_t m, uint32_t k, const uint64_t *d_keys,
+                               const uint32_t *d_idx, const float *d_exact,
+                               const uint32_t *d_count, uint32_t *d_out_idx, float *d_out_dist,
+                               uint32_t *d_out_count, uint32_t *d_status, void *hip_stream);
 /* Greedy size-balanced leaf->rank assignment used by the harness (not in the reference). */
 int scann_hip_assign_leaves(const uint32_t *leaf_sizes, uint32_t num_partitions,
                             uint32_t world, uint32_t *out_owner);

@@ -898,26 +898,29 @@ __global__ __launch_bounds__(kSelectThreads) void final_sort_kernel(
 // of world*m keys is needed.  Then the same stable exact sort as above.
 // =====================================================================================
 __global__ __launch_bounds__(kSelectThreads) void merge_kernel(
-    uint32_t world, uint32_t nq, uint32_t m, uint32_t k, uint32_t m2max,
+    uint32_t world, uint32_t nq, uint32_t m_local, uint32_t m, uint32_t k, uint32_t m2max,
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx,
     const float *__restrict__ exact, const uint32_t *__restrict__ count,
     uint32_t *__restrict__ out_idx, float *__restrict__ out_dist,
-    uint32_t *__restrict__ out_count) {
+    uint32_t *__restrict__ out_count, uint32_t *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];   // [m2max]
     uint32_t *s_src = reinterpret_cast<uint32_t *>(skeys + m2max);     // [m2max]
+    uint64_t *s_mth = reinterpret_cast<uint64_t *>(s_src + m2max);     // [1] key at rank nsel-1
     const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     uint32_t tot = 0;
     for (uint32_t g = 0; g < world; ++g) tot += count[(size_t)g * nq + q];
     const uint32_t nsel = min(m, tot);
+    if (tid == 0) *s_mth = SCANN_KEY_MAX;
+    __syncthreads();
     for (uint32_t g = 0; g < world; ++g) {
         const uint32_t cg = count[(size_t)g * nq + q];
-        const uint64_t *kl = keys + ((size_t)g * nq + q) * m;
+        const uint64_t *kl = keys + ((size_t)g * nq + q) * m_local;
         for (uint32_t i = tid; i < cg; i += nt) {
             const uint64_t key = kl[i];
             uint32_t rank = i;                      // smaller keys in its own list
             for (uint32_t g2 = 0; g2 < world; ++g2) {
                 if (g2 == g) continue;
-                const uint64_t *k2 = keys + ((size_t)g2 * nq + q) * m;
+                const uint64_t *k2 = keys + ((size_t)g2 * nq + q) * m_local;
                 uint32_t lo = 0, hi = count[(size_t)g2 * nq + q];
                 while (lo < hi) {
                     uint32_t mid = (lo + hi) >> 1;
@@ -925,10 +928,21 @@ __global__ __launch_bounds__(kSelectThreads) void merge_kernel(
                 }
                 rank += lo;
             }
-            if (rank < nsel) s_src[rank] = (uint32_t)(((size_t)g * nq + q) * m + i);
+            if (rank < nsel) s_src[rank] = (uint32_t)(((size_t)g * nq + q) * m_local + i);
+            if (rank + 1 == nsel) *s_mth = key;
         }
     }
     __syncthreads();
+    // Ranks may send fewer than m candidates (m_local < m, sized for a random shard's share
+    // of the global top-m).  A truncated list whose last key is still below the global m-th
+    // key could have held more members: report it, the caller re-runs with m_local = m.
+    if (status && m_local < m && tid < world) {
+        const uint32_t cg = count[(size_t)tid * nq + q];
+        if (cg == m_local && cg > 0) {
+            const uint64_t last = keys[((size_t)tid * nq + q) * m_local + cg - 1];
+            if (tot < m || last < *s_mth) atomicMax(status, (uint32_t)SCANN_HIP_ABORTED);
+        }
+    }
     uint32_t m2 = 1;
     while (m2 < nsel) m2 <<= 1;
     for (uint32_t i = tid; i < m2; i += nt)
@@ -1167,19 +1181,20 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
     return SCANN_HIP_OK;
 }
 
-int txh_launch_merge(uint32_t world, uint32_t nq, uint32_t m, uint32_t k, const uint64_t *d_keys,
-                     const uint32_t *d_idx, const float *d_exact, const uint32_t *d_count,
-                     uint32_t *d_out_idx, float *d_out_dist, uint32_t *d_out_count,
-                     hipStream_t st) {
+int txh_launch_merge(uint32_t world, uint32_t nq, uint32_t m_local, uint32_t m, uint32_t k,
+                     const uint64_t *d_keys, const uint32_t *d_idx, const float *d_exact,
+                     const uint32_t *d_count, uint32_t *d_out_idx, float *d_out_dist,
+                     uint32_t *d_out_count, uint32_t *d_status, hipStream_t st) {
     if (nq == 0) return SCANN_HIP_OK;
     if (world == 0 || world > 64) return fail(SCANN_HIP_INVALID_ARGUMENT, "world must be 1..64");
+    if (m_local == 0 || m_local > m) return fail(SCANN_HIP_INVALID_ARGUMENT, "need 0 < m_local <= m");
     if (m > kMaxPreReorderK)
         return fail(SCANN_HIP_UNIMPLEMENTED, "pre_reorder_k exceeds the LDS merge capacity");
     const uint32_t m2 = next_pow2_u32(std::max<uint32_t>(1u, m));
-    const size_t lds = (size_t)m2 * 12;
+    const size_t lds = (size_t)m2 * 12 + 16;
     SCANN_TRY(set_dyn_lds(merge_kernel, lds));
-    hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kSelectThreads), lds, st, world, nq, m, k, m2, d_keys,
-                       d_idx, d_exact, d_count, d_out_idx, d_out_dist, d_out_count);
+    hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kSelectThreads), lds, st, world, nq, m_local, m, k, m2,
+                       d_keys, d_idx, d_exact, d_count, d_out_idx, d_out_dist, d_out_count, d_status);
     LAUNCH_CHECK();
     return SCANN_HIP_OK;
 }

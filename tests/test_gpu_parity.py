@@ -364,12 +364,15 @@ def test_sharded_local_plus_merge_equals_single_index(world):
     out_idx = torch.zeros((nq, k), dtype=torch.int32, device=dev)
     out_dist = torch.zeros((nq, k), dtype=torch.float32, device=dev)
     out_cnt = torch.zeros((nq,), dtype=torch.int32, device=dev)
-    hip.check(Lh.scann_hip_txh_merge_device(hip.context(0), world, nq, m, k,
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    hip.check(Lh.scann_hip_txh_merge_device(hip.context(0), world, nq, m, m, k,
                                             C.c_void_p(g_keys.data_ptr()), C.c_void_p(g_idx.data_ptr()),
                                             C.c_void_p(g_ex.data_ptr()), C.c_void_p(g_cnt.data_ptr()),
                                             C.c_void_p(out_idx.data_ptr()), C.c_void_p(out_dist.data_ptr()),
-                                            C.c_void_p(out_cnt.data_ptr()), sptr))
+                                            C.c_void_p(out_cnt.data_ptr()), C.c_void_p(status.data_ptr()),
+                                            sptr))
     torch.cuda.synchronize()
+    assert int(status.item()) == 0
     gi = out_idx.cpu().numpy().view(np.uint32)
     gd = out_dist.cpu().numpy()
     gc = out_cnt.cpu().numpy()
