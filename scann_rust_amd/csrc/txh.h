@@ -6,7 +6,7 @@ namespace scann {
 
 // Tunables of the scan decomposition (see DESIGN.md "Leaf scan").
 constexpr uint32_t kScanThreads = 256;
-constexpr uint32_t kScanPPT = 4;                          // points per thread per chunk
+constexpr uint32_t kScanPPT = 2;                          // points per thread per chunk
 constexpr uint32_t kScanTP = kScanThreads * kScanPPT;     // points per tile chunk
 constexpr uint32_t kScanQuadsPerTile = 32;                // query quads per tile
 constexpr uint32_t kSortCap = 16384;                      // u64 keys sorted in LDS (select)

@@ -444,7 +444,7 @@ __device__ __forceinline__ void scan_quad_compute(const float4 *lut_base,
     }
 }
 
-static_assert(kScanPPT == 4, "adc_scan_kernel's nsub switch assumes 4 points per thread");
+static_assert(kScanPPT <= 4, "adc_scan_kernel's nsub switch handles up to 4 points per thread");
 constexpr uint32_t kScanStage = 128;   // LDS-staged survivors per (quad, query); <= kScanThreads
 static_assert(kScanStage <= kScanThreads, "the flush copies one survivor per thread");
 
@@ -459,7 +459,7 @@ struct ScanArgs {
 };
 
 template <int NW>
-__global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 4 : 2)) void adc_scan_kernel(TxhIndexDev ix, ScanArgs a) {
+__global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 6 : 3)) void adc_scan_kernel(TxhIndexDev ix, ScanArgs a) {
     constexpr int S = NW * 8;
     constexpr int LUT4 = S * 16;                                    // float4 per quad
     constexpr int STG = (LUT4 + kScanThreads - 1) / kScanThreads;   // staged float4 / thread
@@ -591,16 +591,12 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 4 : 2)) void adc_scan_kern
                 if (buf == 0) {
                     switch (nsub) {
                         case 1: scan_quad_compute<NW, 1, 0>(lut_s, wlo, whi, acc); break;
-                        case 2: scan_quad_compute<NW, 2, 0>(lut_s, wlo, whi, acc); break;
-                        case 3: scan_quad_compute<NW, 3, 0>(lut_s, wlo, whi, acc); break;
-                        default: scan_quad_compute<NW, 4, 0>(lut_s, wlo, whi, acc); break;
+                        default: scan_quad_compute<NW, (kScanPPT < 2 ? 1 : 2), 0>(lut_s, wlo, whi, acc); break;
                     }
                 } else {
                     switch (nsub) {
                         case 1: scan_quad_compute<NW, 1, 1>(lut_s, wlo, whi, acc); break;
-                        case 2: scan_quad_compute<NW, 2, 1>(lut_s, wlo, whi, acc); break;
-                        case 3: scan_quad_compute<NW, 3, 1>(lut_s, wlo, whi, acc); break;
-                        default: scan_quad_compute<NW, 4, 1>(lut_s, wlo, whi, acc); break;
+                        default: scan_quad_compute<NW, (kScanPPT < 2 ? 1 : 2), 1>(lut_s, wlo, whi, acc); break;
                     }
                 }
                 // threshold filter: survivors go to the LDS stage of this quad
