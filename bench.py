@@ -144,12 +144,12 @@ def main():
     else:
         # codebook: identical on every rank (trained on a deterministic global sample)
         if args.dist == "uniform":
-            sel = (synth.splitmix64(0xC0DE, 0, 32768) % np.uint64(n)).astype(np.int64)
+            sel = (synth.splitmix64(0xC0DE, 0, 65536) % np.uint64(n)).astype(np.int64)
             sample = synth.uniform_rows(sel, dim, 42)
         else:
-            sample = rows[:: max(1, n // 32768)]
+            sample = rows[:: max(1, n // 65536)]
         if args.workload == "ah":
-            codebook = trainer.train_codebook(sample, S, K, iters=8, seed=42, sample=1 << 30)
+            codebook = trainer.train_codebook(sample, S, K, iters=25, seed=42, sample=1 << 30)
             codes = hip.encode(codebook, data, stride=stride, device=local_rank)
             if world == 1:
                 index = hip.txh_create(data=data, n_rows=n, dim=dim, stride=stride, centers=None,

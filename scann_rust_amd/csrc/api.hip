@@ -452,6 +452,7 @@ static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallP
     w->cap = p.cap;
     w->exact_reorder = p.exact_reorder;
     w->no_threshold = p.no_threshold;
+    w->need_sorted_cands = 0;
     w->queries = s.queries.as<float>();
     w->cdist = s.cdist.as<float>();
     w->tokens = s.tokens.as<uint32_t>();
@@ -510,6 +511,7 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
         }
         TxhWork w;
         SCANN_TRY(ensure_txh_workspace(ix, nq, p, true, q_stride, true, &w));
+        w.need_sorted_cands = (opts && (opts->cand_idx || opts->cand_dist)) ? 1 : 0;
         SCANN_HIP_CHECK(hipMemcpyAsync(ix->ws.queries.p, queries, (size_t)nq * q_stride * 4,
                                        hipMemcpyHostToDevice, ix->stream));
         ix->next_events();

@@ -67,6 +67,7 @@ struct TxhWork {
     uint32_t nq, q_stride, P, m, k, cap;
     int exact_reorder;
     int no_threshold;          // retry mode: keep every scanned point as a candidate
+    int need_sorted_cands;     // the caller reads cand_* (parity outputs): keep them sorted
     const float *queries;      // device
     float *cdist;              // [nq][L]
     uint32_t *tokens;          // [nq][P]

@@ -663,6 +663,7 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 6 : 3)) void adc_scan_kern
 struct SelectArgs {
     uint32_t P, m, k, cap;
     int exact_reorder, local_only;
+    int unsorted;   // candidates may leave in any order (final stage orders by 96-bit keys)
     const float *queries;
     uint32_t q_stride;
     const uint32_t *tokens, *vbase;
@@ -710,6 +711,53 @@ __device__ static uint32_t block_compact_le(uint64_t *list, uint32_t cnt, uint64
         __syncthreads();
     }
     return *s_base;
+}
+
+// Key of rank r (0-based) among the n unique u64 keys in LDS, by MSB-first radix select:
+// 8 passes of (256-bin histogram of the active keys -> bin holding rank r).  hist: LDS
+// [258].  Every thread of the block must call; returns the same value in every thread.
+__device__ static uint64_t block_radix_select(const uint64_t *keys, uint32_t n, uint32_t r,
+                                              uint32_t *hist) {
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    uint64_t prefix = 0, mask = 0;
+    uint32_t rem = r;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        for (uint32_t i = tid; i < 256; i += nt) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += nt) {
+            const uint64_t kx = keys[i];
+            if ((kx & mask) == prefix) atomicAdd(&hist[(uint32_t)(kx >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {   // one wave: lane l owns bins 4l .. 4l+3
+            const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2],
+                           c3 = hist[4 * tid + 3];
+            const uint32_t sum = c0 + c1 + c2 + c3;
+            uint32_t incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d, 64);
+                if ((int)tid >= d) incl += o;
+            }
+            const uint32_t excl = incl - sum;
+            if (rem >= excl && rem < incl) {
+                uint32_t b = 0, before = excl;
+                if (rem >= before + c0) { before += c0; b = 1;
+                    if (rem >= before + c1) { before += c1; b = 2;
+                        if (rem >= before + c2) { before += c2; b = 3; } } }
+                hist[256] = 4 * tid + b;
+                hist[257] = rem - before;
+            }
+        }
+        __syncthreads();
+        const uint32_t bin = hist[256];
+        rem = hist[257];
+        prefix |= (uint64_t)bin << shift;
+        mask |= 0xFFull << shift;
+        __syncthreads();
+    }
+    return prefix;
 }
 
 __device__ static void select_fail(const SelectArgs &a, uint32_t q, uint32_t status) {
@@ -762,15 +810,65 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
         return;
     }
 
+    const uint32_t nsel = min(m, cnt);   // truncate(pre_reorder_k)  mod.rs:290
+    const uint32_t *vb = a.vbase + (size_t)q * (a.P + 1);
+    auto decode = [&](uint64_t key, uint32_t i) {
+        // merge key -> (rank, position in leaf) -> CSR row -> datapoint index
+        const uint32_t vpos = (uint32_t)key;
+        uint32_t lo = 0, hi = a.P;
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (vb[mid] <= vpos) lo = mid; else hi = mid;
+        }
+        const uint32_t leaf = a.tokens[(size_t)q * a.P + lo];
+        const uint32_t csr = ix.leaf_off[leaf] + (vpos - vb[lo]);
+        const uint32_t idx = ix.leaf_ids ? ix.leaf_ids[csr] : csr;
+        a.cand_row[(size_t)q * m + i] = ix.rows_csr ? csr : idx;
+        a.cand_key[(size_t)q * m + i] = key;
+        a.cand_idx[(size_t)q * m + i] = idx;
+        a.cand_dist[(size_t)q * m + i] = ordered_to_f32((uint32_t)(key >> 32));
+    };
+
+    if (a.unsorted) {
+        // Selection without a sort: radix-select the m-th smallest key, keep keys <= it.
+        // The final stage orders by (exact, merge key), which equals (exact, approx rank).
+        for (uint32_t i = tid; i < cnt; i += nt) skeys[i] = list[i];
+        __syncthreads();
+        uint32_t *hist = s_basep + 4;
+        const uint64_t T = cnt > m ? block_radix_select(skeys, cnt, m - 1, hist) : SCANN_KEY_MAX;
+        const uint32_t wave = tid >> 6, nwv = nt >> 6;
+        uint32_t base_slot = 0;
+        for (uint32_t b = 0; b < cnt; b += nt) {
+            const uint32_t i = b + tid;
+            uint64_t key = 0;
+            bool keep = false;
+            if (i < cnt) {
+                key = skeys[i];
+                keep = key <= T;
+            }
+            uint32_t wtot;
+            const uint32_t wpre = wave_prefix_count(keep, &wtot);
+            if ((tid & 63u) == 0) s_wave[wave] = wtot;
+            __syncthreads();
+            uint32_t off = base_slot, tot = 0;
+            for (uint32_t w2 = 0; w2 < nwv; ++w2) {
+                if (w2 < wave) off += s_wave[w2];
+                tot += s_wave[w2];
+            }
+            if (keep) decode(key, off + wpre);
+            base_slot += tot;
+            __syncthreads();
+        }
+        if (tid == 0) a.cand_count[q] = nsel;
+        return;
+    }
+
     uint32_t n2 = 1;
     while (n2 < cnt) n2 <<= 1;
     for (uint32_t i = tid; i < n2; i += nt) skeys[i] = (i < cnt) ? list[i] : SCANN_KEY_MAX;
     __syncthreads();
     bitonic_sort_lds(skeys, n2);
-    const uint32_t nsel = min(m, cnt);   // truncate(pre_reorder_k)  mod.rs:290
 
-    // decode merge key -> (rank, position in leaf) -> CSR row -> datapoint index
-    const uint32_t *vb = a.vbase + (size_t)q * (a.P + 1);
     for (uint32_t i = tid; i < nsel; i += nt) {
         const uint64_t key = skeys[i];
         const uint32_t vpos = (uint32_t)key;
@@ -883,6 +981,86 @@ __global__ __launch_bounds__(kSelectThreads) void final_sort_kernel(
         }
         out_idx[(size_t)q * k + i] = oi;
         out_dist[(size_t)q * k + i] = od;
+    }
+    if (tid == 0) out_count[q] = nout;
+}
+
+// K9b: the same ordering without a sort, for small k and unsorted candidates: k rounds of a
+// block-wide arg-min over (ordered(exact), merge key) -- the merge key is monotone in the
+// approximate rank, so this is exactly the stable sort's order.
+constexpr uint32_t kTopkMaxK = 64;
+__global__ __launch_bounds__(kSelectThreads) void final_topk_kernel(
+    uint32_t m, uint32_t k, const uint32_t *__restrict__ cand_count,
+    const uint32_t *__restrict__ cand_idx, const uint64_t *__restrict__ cand_key,
+    const float *__restrict__ cand_exact, uint32_t *__restrict__ out_idx,
+    float *__restrict__ out_dist, uint32_t *__restrict__ out_count) {
+    constexpr int E = kMaxPreReorderK / kSelectThreads;   // candidates per thread
+    __shared__ uint32_t s_eb[kSelectThreads / 64];
+    __shared__ uint64_t s_kk[kSelectThreads / 64];
+    __shared__ uint32_t s_sl[kSelectThreads / 64];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t nsel = cand_count[q];
+    uint32_t eb[E];
+    uint64_t kk[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t slot = e * kSelectThreads + tid;
+        const bool alive = slot < nsel;
+        eb[e] = alive ? f32_to_ordered(cand_exact[(size_t)q * m + slot]) : 0xFFFFFFFFu;
+        kk[e] = alive ? cand_key[(size_t)q * m + slot] : SCANN_KEY_MAX;
+    }
+    const uint32_t nout = min(k, nsel);
+    for (uint32_t r = 0; r < nout; ++r) {
+        uint32_t b_eb = 0xFFFFFFFFu, b_sl = 0;
+        uint64_t b_kk = SCANN_KEY_MAX;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (eb[e] < b_eb || (eb[e] == b_eb && kk[e] < b_kk)) {
+                b_eb = eb[e];
+                b_kk = kk[e];
+                b_sl = e * kSelectThreads + tid;
+            }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o_eb = __shfl_xor(b_eb, d, 64), o_sl = __shfl_xor(b_sl, d, 64);
+            const uint64_t o_kk = __shfl_xor(b_kk, d, 64);
+            if (o_eb < b_eb || (o_eb == b_eb && o_kk < b_kk)) {
+                b_eb = o_eb;
+                b_kk = o_kk;
+                b_sl = o_sl;
+            }
+        }
+        if (lane == 0) {
+            s_eb[wave] = b_eb;
+            s_kk[wave] = b_kk;
+            s_sl[wave] = b_sl;
+        }
+        __syncthreads();
+        uint32_t g_eb = s_eb[0], g_sl = s_sl[0];
+        uint64_t g_kk = s_kk[0];
+#pragma unroll
+        for (int w2 = 1; w2 < (int)(kSelectThreads / 64); ++w2)
+            if (s_eb[w2] < g_eb || (s_eb[w2] == g_eb && s_kk[w2] < g_kk)) {
+                g_eb = s_eb[w2];
+                g_kk = s_kk[w2];
+                g_sl = s_sl[w2];
+            }
+        if ((g_sl & (kSelectThreads - 1)) == tid) {
+            const uint32_t we = g_sl / kSelectThreads;
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if ((uint32_t)e == we) {
+                    eb[e] = 0xFFFFFFFFu;
+                    kk[e] = SCANN_KEY_MAX;
+                }
+            out_idx[(size_t)q * k + r] = cand_idx[(size_t)q * m + g_sl];
+            out_dist[(size_t)q * k + r] = ordered_to_f32(g_eb);
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = nout + tid; i < k; i += blockDim.x) {
+        out_idx[(size_t)q * k + i] = kInvalid;
+        out_dist[(size_t)q * k + i] = __builtin_inff();
     }
     if (tid == 0) out_count[q] = nout;
 }
@@ -1152,13 +1330,15 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
     SelectArgs s;
     s.P = w.P; s.m = w.m; s.k = w.k; s.cap = w.cap;
     s.exact_reorder = w.exact_reorder; s.local_only = local_only ? 1 : 0;
+    const bool unsorted = w.exact_reorder && !local_only && !w.need_sorted_cands && w.k <= kTopkMaxK;
+    s.unsorted = unsorted ? 1 : 0;
     s.queries = w.queries; s.q_stride = w.q_stride; s.tokens = w.tokens; s.vbase = w.vbase;
     s.thr = w.thr; s.cand_row = w.cand_row;
     s.cand_cnt = w.cand_cnt; s.cand = w.cand; s.counters = w.counters; s.cand_key = w.cand_key;
     s.cand_idx = w.cand_idx; s.cand_dist = w.cand_dist; s.cand_exact = w.cand_exact;
     s.cand_count = w.cand_count; s.out_idx = w.out_idx; s.out_dist = w.out_dist;
     s.out_count = w.out_count;
-    const size_t lds_sel = (size_t)kSortCap * 8 + (size_t)(kSelectThreads / 64 + 4) * 4;
+    const size_t lds_sel = (size_t)kSortCap * 8 + (size_t)(kSelectThreads / 64 + 4 + 260) * 4;
     SCANN_TRY(set_dyn_lds(select_rerank_kernel, lds_sel));
     hipLaunchKernelGGL(select_rerank_kernel, dim3(w.nq), dim3(kSelectThreads), lds_sel, st, ix, s);
     LAUNCH_CHECK();
@@ -1169,6 +1349,13 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
                        w.queries, w.q_stride, w.m, w.cand_row, w.cand_count, w.cand_exact);
     LAUNCH_CHECK();
     if (local_only) return SCANN_HIP_OK;
+    if (unsorted) {
+        hipLaunchKernelGGL(final_topk_kernel, dim3(w.nq), dim3(kSelectThreads), 0, st, w.m, w.k,
+                           w.cand_count, w.cand_idx, w.cand_key, w.cand_exact, w.out_idx, w.out_dist,
+                           w.out_count);
+        LAUNCH_CHECK();
+        return SCANN_HIP_OK;
+    }
     const size_t lds_fs = (size_t)next_pow2_u32(std::max(1u, w.m)) * 8;
     SCANN_TRY(set_dyn_lds(final_sort_kernel, lds_fs));
     hipLaunchKernelGGL(final_sort_kernel, dim3(w.nq), dim3(kSelectThreads), lds_fs, st, w.m, w.k,

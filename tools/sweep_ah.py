@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--ms", default="10,100,1000,2048,4096,6000,8192")
     ap.add_argument("--dist", default="uniform")
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--pq-iters", type=int, default=8)
+    ap.add_argument("--pq-sample", type=int, default=32768)
     a = ap.parse_args()
     import torch
     from scann_rust_amd import hip, synth, trainer
@@ -40,7 +42,8 @@ def main():
     data[:, :dim] = rows
     print("data %.1fs" % (time.time() - t0), flush=True)
     t0 = time.time()
-    cb = trainer.train_codebook(rows[:: max(1, n // 32768)], S, 16, iters=8, seed=42, sample=1 << 30)
+    cb = trainer.train_codebook(rows[:: max(1, n // a.pq_sample)], S, 16, iters=a.pq_iters, seed=42,
+                                sample=1 << 30)
     codes = hip.encode(cb, data, stride=stride)
     index = hip.txh_create(data=data, n_rows=n, dim=dim, stride=stride, centers=None,
                            leaf_offsets=None, leaf_ids=None, codebook=cb, codes=codes,
