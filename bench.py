@@ -69,6 +69,98 @@ def dev_ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def build_txh(args, torch, dist, hip, synth, trainer, device, local_rank, rank, world, stride):
+    """Tree-X-Hybrid index on a clustered synthetic set (mixture of 1000 Gaussians, SURVEY.md
+    8d).  Harness plumbing: data and k-means run in torch on the GPU; rank 0 trains and
+    broadcasts so every rank holds the identical index, then keeps only its leaves."""
+    from scann_rust_amd import sharding
+    n, dim, S, L, Q, k = args.n, args.dim, args.subspaces, args.leaves, args.batch, args.k
+    g = torch.Generator(device=device)
+    g.manual_seed(7)
+    cen = torch.rand((1000, dim), generator=g, device=device)
+    sig = 0.1 * (1.0 / 6.0) ** 0.5
+    X = cen[torch.randint(0, 1000, (n,), generator=g, device=device)] + \
+        sig * torch.randn((n, dim), generator=g, device=device)
+    nq = max(Q * 4, args.eval_queries)
+    Xq = cen[torch.randint(0, 1000, (nq,), generator=g, device=device)] + \
+        sig * torch.randn((nq, dim), generator=g, device=device)
+    C = torch.empty((L, dim), device=device)
+    assign = torch.empty((n,), dtype=torch.int64, device=device)
+    cb_t = torch.empty((S, 16, dim // S), device=device)
+    if rank == 0:
+        Cn = X[torch.randperm(n, generator=g, device=device)[:L]].clone()
+        for it in range(9):
+            cn = (Cn * Cn).sum(1)
+            a = torch.cat([(cn[None, :] - 2.0 * (X[r0:r0 + 262144] @ Cn.T)).argmin(1)
+                           for r0 in range(0, n, 262144)])
+            if it == 8:
+                break
+            sums = torch.zeros_like(Cn).index_add_(0, a, X)
+            cnt = torch.bincount(a, minlength=L)
+            newC = sums / cnt.clamp(min=1).to(X.dtype)[:, None]
+            newC[cnt == 0] = Cn[cnt == 0]
+            Cn = newC
+        C.copy_(Cn)
+        assign.copy_(a)
+        res = X - C[assign]
+        sample = res[torch.randperm(n, generator=g, device=device)[:65536]].cpu().numpy()
+        cb_t.copy_(torch.from_numpy(trainer.train_codebook(sample, S, 16, iters=15, seed=42,
+                                                           sample=1 << 30)).to(device))
+    if world > 1:
+        if args.backend == "nccl":
+            for t in (C, assign, cb_t):
+                dist.broadcast(t, 0)
+        else:
+            for t in (C, assign, cb_t):
+                h = t.cpu()
+                dist.broadcast(h, 0)
+                t.copy_(h.to(device))
+    order = torch.argsort(assign, stable=True)
+    counts = torch.bincount(assign, minlength=L).cpu().numpy()
+    leaf_off = np.zeros(L + 1, np.uint32)
+    leaf_off[1:] = np.cumsum(counts)
+    sizes = counts.astype(np.uint32)
+    owner = sharding.assign_leaves(sizes, world)
+    mine = owner == rank
+    centers = C.cpu().numpy().astype(np.float32)
+    codebook = cb_t.cpu().numpy().astype(np.float32)
+    order_np = order.cpu().numpy()
+    sel = np.concatenate([order_np[leaf_off[l]:leaf_off[l + 1]] for l in range(L) if mine[l]]
+                         or [np.zeros(0, np.int64)])
+    local_sizes = np.where(mine, sizes, 0).astype(np.uint32)
+    loc_off = np.zeros(L + 1, np.uint32)
+    loc_off[1:] = np.cumsum(local_sizes)
+    leaf_of_row = np.repeat(np.arange(L, dtype=np.uint32), local_sizes)
+    rows_csr = np.zeros((sel.size, stride), np.float32)
+    rows_csr[:, :dim] = X[torch.from_numpy(sel).to(device)].cpu().numpy()
+    codes = hip.encode(codebook, rows_csr, stride=stride, centers=centers, leaf_of_row=leaf_of_row,
+                       device=local_rank)
+    index = hip.txh_create(data=rows_csr, n_rows=sel.size, dim=dim, stride=stride, centers=centers,
+                           leaf_offsets=loc_off, leaf_ids=sel.astype(np.uint32),
+                           leaf_sizes_global=sizes, codebook=codebook, codes=codes, use_residuals=True,
+                           partitions_to_search=args.partitions_to_search,
+                           pre_reorder_multiplier=float(args.pre_reorder_k) / k, data_is_csr_order=True,
+                           device=local_rank)
+    queries = Xq.cpu().numpy().astype(np.float32)
+    tok, _, _ = hip.txh_partition(index, np.ascontiguousarray(queries[:Q]), args.partitions_to_search)
+    scanned_local = local_sizes[tok.astype(np.int64)].sum(1).mean()
+    state = dict(index=index, queries=queries, n_local=int(sel.size), data=rows_csr, codebook=codebook,
+                 codes=codes,
+                 scan_bytes_per_query=int(scanned_local * (S // 2) + args.partitions_to_search * S * 64))
+    full = None
+    if world == 1:
+        full = np.zeros((n, stride), np.float32)
+        full[:, :dim] = X.cpu().numpy()
+    state["full_data"] = full
+
+    def oracle_index(orc, m, kk):
+        return orc.TxhIndex(full, stride, dim, centers, leaf_off, order_np.astype(np.uint32), codebook,
+                            codes, use_residuals=True, partitions_to_search=args.partitions_to_search,
+                            pre_reorder_multiplier=float(m) / kk)
+    state["oracle_index"] = oracle_index
+    return state
+
+
 def main():
     args = parse()
     import torch
@@ -111,7 +203,14 @@ def main():
     t0 = time.time()
     lo, hi = (n * rank) // world, (n * (rank + 1)) // world
     n_loc = hi - lo
-    if args.dist == "uniform":
+    txh_state = None
+    if args.workload == "txh":
+        txh_state = build_txh(args, torch, dist, hip, synth, trainer, device, local_rank, rank, world,
+                              stride)
+        rows = None
+        queries_all = txh_state["queries"]
+        n_loc = txh_state["n_local"]
+    elif args.dist == "uniform":
         rows = synth.uniform_f32(n_loc, dim, 42, row_offset=lo)
         queries_all = synth.uniform_f32(max(Q * 4, args.eval_queries), dim, 123)
     else:
@@ -120,8 +219,11 @@ def main():
         rows, _ = synth.clustered_f32(n, dim, 7, n_clusters=1000)
         qsrc, _ = synth.clustered_f32(max(Q * 4, args.eval_queries), dim, 8, n_clusters=1000)
         queries_all = qsrc
-    data = np.zeros((n_loc, stride), np.float32)
-    data[:, :dim] = rows
+    if rows is not None:
+        data = np.zeros((n_loc, stride), np.float32)
+        data[:, :dim] = rows
+    else:
+        data = txh_state["data"]
     log("data %.1fs (n_local=%d)" % (time.time() - t0, n_loc))
 
     workload_name = {"ah": "AsymmetricHasher LUT16 S=%d K=16 + exact re-rank" % S,
@@ -135,7 +237,14 @@ def main():
     flops_per_query = None
     codebook = codes = None
     t0 = time.time()
-    if args.workload == "bf_dot":
+    if args.workload == "txh":
+        index = txh_state["index"]
+        codebook, codes = txh_state["codebook"], txh_state["codes"]
+        algo_bytes_per_query = txh_state["scan_bytes_per_query"]
+        opts.partitions_to_search = args.partitions_to_search
+        opts.pre_reorder_k = m
+        opts.exact_reorder = 1
+    elif args.workload == "bf_dot":
         if world > 1:
             raise SystemExit("bf_dot is single-GPU only in this round")
         index = hip.bf_create(data, n, dim, stride, hip.DOT_PRODUCT)
@@ -171,8 +280,6 @@ def main():
                     data_is_csr_order=True, device=local_rank)
             # 16 002 128 B at N = 1; per launch a rank scans its n_loc points
             algo_bytes_per_query = n_loc * (S // 2) + S * 16 * 4 + k * 8
-        else:
-            raise SystemExit("txh workload is wired in tools/sweep.py; bench default is `ah`")
         opts.pre_reorder_k = m
         opts.exact_reorder = 1
     log("index %.1fs" % (time.time() - t0))
@@ -189,7 +296,7 @@ def main():
     # the merge kernel VERIFIES it (status Aborted -> the whole measurement is repeated with
     # m_local = m, which is exact by construction).
     m_local = m
-    if world > 1:
+    if world > 1 and args.workload == "ah":
         m_local = min(m, int(m / world + 6.0 * (m / world) ** 0.5 + 16))
     elapsed = kernel_ms = 0.0
     kernel_name = ""
@@ -197,6 +304,7 @@ def main():
         lopts = hip.default_opts()
         lopts.pre_reorder_k = m_local if world > 1 else opts.pre_reorder_k
         lopts.exact_reorder = opts.exact_reorder
+        lopts.partitions_to_search = opts.partitions_to_search
         if world > 1:
             keys = torch.empty((Q, m_local), dtype=torch.int64, device=device)
             cidx = torch.empty((Q, m_local), dtype=torch.int32, device=device)
@@ -271,7 +379,8 @@ def main():
         ne = min(args.eval_queries, queries_all.shape[0])
         qe = np.ascontiguousarray(queries_all[:ne])
         gi, gd, gc = index.search_batched(qe, k, opts)
-        bf = hip.bf_create(data, n, dim, stride, hip.SQUARED_L2, device=local_rank)
+        bf = hip.bf_create(txh_state["full_data"] if txh_state else data, n, dim, stride,
+                           hip.SQUARED_L2, device=local_rank)
         ti, td, tc = bf.search_batched(qe, k)
         hits = sum(len(set(gi[i].tolist()) & set(ti[i].tolist())) for i in range(ne))
         recall = hits / float(ne * k)
@@ -302,6 +411,8 @@ def main():
         for i in range(nchk):
             if args.workload == "bf_dot":
                 oi, od = orc.bf_search(data, n, dim, stride, orc.DOT_PRODUCT, qe[i], k)
+            elif args.workload == "txh":
+                oi, od = orc.txh_search(txh_state["oracle_index"](orc, m, k), qe[i], k)
             else:
                 oi, od = orc.ah_search_with_reordering(codebook, codes, data, stride, qe[i], k, m)
             ok = ok and np.array_equal(gd[i].view(np.uint32), od.view(np.uint32)) \
@@ -320,6 +431,8 @@ def main():
             t1 = time.perf_counter()
             if args.workload == "bf_dot":
                 orc.bf_search_batched(data, n, dim, stride, orc.DOT_PRODUCT, qb, k, threads)
+            elif args.workload == "txh":
+                orc.txh_search_batched(txh_state["oracle_index"](orc, m, k), qb, k, threads)
             else:
                 orc.ah_search_batched(codebook, codes, data, stride, qb, k, m, True, threads)
             return time.perf_counter() - t1
@@ -344,8 +457,10 @@ def main():
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kernel_name,
                     "kernel_ms": kernel_ms,
-                    "algorithmic": "%d B per query (N_local*S/2 codes + S*16*4 LUT + k*8 out) x %d "
-                                   "queries per launch (rank 0)" % (algo_bytes_per_query, Q)}
+                    "algorithmic": ("%d B per query (scanned codes + LUTs of the selected leaves) x %d "
+                                    "queries per launch (rank 0)" if args.workload == "txh" else
+                                    "%d B per query (N_local*S/2 codes + S*16*4 LUT + k*8 out) x %d "
+                                    "queries per launch (rank 0)") % (algo_bytes_per_query, Q)}
         tr = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr):
             try:
@@ -361,7 +476,10 @@ def main():
             "config": {"workload": workload_name, "n": n, "dim": dim, "k": k, "batch": Q,
                        "pre_reorder_k": m if args.workload != "bf_dot" else None,
                        "pre_reorder_k_per_rank": m_local if world > 1 else None,
-                       "distribution": args.dist, "recall10@10": recall,
+                       "distribution": args.dist if args.workload != "txh" else "clustered (1000 Gaussians)",
+                       "leaves": args.leaves if args.workload == "txh" else None,
+                       "partitions_to_search": args.partitions_to_search if args.workload == "txh" else None,
+                       "recall10@10": recall,
                        "oracle_check": checked,
                        "parallelism": "1 process/GPU, leaf(row-range)-sharded x%d + RCCL all_gather"
                                       % world if world > 1 else "single GPU"},
