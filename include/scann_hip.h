@@ -242,6 +242,14 @@ int scann_hip_encode(scann_hip_ctx *ctx, const float *codebook, uint32_t num_sub
 int scann_hip_bf_distances(scann_hip_index *index, const float *queries, uint32_t nq,
                            uint32_t q_stride, float *out);
 
+/* Index build helper: for every row of a brute-force index, the nearest of
+ * `num_centers` centres [num_centers][dim] under the partitioner's arithmetic --
+ * TreePartitioner::partition(x, 1) as used by TreeXHybridSearcher::compute_residuals
+ * (tree_x_hybrid/mod.rs:212-237) and KMeans::assign_clusters (trees/kmeans.rs:352-379):
+ * sequential scalar SquaredL2, lowest centre index on ties.  out_dist may be NULL. */
+int scann_hip_bf_assign_nearest(scann_hip_index *index, const float *centers, uint32_t num_centers,
+                                uint32_t *out_assign, float *out_dist);
+
 /* ---- introspection ------------------------------------------------------------- */
 uint64_t scann_hip_index_size(const scann_hip_index *index);          /* Searcher::dataset_size */
 uint32_t scann_hip_index_dimensionality(const scann_hip_index *index);/* Searcher::dimensionality */

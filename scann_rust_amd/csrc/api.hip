@@ -851,4 +851,14 @@ int scann_hip_bf_distances(scann_hip_index *ix, const float *queries, uint32_t n
     return bf_distances_host(ix->bf, ix->bfw, queries, nq, q_stride, out, ix->stream);
 }
 
+int scann_hip_bf_assign_nearest(scann_hip_index *ix, const float *centers, uint32_t num_centers,
+                                uint32_t *out_assign, float *out_dist) {
+    if (!ix || ix->kind != KIND_BF) return fail(SCANN_HIP_INVALID_ARGUMENT, "not a brute-force index");
+    if (!centers || num_centers == 0 || !out_assign)
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "null/empty centres or output");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    SCANN_TRY(set_device(ix->ctx));
+    return bf_assign_nearest_host(ix->bf, centers, num_centers, out_assign, out_dist, ix->stream);
+}
+
 }  // extern "C"

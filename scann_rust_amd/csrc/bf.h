@@ -33,4 +33,9 @@ int bf_search_device(const BfIndexDev &ix, BfWorkspace &w, const float *d_querie
 int bf_distances_host(const BfIndexDev &ix, BfWorkspace &w, const float *queries, uint32_t nq,
                       uint32_t q_stride, float *out, hipStream_t stream);
 
+// Nearest of k centres for every row of the index (sequential-scalar SquaredL2, lowest index on
+// ties): TreePartitioner::partition(x, 1) / KMeans::assign_clusters.
+int bf_assign_nearest_host(const BfIndexDev &ix, const float *centers, uint32_t k, uint32_t *out_idx,
+                           float *out_dist, hipStream_t stream);
+
 }  // namespace scann

@@ -264,6 +264,85 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_dot_kernel(BfIndexDev ix, BfPa
 }
 
 // =====================================================================================
+// Nearest centre of every row (k-means assignment / residual partitioning).
+// TreePartitioner::partition(x, 1) (partitioning/tree_partitioner.rs:175-229) as called by
+// TreeXHybridSearcher::compute_residuals (tree_x_hybrid/mod.rs:212-237) and, with the same
+// arithmetic, KMeans::assign_clusters (trees/kmeans.rs:352-379): strictly sequential scalar
+// sum of (x_j - c_j)^2, argmin with the lowest index on ties (stable sort / strict '<').
+// One thread per row; centres are staged in LDS tiles and read as broadcasts.
+// =====================================================================================
+constexpr int kAsgTC = 16;   // centres per LDS tile
+constexpr int kAsgDJ = 32;   // row values held in registers at a time
+
+__global__ __launch_bounds__(256) void assign_nearest_kernel(BfIndexDev ix, const float *__restrict__ centers,
+                                                             uint32_t k, uint32_t *__restrict__ out_idx,
+                                                             float *__restrict__ out_dist) {
+    extern __shared__ __attribute__((aligned(16))) float cs[];   // [kAsgTC][dimp]
+    const uint32_t dim = ix.dim, dimp = (dim + 3u) & ~3u;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = i < ix.n;
+    const float *row = ix.rows + (act ? i : 0) * ix.stride;
+    const bool vec = ((ix.stride & 3u) == 0) && ((reinterpret_cast<uintptr_t>(ix.rows) & 15u) == 0);
+    float best = __builtin_inff();
+    uint32_t bi = 0;
+    for (uint32_t c0 = 0; c0 < k; c0 += kAsgTC) {
+        for (uint32_t e = threadIdx.x; e < kAsgTC * dimp; e += blockDim.x) {
+            const uint32_t c = e / dimp, j = e - c * dimp;
+            cs[e] = (c0 + c < k && j < dim) ? centers[(size_t)(c0 + c) * dim + j] : 0.0f;
+        }
+        __syncthreads();
+        float acc[kAsgTC];
+#pragma unroll
+        for (int c = 0; c < kAsgTC; ++c) acc[c] = 0.0f;
+        for (uint32_t j0 = 0; j0 < dim; j0 += kAsgDJ) {
+            float x[kAsgDJ];
+            if (vec && j0 + kAsgDJ <= dim) {
+#pragma unroll
+                for (int j = 0; j < kAsgDJ; j += 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(row + j0 + j);
+                    x[j] = v.x; x[j + 1] = v.y; x[j + 2] = v.z; x[j + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < kAsgDJ; ++j) x[j] = (j0 + j < dim) ? row[j0 + j] : 0.0f;
+            }
+            const uint32_t nj = min((uint32_t)kAsgDJ, dim - j0);
+#pragma unroll
+            for (int c = 0; c < kAsgTC; ++c) {
+                const float *cr = cs + c * dimp + j0;
+                float a = acc[c];
+                if (nj == (uint32_t)kAsgDJ) {
+#pragma unroll
+                    for (int j = 0; j < kAsgDJ; ++j) {
+                        const float d = x[j] - cr[j];
+                        a = a + d * d;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kAsgDJ; ++j)
+                        if ((uint32_t)j < nj) {
+                            const float d = x[j] - cr[j];
+                            a = a + d * d;
+                        }
+                }
+                acc[c] = a;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kAsgTC; ++c)
+            if (c0 + c < k && acc[c] < best) {
+                best = acc[c];
+                bi = c0 + c;
+            }
+        __syncthreads();
+    }
+    if (act) {
+        out_idx[i] = bi;
+        if (out_dist) out_dist[i] = best;
+    }
+}
+
+// =====================================================================================
 // threshold from the sample matrix [nq][ns]; when the sample is the whole dataset
 // (row_mult == 1, ns == n) the sorted sample IS the answer and is written directly.
 // =====================================================================================
@@ -613,6 +692,25 @@ int bf_distances_host(const BfIndexDev &ix, BfWorkspace &w, const float *queries
     a.ld = (uint32_t)ix.n;
     SCANN_TRY(launch_pass(ix, a, st));
     SCANN_HIP_CHECK(hipMemcpyAsync(out, dout.p, (size_t)nq * ix.n * 4, hipMemcpyDeviceToHost, st));
+    SCANN_HIP_CHECK(hipStreamSynchronize(st));
+    return SCANN_HIP_OK;
+}
+
+int bf_assign_nearest_host(const BfIndexDev &ix, const float *centers, uint32_t k, uint32_t *out_idx,
+                           float *out_dist, hipStream_t st) {
+    if (ix.n == 0) return SCANN_HIP_OK;
+    DevBuf dc, di, dd;
+    SCANN_TRY(upload(dc, centers, (size_t)k * ix.dim * 4));
+    SCANN_TRY(di.ensure((size_t)ix.n * 4));
+    if (out_dist) SCANN_TRY(dd.ensure((size_t)ix.n * 4));
+    const uint32_t dimp = (ix.dim + 3u) & ~3u;
+    const size_t lds = (size_t)kAsgTC * dimp * sizeof(float);
+    SCANN_TRY(set_dyn_lds(assign_nearest_kernel, lds));
+    hipLaunchKernelGGL(assign_nearest_kernel, dim3((uint32_t)ceil_div_u64(ix.n, 256)), dim3(256), lds, st, ix,
+                       dc.as<float>(), k, di.as<uint32_t>(), out_dist ? dd.as<float>() : nullptr);
+    LAUNCH_CHECK();
+    SCANN_HIP_CHECK(hipMemcpyAsync(out_idx, di.p, (size_t)ix.n * 4, hipMemcpyDeviceToHost, st));
+    if (out_dist) SCANN_HIP_CHECK(hipMemcpyAsync(out_dist, dd.p, (size_t)ix.n * 4, hipMemcpyDeviceToHost, st));
     SCANN_HIP_CHECK(hipStreamSynchronize(st));
     return SCANN_HIP_OK;
 }

@@ -30,7 +30,7 @@ EXPORTS = [
     "scann_hip_txh_search_local_device", "scann_hip_txh_merge_device",
     "scann_hip_assign_leaves", "scann_hip_txh_partition", "scann_hip_lut_from_query",
     "scann_hip_adc_distances", "scann_hip_lut16_distances_batch", "scann_hip_encode",
-    "scann_hip_bf_distances", "scann_hip_index_size", "scann_hip_index_dimensionality",
+    "scann_hip_bf_distances", "scann_hip_bf_assign_nearest", "scann_hip_index_size", "scann_hip_index_dimensionality",
     "scann_hip_index_destroy", "scann_hip_index_enable_timing",
     "scann_hip_index_last_kernel_ms",
 ]
@@ -119,6 +119,7 @@ def load():
     L.scann_hip_encode.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, f32p,
                                    C.c_uint64, C.c_uint32, f32p, u32p, u8p]
     L.scann_hip_bf_distances.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, f32p]
+    L.scann_hip_bf_assign_nearest.argtypes = [vp, f32p, C.c_uint32, u32p, f32p]
     L.scann_hip_index_size.restype = C.c_uint64
     L.scann_hip_index_size.argtypes = [vp]
     L.scann_hip_index_dimensionality.restype = C.c_uint32
@@ -339,6 +340,16 @@ def bf_distances(index, queries):
     out = np.zeros((nq, index.size()), np.float32)
     check(load().scann_hip_bf_distances(index.h, ptr(q, f32p), nq, qs, ptr(out, f32p)))
     return out
+
+
+def bf_assign_nearest(index, centers, want_dist=True):
+    c = f32(centers)
+    n = index.size()
+    out = np.zeros(n, np.uint32)
+    dist = np.zeros(n, np.float32) if want_dist else None
+    check(load().scann_hip_bf_assign_nearest(index.h, ptr(c, f32p), c.shape[0], ptr(out, u32p),
+                                             ptr(dist, f32p)))
+    return (out, dist) if want_dist else out
 
 
 def assign_leaves(sizes, world):

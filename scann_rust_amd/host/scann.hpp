@@ -182,6 +182,43 @@ inline void kmeans(const float *rows, size_t n, size_t stride, size_t c0, size_t
     }
 }
 
+// Lloyd k-means over whole rows with the ASSIGNMENT step on the GPU
+// (scann_hip_bf_assign_nearest: the partitioner's sequential-scalar arithmetic, lowest index
+// on ties) and the centre update on the host in f64, as trees/kmeans.rs:382-414 does.
+// `bf` is a brute-force index holding the same rows.
+inline void kmeans_gpu(scann_hip_index *bf, const float *rows, size_t n, size_t stride, size_t d, size_t k,
+                       size_t iters, uint64_t seed, std::vector<float> &centers, std::vector<uint32_t> &assign) {
+    k = std::min(k, n);
+    centers.assign(k * d, 0.0f);
+    assign.assign(n, 0);
+    uint64_t s = seed;
+    std::vector<size_t> pick;
+    while (pick.size() < k) {
+        size_t c = splitmix(s) % n;
+        if (std::find(pick.begin(), pick.end(), c) == pick.end()) pick.push_back(c);
+    }
+    for (size_t c = 0; c < k; ++c) std::memcpy(&centers[c * d], rows + pick[c] * stride, d * 4);
+    std::vector<uint32_t> next(n);
+    std::vector<double> sums(k * d);
+    std::vector<size_t> cnt(k);
+    for (size_t it = 0; it <= iters; ++it) {
+        check(scann_hip_bf_assign_nearest(bf, centers.data(), (uint32_t)k, next.data(), nullptr));
+        const bool changed = next != assign;
+        assign.swap(next);
+        if (it == iters || (!changed && it > 0)) break;
+        std::fill(sums.begin(), sums.end(), 0.0);
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (size_t i = 0; i < n; ++i) {
+            const float *x = rows + i * stride;
+            double *sp = &sums[(size_t)assign[i] * d];
+            for (size_t j = 0; j < d; ++j) sp[j] += x[j];
+            ++cnt[assign[i]];
+        }
+        for (size_t c = 0; c < k; ++c)
+            if (cnt[c]) for (size_t j = 0; j < d; ++j) centers[c * d + j] = (float)(sums[c * d + j] / cnt[c]);
+    }
+}
+
 // Codebook::train (hashes/codebook.rs:146-202): per-subspace k-means, seed + s.
 inline std::vector<float> train_codebook(const float *rows, size_t n, size_t stride, uint32_t dim,
                                          uint32_t S, uint32_t K, uint64_t seed, size_t iters) {
@@ -352,10 +389,16 @@ public:
         if (dim % S != 0)
             throw ScannError::invalid_argument("Dimensionality " + std::to_string(dim) +
                                                " must be divisible by num_subspaces " + std::to_string(S));
-        // TreePartitioner::build: flat k-means, seed 42 (tree_partitioner.rs:48-98)
+        // TreePartitioner::build: flat k-means, seed 42 (tree_partitioner.rs:48-98); the
+        // assignment step (N x L x d) runs on the GPU, the f64 centre update on the host.
         std::vector<uint32_t> assign;
-        detail::kmeans(ds.raw_data(), n, st, 0, dim, config_.num_partitions, config_.kmeans_iterations, 42,
-                       centers_, assign);
+        {
+            detail::IndexHandle tmp;
+            check(scann_hip_bf_create(context(device_), ds.raw_data(), n, (uint32_t)dim, (uint32_t)st,
+                                      SCANN_HIP_SQUARED_L2, &tmp.h));
+            detail::kmeans_gpu(tmp.h, ds.raw_data(), n, st, dim, config_.num_partitions,
+                               config_.kmeans_iterations, 42, centers_, assign);
+        }
         const uint32_t L = (uint32_t)(centers_.size() / dim);
         leaf_off_.assign(L + 1, 0);
         for (uint32_t a : assign) ++leaf_off_[a + 1];

@@ -384,3 +384,21 @@ def test_sharded_local_plus_merge_equals_single_index(world):
                                           g_idx.cpu().numpy().view(np.uint32), g_ex.cpu().numpy(),
                                           g_cnt.cpu().numpy(), m, k)
     assert np.array_equal(mi, gi) and np.array_equal(md.view(np.uint32), gd.view(np.uint32))
+
+
+# ---- index-build helper: TreePartitioner::partition(x, 1) for every row -----------------------------------
+@pytest.mark.parametrize("n,dim,k", [(3000, 128, 100), (1000, 96, 37), (700, 50, 5), (500, 7, 16), (64, 32, 1)])
+def test_assign_nearest_bit_exact(n, dim, k):
+    rows = synth.uniform_f32(n, dim, 17)
+    data, stride = orc.to_strided(rows)
+    centers = synth.uniform_f32(k, dim, 18)
+    index = hip.bf_create(data, n, dim, stride, hip.SQUARED_L2)
+    asg, dist = hip.bf_assign_nearest(index, centers)
+    for i in range(0, n, 7):
+        tok, d = orc.partition(centers, rows[i], 1)
+        assert asg[i] == tok[0]
+        assert np.float32(dist[i]) == d[0]
+    # ties -> lowest centre index (stable sort, tree_partitioner.rs:212)
+    dup = np.concatenate([centers, centers[:1]])
+    asg2, _ = hip.bf_assign_nearest(index, dup)
+    assert np.array_equal(asg2, asg)
