@@ -306,15 +306,17 @@ def main():
         lopts.exact_reorder = opts.exact_reorder
         lopts.partitions_to_search = opts.partitions_to_search
         if world > 1:
-            keys = torch.empty((Q, m_local), dtype=torch.int64, device=device)
-            cidx = torch.empty((Q, m_local), dtype=torch.int32, device=device)
-            cex = torch.empty((Q, m_local), dtype=torch.float32, device=device)
-            ccnt = torch.empty((Q,), dtype=torch.int32, device=device)
-            g_keys = torch.empty((world, Q, m_local), dtype=torch.int64, device=device)
-            g_idx = torch.empty((world, Q, m_local), dtype=torch.int32, device=device)
-            g_ex = torch.empty((world, Q, m_local), dtype=torch.float32, device=device)
-            g_cnt = torch.empty((world, Q), dtype=torch.int32, device=device)
+            # one packed per-rank buffer [keys u64 | idx u32 | exact f32 | count u32] -> ONE
+            # all_gather per step; the merge kernel walks ranks with a byte stride
+            kb, ib, cb = Q * m_local * 8, Q * m_local * 4, Q * 4
+            sec = [0, kb, kb + ib, kb + 2 * ib]
+            pack_bytes = (kb + 2 * ib + cb + 255) // 256 * 256
+            pack = torch.zeros((pack_bytes,), dtype=torch.uint8, device=device)
+            g_pack = torch.zeros((world, pack_bytes), dtype=torch.uint8, device=device)
             mstatus = torch.zeros((1,), dtype=torch.int32, device=device)
+
+            def sect(t, i):
+                return ctypes.c_void_p(t.data_ptr() + sec[i])
         hip.check(L.scann_hip_index_reserve(index.h, Q, k, ctypes.byref(lopts)))
 
         def step(i):
@@ -325,16 +327,13 @@ def main():
                                                             dev_ptr(out_dist), dev_ptr(out_cnt), sptr))
             else:
                 hip.check(L.scann_hip_txh_search_local_device(index.h, dev_ptr(qd), Q, dim, k,
-                                                              ctypes.byref(lopts), dev_ptr(keys),
-                                                              dev_ptr(cidx), dev_ptr(cex),
-                                                              dev_ptr(ccnt), sptr))
-                all_gather(g_keys, keys)
-                all_gather(g_idx, cidx)
-                all_gather(g_ex, cex)
-                all_gather(g_cnt, ccnt)
+                                                              ctypes.byref(lopts), sect(pack, 0),
+                                                              sect(pack, 1), sect(pack, 2),
+                                                              sect(pack, 3), sptr))
+                all_gather(g_pack, pack)
                 hip.check(L.scann_hip_txh_merge_device(hip.context(local_rank), world, Q, m_local, m,
-                                                       k, dev_ptr(g_keys), dev_ptr(g_idx),
-                                                       dev_ptr(g_ex), dev_ptr(g_cnt), dev_ptr(out_idx),
+                                                       k, pack_bytes, sect(g_pack, 0), sect(g_pack, 1),
+                                                       sect(g_pack, 2), sect(g_pack, 3), dev_ptr(out_idx),
                                                        dev_ptr(out_dist), dev_ptr(out_cnt),
                                                        dev_ptr(mstatus), sptr))
 

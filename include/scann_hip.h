@@ -198,9 +198,13 @@ int scann_hip_txh_search_local_device(scann_hip_index *index, const float *d_que
  * m_local == m is exact by construction.  m_local < m (a random shard holds ~m/world of the
  * global best m) is verified: if a truncated rank could have held more members,
  * *d_status (caller-zeroed device word, may be NULL) is raised to Aborted and the caller
- * re-runs with m_local = m. */
+ * re-runs with m_local = m.
+ * rank_stride_bytes: 0 for dense arrays; otherwise the four pointers address rank 0's
+ * sections of a packed per-rank buffer and rank g's sections lie g * rank_stride_bytes
+ * further (one all_gather of [keys | idx | exact | count] instead of four). */
 int scann_hip_txh_merge_device(scann_hip_ctx *ctx, uint32_t world, uint32_t nq, uint32_t m_local,
-                               uint32_t m, uint32_t k, const uint64_t *d_keys,
+                               uint32_t m, uint32_t k, uint64_t rank_stride_bytes,
+                               const uint64_t *d_keys,
                                const uint32_t *d_idx, const float *d_exact,
                                const uint32_t *d_count, uint32_t *d_out_idx, float *d_out_dist,
                                uint32_t *d_out_count, uint32_t *d_status, void *hip_stream);

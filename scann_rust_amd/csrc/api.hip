@@ -695,13 +695,15 @@ int scann_hip_txh_search_local_device(scann_hip_index *ix, const float *d_querie
 }
 
 int scann_hip_txh_merge_device(scann_hip_ctx *ctx, uint32_t world, uint32_t nq, uint32_t m_local,
-                               uint32_t m, uint32_t k, const uint64_t *d_keys, const uint32_t *d_idx,
+                               uint32_t m, uint32_t k, uint64_t rank_stride_bytes,
+                               const uint64_t *d_keys, const uint32_t *d_idx,
                                const float *d_exact, const uint32_t *d_count, uint32_t *d_out_idx,
                                float *d_out_dist, uint32_t *d_out_count, uint32_t *d_status,
                                void *hip_stream) {
     if (!ctx) return fail(SCANN_HIP_INVALID_ARGUMENT, "ctx is null");
     SCANN_TRY(set_device(ctx));
-    return txh_launch_merge(world, nq, m_local, m, k, d_keys, d_idx, d_exact, d_count, d_out_idx,
+    return txh_launch_merge(world, nq, m_local, m, k, (size_t)rank_stride_bytes, d_keys, d_idx, d_exact,
+                            d_count, d_out_idx,
                             d_out_dist, d_out_count, d_status, static_cast<hipStream_t>(hip_stream));
 }
 

@@ -107,7 +107,7 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only,
 int txh_launch_partition_only(const TxhIndexDev &ix, const TxhWork &w, hipStream_t stream);
 
 int txh_launch_merge(uint32_t world, uint32_t nq, uint32_t m_local, uint32_t m, uint32_t k,
-                     const uint64_t *d_keys, const uint32_t *d_idx, const float *d_exact,
+                     size_t rank_stride_bytes, const uint64_t *d_keys, const uint32_t *d_idx, const float *d_exact,
                      const uint32_t *d_count, uint32_t *d_out_idx, float *d_out_dist,
                      uint32_t *d_out_count, uint32_t *d_status, hipStream_t stream);
 

@@ -1073,36 +1073,55 @@ __global__ __launch_bounds__(kSelectThreads) void final_topk_kernel(
 // =====================================================================================
 __global__ __launch_bounds__(kSelectThreads) void merge_kernel(
     uint32_t world, uint32_t nq, uint32_t m_local, uint32_t m, uint32_t k, uint32_t m2max,
-    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx,
+    size_t rank_stride, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx,
     const float *__restrict__ exact, const uint32_t *__restrict__ count,
     uint32_t *__restrict__ out_idx, float *__restrict__ out_dist,
     uint32_t *__restrict__ out_count, uint32_t *__restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];   // [m2max]
-    uint32_t *s_src = reinterpret_cast<uint32_t *>(skeys + m2max);     // [m2max]
+    // rank g's arrays start rank_stride BYTES after rank g-1's (a packed all_gather buffer);
+    // rank_stride == 0 means dense [world][nq][m_local] arrays.
+    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];   // [m2max] (sort path)
+    uint32_t *s_src = reinterpret_cast<uint32_t *>(skeys + m2max);     // [m2max] packed (g, slot)
     uint64_t *s_mth = reinterpret_cast<uint64_t *>(s_src + m2max);     // [1] key at rank nsel-1
+    uint64_t *s_red = s_mth + 1;                                       // [kSelectThreads/64]
     const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    auto at = [&](const void *base, uint32_t g, size_t dense_elems, size_t esz) -> const char * {
+        return reinterpret_cast<const char *>(base) +
+               (rank_stride ? (size_t)g * rank_stride : (size_t)g * dense_elems * esz);
+    };
+    auto keys_of = [&](uint32_t g) {
+        return reinterpret_cast<const uint64_t *>(at(keys, g, (size_t)nq * m_local, 8)) + (size_t)q * m_local;
+    };
+    auto idx_of = [&](uint32_t g) {
+        return reinterpret_cast<const uint32_t *>(at(idx, g, (size_t)nq * m_local, 4)) + (size_t)q * m_local;
+    };
+    auto exact_of = [&](uint32_t g) {
+        return reinterpret_cast<const float *>(at(exact, g, (size_t)nq * m_local, 4)) + (size_t)q * m_local;
+    };
+    auto count_of = [&](uint32_t g) {
+        return reinterpret_cast<const uint32_t *>(at(count, g, (size_t)nq, 4))[q];
+    };
     uint32_t tot = 0;
-    for (uint32_t g = 0; g < world; ++g) tot += count[(size_t)g * nq + q];
+    for (uint32_t g = 0; g < world; ++g) tot += count_of(g);
     const uint32_t nsel = min(m, tot);
     if (tid == 0) *s_mth = SCANN_KEY_MAX;
     __syncthreads();
     for (uint32_t g = 0; g < world; ++g) {
-        const uint32_t cg = count[(size_t)g * nq + q];
-        const uint64_t *kl = keys + ((size_t)g * nq + q) * m_local;
+        const uint32_t cg = count_of(g);
+        const uint64_t *kl = keys_of(g);
         for (uint32_t i = tid; i < cg; i += nt) {
             const uint64_t key = kl[i];
             uint32_t rank = i;                      // smaller keys in its own list
             for (uint32_t g2 = 0; g2 < world; ++g2) {
                 if (g2 == g) continue;
-                const uint64_t *k2 = keys + ((size_t)g2 * nq + q) * m_local;
-                uint32_t lo = 0, hi = count[(size_t)g2 * nq + q];
+                const uint64_t *k2 = keys_of(g2);
+                uint32_t lo = 0, hi = count_of(g2);
                 while (lo < hi) {
                     uint32_t mid = (lo + hi) >> 1;
                     if (k2[mid] < key) lo = mid + 1; else hi = mid;
                 }
                 rank += lo;
             }
-            if (rank < nsel) s_src[rank] = (uint32_t)(((size_t)g * nq + q) * m_local + i);
+            if (rank < nsel) s_src[rank] = (g << 24) | i;     // world <= 64, m_local <= 8192
             if (rank + 1 == nsel) *s_mth = key;
         }
     }
@@ -1111,25 +1130,75 @@ __global__ __launch_bounds__(kSelectThreads) void merge_kernel(
     // of the global top-m).  A truncated list whose last key is still below the global m-th
     // key could have held more members: report it, the caller re-runs with m_local = m.
     if (status && m_local < m && tid < world) {
-        const uint32_t cg = count[(size_t)tid * nq + q];
+        const uint32_t cg = count_of(tid);
         if (cg == m_local && cg > 0) {
-            const uint64_t last = keys[((size_t)tid * nq + q) * m_local + cg - 1];
+            const uint64_t last = keys_of(tid)[cg - 1];
             if (tot < m || last < *s_mth) atomicMax(status, (uint32_t)SCANN_HIP_ABORTED);
         }
     }
+    const uint32_t nout = min(k, nsel);
+    if (k <= kTopkMaxK) {
+        // stable sort by exact == order by (exact, merged approx rank): k block-wide arg-mins
+        constexpr int E = kMaxPreReorderK / kSelectThreads;
+        uint64_t key2[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t r = e * kSelectThreads + tid;
+            key2[e] = SCANN_KEY_MAX;
+            if (r < nsel) {
+                const uint32_t src = s_src[r];
+                key2[e] = make_key(exact_of(src >> 24)[src & 0xFFFFFFu], r);
+            }
+        }
+        for (uint32_t r = 0; r < nout; ++r) {
+            uint64_t b = key2[0];
+#pragma unroll
+            for (int e = 1; e < E; ++e) b = min(b, key2[e]);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) b = min(b, (uint64_t)__shfl_xor((unsigned long long)b, d, 64));
+            if ((tid & 63u) == 0) s_red[tid >> 6] = b;
+            __syncthreads();
+            uint64_t gmin = s_red[0];
+#pragma unroll
+            for (int w2 = 1; w2 < (int)(kSelectThreads / 64); ++w2) gmin = min(gmin, s_red[w2]);
+            const uint32_t rk = (uint32_t)gmin;
+            if ((rk & (kSelectThreads - 1)) == tid) {
+                const uint32_t we = rk / kSelectThreads;
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if ((uint32_t)e == we) key2[e] = SCANN_KEY_MAX;
+                const uint32_t src = s_src[rk];
+                out_idx[(size_t)q * k + r] = idx_of(src >> 24)[src & 0xFFFFFFu];
+                out_dist[(size_t)q * k + r] = ordered_to_f32((uint32_t)(gmin >> 32));
+            }
+            __syncthreads();
+        }
+        for (uint32_t i = nout + tid; i < k; i += nt) {
+            out_idx[(size_t)q * k + i] = kInvalid;
+            out_dist[(size_t)q * k + i] = __builtin_inff();
+        }
+        if (tid == 0) out_count[q] = nout;
+        return;
+    }
     uint32_t m2 = 1;
     while (m2 < nsel) m2 <<= 1;
-    for (uint32_t i = tid; i < m2; i += nt)
-        skeys[i] = (i < nsel) ? make_key(exact[s_src[i]], i) : SCANN_KEY_MAX;
+    for (uint32_t i = tid; i < m2; i += nt) {
+        uint64_t kv = SCANN_KEY_MAX;
+        if (i < nsel) {
+            const uint32_t src = s_src[i];
+            kv = make_key(exact_of(src >> 24)[src & 0xFFFFFFu], i);
+        }
+        skeys[i] = kv;
+    }
     __syncthreads();
     bitonic_sort_lds(skeys, m2);
-    const uint32_t nout = min(k, nsel);
     for (uint32_t i = tid; i < k; i += nt) {
         uint32_t oi = kInvalid;
         float od = __builtin_inff();
         if (i < nout) {
             const uint64_t key = skeys[i];
-            oi = idx[s_src[(uint32_t)key]];
+            const uint32_t src = s_src[(uint32_t)key];
+            oi = idx_of(src >> 24)[src & 0xFFFFFFu];
             od = ordered_to_f32((uint32_t)(key >> 32));
         }
         out_idx[(size_t)q * k + i] = oi;
@@ -1365,19 +1434,20 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
 }
 
 int txh_launch_merge(uint32_t world, uint32_t nq, uint32_t m_local, uint32_t m, uint32_t k,
-                     const uint64_t *d_keys, const uint32_t *d_idx, const float *d_exact,
-                     const uint32_t *d_count, uint32_t *d_out_idx, float *d_out_dist,
-                     uint32_t *d_out_count, uint32_t *d_status, hipStream_t st) {
+                     size_t rank_stride_bytes, const uint64_t *d_keys, const uint32_t *d_idx,
+                     const float *d_exact, const uint32_t *d_count, uint32_t *d_out_idx,
+                     float *d_out_dist, uint32_t *d_out_count, uint32_t *d_status, hipStream_t st) {
     if (nq == 0) return SCANN_HIP_OK;
     if (world == 0 || world > 64) return fail(SCANN_HIP_INVALID_ARGUMENT, "world must be 1..64");
     if (m_local == 0 || m_local > m) return fail(SCANN_HIP_INVALID_ARGUMENT, "need 0 < m_local <= m");
     if (m > kMaxPreReorderK)
         return fail(SCANN_HIP_UNIMPLEMENTED, "pre_reorder_k exceeds the LDS merge capacity");
     const uint32_t m2 = next_pow2_u32(std::max<uint32_t>(1u, m));
-    const size_t lds = (size_t)m2 * 12 + 16;
+    const size_t lds = (size_t)m2 * 12 + 16 + (kSelectThreads / 64) * 8;
     SCANN_TRY(set_dyn_lds(merge_kernel, lds));
     hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kSelectThreads), lds, st, world, nq, m_local, m, k, m2,
-                       d_keys, d_idx, d_exact, d_count, d_out_idx, d_out_dist, d_out_count, d_status);
+                       rank_stride_bytes, d_keys, d_idx, d_exact, d_count, d_out_idx, d_out_dist,
+                       d_out_count, d_status);
     LAUNCH_CHECK();
     return SCANN_HIP_OK;
 }

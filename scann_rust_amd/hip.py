@@ -108,7 +108,7 @@ def load():
     L.scann_hip_txh_search_local_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32,
                                                     C.POINTER(SearchOpts), vp, vp, vp, vp, vp]
     L.scann_hip_txh_merge_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
-                                             C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+                                             C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.scann_hip_assign_leaves.argtypes = [u32p, C.c_uint32, C.c_uint32, u32p]
     L.scann_hip_txh_partition.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.c_uint32, u32p, f32p, u32p]

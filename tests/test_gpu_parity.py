@@ -328,12 +328,12 @@ def test_concurrent_queries():
 
 
 # ---- multi-GPU stages on one GPU: two leaf shards -> local stage x2 -> merge ------------------------------
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_local_plus_merge_equals_single_index(world):
+@pytest.mark.parametrize("world,k,m", [(2, 10, 60), (3, 10, 60), (2, 100, 400)])
+def test_sharded_local_plus_merge_equals_single_index(world, k, m):
     import ctypes as C
     import torch
     from scann_rust_amd import sharding
-    n, dim, L, S, k, P, m, nq = 6000, 128, 24, 32, 10, 8, 60, 50
+    n, dim, L, S, P, nq = 6000, 128, 24, 32, 8, 50
     rows, data, stride, ix, oix, kw = H.make_txh_case(n, dim, L, S, seed=12, P=P, mult=m / k,
                                                       kmeans_iters=3, pq_iters=3)
     full = hip.txh_create(**kw)
@@ -365,7 +365,7 @@ def test_sharded_local_plus_merge_equals_single_index(world):
     out_dist = torch.zeros((nq, k), dtype=torch.float32, device=dev)
     out_cnt = torch.zeros((nq,), dtype=torch.int32, device=dev)
     status = torch.zeros((1,), dtype=torch.int32, device=dev)
-    hip.check(Lh.scann_hip_txh_merge_device(hip.context(0), world, nq, m, m, k,
+    hip.check(Lh.scann_hip_txh_merge_device(hip.context(0), world, nq, m, m, k, 0,
                                             C.c_void_p(g_keys.data_ptr()), C.c_void_p(g_idx.data_ptr()),
                                             C.c_void_p(g_ex.data_ptr()), C.c_void_p(g_cnt.data_ptr()),
                                             C.c_void_p(out_idx.data_ptr()), C.c_void_p(out_dist.data_ptr()),
