@@ -150,6 +150,14 @@ typedef struct {
     uint32_t *cand_idx;
     float *cand_dist;
     uint32_t *cand_count;
+    /* TreeXHybridSearcher::search_with_filter(query, k, Some(filter)) for allow-list filters
+     * (tree_x_hybrid/mod.rs:245-250, 327-332; restricts/allowlist.rs): bit i set = datapoint i
+     * may be returned; disallowed points are skipped before scoring.  NULL = no filter.  Host
+     * pointer in the host entry points, DEVICE pointer in the *_device entry points.
+     * allow_bitmap_bits >= the largest datapoint index + 1.  Arbitrary `dyn RestrictFilter`s
+     * stay on the caller's CPU path. */
+    const uint64_t *allow_bitmap;
+    uint64_t allow_bitmap_bits;
 } scann_hip_search_opts;
 
 void scann_hip_search_opts_default(scann_hip_search_opts *opts);

@@ -47,6 +47,7 @@ class TxhIndexC(C.Structure):
         ("use_residuals", C.c_int32),
         ("partitions_to_search", C.c_uint32),
         ("pre_reorder_multiplier", C.c_float),
+        ("allow", C.POINTER(C.c_uint64)),
     ]
 
 
@@ -408,6 +409,7 @@ class TxhIndex:
         self.use_residuals = bool(use_residuals)
         self.partitions_to_search = int(partitions_to_search)
         self.pre_reorder_multiplier = float(pre_reorder_multiplier)
+        self.allow = None   # optional uint64 allow-bitmap (search_with_filter)
 
     def c_struct(self):
         s = TxhIndexC()
@@ -423,6 +425,9 @@ class TxhIndex:
         s.use_residuals = 1 if self.use_residuals else 0
         s.partitions_to_search = self.partitions_to_search
         s.pre_reorder_multiplier = self.pre_reorder_multiplier
+        if self.allow is not None:
+            self.allow = np.ascontiguousarray(self.allow, np.uint64)
+            s.allow = self.allow.ctypes.data_as(C.POINTER(C.c_uint64))
         return s
 
 

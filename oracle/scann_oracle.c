@@ -825,7 +825,9 @@ static size_t txh_search_partition(const or_txh_index *ix, const float *q, uint3
     f->size = 0; /* FastTopNeighbors::new(k) :322 */
     for (size_t i = 0; i < f->capacity; ++i) f->distances[i] = INFINITY;
     uint32_t b = ix->leaf_off[pid], e = ix->leaf_off[pid + 1];
-    for (uint32_t i = b; i < e; ++i) { /* :324-336 (filter = None) */
+    for (uint32_t i = b; i < e; ++i) { /* :324-336 */
+        uint32_t id = ix->leaf_ids[i];
+        if (ix->allow && !((ix->allow[id >> 6] >> (id & 63u)) & 1u)) continue; /* :328-332 */
         float d = or_lut_distance(lut, ix->S, ix->K, ix->codes + (size_t)i * ix->S);
         ftn_push(f, ix->leaf_ids[i], d);
     }

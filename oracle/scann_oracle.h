@@ -155,6 +155,9 @@ typedef struct {
     int32_t use_residuals;
     uint32_t partitions_to_search;
     float pre_reorder_multiplier;
+    /* search_with_filter(.., Some(f)) with an allow-list f (restricts/mod.rs:17-30): bit i =
+     * datapoint i allowed.  NULL = filter None. */
+    const uint64_t *allow;
 } or_txh_index;
 
 /* Optional stage outputs (may be NULL):

@@ -35,7 +35,7 @@ enum IndexKind { KIND_BF = 1, KIND_TXH = 2 };
 struct TxhWorkspace {
     DevBuf queries, cdist, tokens, token_dists, vbase, leaf_cnt, leaf_cursor, pair_off, tile_off,
         counters, pair_q, pair_leaf, pair_vbase, pair_thr, slot_of, lutq, thr, cand_cnt, cand, cand_key,
-        cand_idx, cand_dist, cand_exact, cand_row, cand_count, out_idx, out_dist, out_count;
+        cand_idx, cand_dist, cand_exact, cand_row, cand_count, out_idx, out_dist, out_count, allow;
 };
 
 struct scann_hip_index {
@@ -377,6 +377,8 @@ static int resolve_params(const scann_hip_index *ix, uint32_t k, const scann_hip
         return fail(SCANN_HIP_UNIMPLEMENTED,
                     "pre-reorder candidate count " + std::to_string(m) + " exceeds " +
                         std::to_string(kMaxPreReorderK));
+    if (o->allow_bitmap && o->allow_bitmap_bits == 0)
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "allow_bitmap_bits must cover every datapoint index");
     if (o->exact_reorder && !ix->tx.rows)  // hasher.rs:194-197
         return fail(SCANN_HIP_FAILED_PRECONDITION, "Dataset not stored");
     const uint64_t ms = std::min<uint64_t>(std::max<uint64_t>(1, max_stream(ix, P)), 0xFFFFFFFFull);
@@ -453,6 +455,7 @@ static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallP
     w->exact_reorder = p.exact_reorder;
     w->no_threshold = p.no_threshold;
     w->need_sorted_cands = 0;
+    w->allow = nullptr;
     w->queries = s.queries.as<float>();
     w->cdist = s.cdist.as<float>();
     w->tokens = s.tokens.as<uint32_t>();
@@ -512,6 +515,13 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
         TxhWork w;
         SCANN_TRY(ensure_txh_workspace(ix, nq, p, true, q_stride, true, &w));
         w.need_sorted_cands = (opts && (opts->cand_idx || opts->cand_dist)) ? 1 : 0;
+        if (opts && opts->allow_bitmap) {   // search_with_filter(Some(allow-list))
+            const size_t words = (size_t)((opts->allow_bitmap_bits + 63) / 64);
+            SCANN_TRY(ix->ws.allow.ensure(words * 8));
+            SCANN_HIP_CHECK(hipMemcpyAsync(ix->ws.allow.p, opts->allow_bitmap, words * 8,
+                                           hipMemcpyHostToDevice, ix->stream));
+            w.allow = ix->ws.allow.as<uint64_t>();
+        }
         SCANN_HIP_CHECK(hipMemcpyAsync(ix->ws.queries.p, queries, (size_t)nq * q_stride * 4,
                                        hipMemcpyHostToDevice, ix->stream));
         ix->next_events();
@@ -638,6 +648,7 @@ int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries,
     w.out_idx = d_out_idx;
     w.out_dist = d_out_dist;
     w.out_count = d_out_count;
+    if (opts && opts->allow_bitmap) w.allow = opts->allow_bitmap;   // device pointer on this path
     ix->last_work = w;
     ix->next_events();
     SCANN_TRY(txh_launch_search(ix->tx, w, false, st, ix->ev0,
@@ -685,6 +696,7 @@ int scann_hip_txh_search_local_device(scann_hip_index *ix, const float *d_querie
     w.cand_idx = d_idx;
     w.cand_exact = d_exact;
     w.cand_count = d_count;
+    if (opts && opts->allow_bitmap) w.allow = opts->allow_bitmap;   // device pointer on this path
     ix->last_work = w;
     ix->next_events();
     SCANN_TRY(txh_launch_search(ix->tx, w, true, st, ix->ev0,

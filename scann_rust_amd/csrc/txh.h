@@ -68,6 +68,7 @@ struct TxhWork {
     int exact_reorder;
     int no_threshold;          // retry mode: keep every scanned point as a candidate
     int need_sorted_cands;     // the caller reads cand_* (parity outputs): keep them sorted
+    const uint64_t *allow;     // device allow-bitmap (bit = datapoint index) or nullptr
     const float *queries;      // device
     float *cdist;              // [nq][L]
     uint32_t *tokens;          // [nq][P]

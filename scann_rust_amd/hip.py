@@ -72,6 +72,7 @@ class SearchOpts(C.Structure):
         ("exact_reorder", C.c_int32),
         ("tokens", u32p), ("token_dists", f32p),
         ("cand_idx", u32p), ("cand_dist", f32p), ("cand_count", u32p),
+        ("allow_bitmap", u64p), ("allow_bitmap_bits", C.c_uint64),
     ]
 
 
@@ -193,7 +194,8 @@ class Index:
     def dimensionality(self):
         return int(load().scann_hip_index_dimensionality(self.h))
 
-    def search_batched(self, queries, k, opts=None, q_dim=None, stages=False):
+    def search_batched(self, queries, k, opts=None, q_dim=None, stages=False, allow=None):
+        """`allow`: optional uint64 allow-bitmap (see allow_bitmap()) = search_with_filter."""
         q = f32(queries)
         if q.ndim == 1:
             q = q[None]
@@ -204,6 +206,9 @@ class Index:
         out_cnt = np.zeros(nq, np.uint32)
         o = opts if opts is not None else default_opts()
         extra = None
+        if allow is not None:
+            allow = np.ascontiguousarray(allow, np.uint64)
+            o.allow_bitmap, o.allow_bitmap_bits = ptr(allow, u64p), allow.size * 64
         if stages:
             P = o.partitions_to_search or 4096
             m = o.pre_reorder_k or 4096
@@ -227,6 +232,15 @@ class Index:
         name = C.c_char_p()
         ms = load().scann_hip_index_last_kernel_ms(self.h, C.byref(name))
         return float(ms), (name.value or b"").decode()
+
+
+def allow_bitmap(n, allowed):
+    """uint64 bitmap with bit i set for every datapoint index in `allowed`
+    (restricts/allowlist.rs semantics: listed indices are allowed)."""
+    bits = np.zeros((n + 63) // 64, np.uint64)
+    a = np.asarray(allowed, np.uint64)
+    np.bitwise_or.at(bits, (a >> np.uint64(6)).astype(np.int64), np.uint64(1) << (a & np.uint64(63)))
+    return bits
 
 
 def bf_create(data, n, dim, stride, measure, device=0):

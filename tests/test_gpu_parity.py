@@ -402,3 +402,54 @@ def test_assign_nearest_bit_exact(n, dim, k):
     dup = np.concatenate([centers, centers[:1]])
     asg2, _ = hip.bf_assign_nearest(index, dup)
     assert np.array_equal(asg2, asg)
+
+
+@pytest.mark.parametrize("frac,k", [(0.5, 10), (0.05, 10), (0.002, 5)])
+def test_txh_allow_bitmap_filter(frac, k):
+    """search_with_filter(.., Some(allow-list)) (tree_x_hybrid/mod.rs:245-250, 327-332):
+    disallowed datapoints are skipped before scoring; every stage still matches the oracle.
+    frac=0.002 leaves fewer allowed points than pre_reorder_k (and for some queries than k)."""
+    n, dim, L, S = 6000, 64, 24, 16
+    rows, data, stride, ix, oix, kw = H.make_txh_case(n, dim, L, S, seed=91, P=6, mult=8.0)
+    rng = np.random.default_rng(17)
+    allowed = np.flatnonzero(rng.random(n) < frac)
+    bits = hip.allow_bitmap(n, allowed)
+    oix.allow = bits
+    index = hip.txh_create(**kw)
+    q = synth.uniform_f32(33, dim, 92)
+    o = hip.default_opts()
+    o.partitions_to_search, o.pre_reorder_k = 6, int(np.float32(k) * np.float32(8.0))
+    idx, dist, cnt, (tok, tokd, ci, cd, cc) = index.search_batched(q, k, opts=o, stages=True,
+                                                                   allow=bits)
+    aset = set(allowed.tolist())
+    for i in range(q.shape[0]):
+        assert set(idx[i, :cnt[i]].tolist()) <= aset
+        H.check_txh_query(oix, q[i], k, idx[i, :cnt[i]], dist[i, :cnt[i]], tok[i], tokd[i],
+                          ci[i, :cc[i]], cd[i, :cc[i]], what="filter q%d" % i)
+    # no filter afterwards: the bitmap does not stick to the handle
+    oix.allow = None
+    idx2, dist2, cnt2 = index.search_batched(q[:4], k)
+    for i in range(4):
+        oi, od = orc.txh_search(oix, q[i], k)
+        H.assert_topk_equal_up_to_ties(idx2[i, :cnt2[i]], dist2[i, :cnt2[i]], oi, od)
+
+
+def test_ah_allow_bitmap_filter():
+    """Same filter on the flat AsymmetricHasher index (no partitions)."""
+    n, dim, S = 5000, 32, 8
+    rows, data, stride, ix, kw = H.make_ah_case(n, dim, S, seed=93)
+    index = hip.txh_create(**kw)
+    allowed = np.arange(0, n, 7)
+    bits = hip.allow_bitmap(n, allowed)
+    q = synth.uniform_f32(9, dim, 94)
+    o = hip.default_opts()
+    o.exact_reorder, o.pre_reorder_k = 1, 50
+    idx, dist, cnt = index.search_batched(q, 10, opts=o, allow=bits)
+    sub = np.ascontiguousarray(ix["codes"][allowed])
+    for i in range(q.shape[0]):
+        assert cnt[i] == 10 and np.all(idx[i] % 7 == 0)
+        # oracle on the allowed subset == filtered search (skipped rows are never pushed)
+        oi, od = orc.ah_search_with_reordering(ix["codebook"], sub,
+                                               np.ascontiguousarray(data.reshape(n, stride)[allowed]),
+                                               stride, q[i], 10, 50)
+        H.assert_topk_equal_up_to_ties(idx[i], dist[i], allowed[oi].astype(np.uint32), od)

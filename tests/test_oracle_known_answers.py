@@ -316,3 +316,29 @@ def test_trainer_encode_matches_oracle():
     cb = trainer.train_codebook(X, 8, 16, iters=3, seed=1)
     assert np.array_equal(trainer.encode(cb, X), orc.encode_many(cb, X))
     assert np.array_equal(trainer.pack4(trainer.encode(cb, X)), orc.pack4(orc.encode_many(cb, X)))
+
+
+def test_txh_filter_equals_search_over_allowed_rows():
+    """search_partition skips disallowed rows before scoring (tree_x_hybrid/mod.rs:327-332),
+    so a filtered search == an unfiltered search of an index whose leaves hold only the
+    allowed rows.  No reference test covers the filter path: parity unpinned by the reference,
+    this pins the restatement against its own unfiltered path."""
+    import helpers as H
+    from scann_rust_amd import hip, synth
+    n, dim = 1200, 32
+    rows, data, stride, ix, oix, kw = H.make_txh_case(n, dim, 8, 8, seed=3, P=3, mult=4.0)
+    allowed = np.arange(0, n, 3)
+    keep = np.isin(ix["leaf_ids"], allowed)
+    sizes = np.add.reduceat(keep.astype(np.uint32), ix["leaf_off"][:-1].astype(np.int64)) \
+        * (np.diff(ix["leaf_off"].astype(np.int64)) > 0)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    sub = orc.TxhIndex(data, stride, dim, ix["centers"], off, ix["leaf_ids"][keep],
+                       ix["codebook"], ix["codes"][keep], partitions_to_search=3,
+                       pre_reorder_multiplier=4.0)
+    oix.allow = hip.allow_bitmap(n, allowed)
+    q = synth.uniform_f32(10, dim, 4)
+    for i in range(10):
+        a = orc.txh_search(oix, q[i], 5, stages=True)
+        b = orc.txh_search(sub, q[i], 5, stages=True)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
