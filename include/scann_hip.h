@@ -154,8 +154,10 @@ typedef struct {
      * (tree_x_hybrid/mod.rs:245-250, 327-332; restricts/allowlist.rs): bit i set = datapoint i
      * may be returned; disallowed points are skipped before scoring.  NULL = no filter.  Host
      * pointer in the host entry points, DEVICE pointer in the *_device entry points.
-     * allow_bitmap_bits >= the largest datapoint index + 1.  Arbitrary `dyn RestrictFilter`s
-     * stay on the caller's CPU path. */
+     * allow_bitmap_bits = the bitmap's capacity (a multiple-of-64-bit allocation is read);
+     * datapoint indices >= capacity are not allowed (allowlist.rs:97-100).  Any other
+     * `dyn RestrictFilter` is served by materialising is_allowed(0..n) into such a bitmap
+     * (what scann.hpp's search_with_filter does). */
     const uint64_t *allow_bitmap;
     uint64_t allow_bitmap_bits;
 } scann_hip_search_opts;

@@ -377,8 +377,6 @@ static int resolve_params(const scann_hip_index *ix, uint32_t k, const scann_hip
         return fail(SCANN_HIP_UNIMPLEMENTED,
                     "pre-reorder candidate count " + std::to_string(m) + " exceeds " +
                         std::to_string(kMaxPreReorderK));
-    if (o->allow_bitmap && o->allow_bitmap_bits == 0)
-        return fail(SCANN_HIP_INVALID_ARGUMENT, "allow_bitmap_bits must cover every datapoint index");
     if (o->exact_reorder && !ix->tx.rows)  // hasher.rs:194-197
         return fail(SCANN_HIP_FAILED_PRECONDITION, "Dataset not stored");
     const uint64_t ms = std::min<uint64_t>(std::max<uint64_t>(1, max_stream(ix, P)), 0xFFFFFFFFull);
@@ -456,6 +454,7 @@ static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallP
     w->no_threshold = p.no_threshold;
     w->need_sorted_cands = 0;
     w->allow = nullptr;
+    w->allow_bits = 0;
     w->queries = s.queries.as<float>();
     w->cdist = s.cdist.as<float>();
     w->tokens = s.tokens.as<uint32_t>();
@@ -521,6 +520,7 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
             SCANN_HIP_CHECK(hipMemcpyAsync(ix->ws.allow.p, opts->allow_bitmap, words * 8,
                                            hipMemcpyHostToDevice, ix->stream));
             w.allow = ix->ws.allow.as<uint64_t>();
+            w.allow_bits = opts->allow_bitmap_bits;
         }
         SCANN_HIP_CHECK(hipMemcpyAsync(ix->ws.queries.p, queries, (size_t)nq * q_stride * 4,
                                        hipMemcpyHostToDevice, ix->stream));
@@ -648,7 +648,10 @@ int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries,
     w.out_idx = d_out_idx;
     w.out_dist = d_out_dist;
     w.out_count = d_out_count;
-    if (opts && opts->allow_bitmap) w.allow = opts->allow_bitmap;   // device pointer on this path
+    if (opts && opts->allow_bitmap) {   // device pointer on this path
+        w.allow = opts->allow_bitmap;
+        w.allow_bits = opts->allow_bitmap_bits;
+    }
     ix->last_work = w;
     ix->next_events();
     SCANN_TRY(txh_launch_search(ix->tx, w, false, st, ix->ev0,
@@ -696,7 +699,10 @@ int scann_hip_txh_search_local_device(scann_hip_index *ix, const float *d_querie
     w.cand_idx = d_idx;
     w.cand_exact = d_exact;
     w.cand_count = d_count;
-    if (opts && opts->allow_bitmap) w.allow = opts->allow_bitmap;   // device pointer on this path
+    if (opts && opts->allow_bitmap) {   // device pointer on this path
+        w.allow = opts->allow_bitmap;
+        w.allow_bits = opts->allow_bitmap_bits;
+    }
     ix->last_work = w;
     ix->next_events();
     SCANN_TRY(txh_launch_search(ix->tx, w, true, st, ix->ev0,

@@ -69,6 +69,7 @@ struct TxhWork {
     int no_threshold;          // retry mode: keep every scanned point as a candidate
     int need_sorted_cands;     // the caller reads cand_* (parity outputs): keep them sorted
     const uint64_t *allow;     // device allow-bitmap (bit = datapoint index) or nullptr
+    uint64_t allow_bits;       // bitmap capacity in bits; indices >= capacity are not allowed
     const float *queries;      // device
     float *cdist;              // [nq][L]
     uint32_t *tokens;          // [nq][P]

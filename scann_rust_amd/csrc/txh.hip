@@ -274,10 +274,12 @@ __global__ __launch_bounds__(256) void lut_from_query_kernel(
 
 // RestrictFilter::is_allowed (restricts/mod.rs:17-30) for the allow-bitmap form of
 // search_with_filter (tree_x_hybrid/mod.rs:327-332): bit i of the bitmap = datapoint i.
-__device__ __forceinline__ bool row_allowed(const TxhIndexDev &ix, const uint64_t *allow, uint32_t csr) {
+// Indices at or beyond the bitmap's capacity are not allowed (allowlist.rs:97-100).
+__device__ __forceinline__ bool row_allowed(const TxhIndexDev &ix, const uint64_t *allow,
+                                            uint64_t allow_bits, uint32_t csr) {
     if (!allow) return true;
     const uint32_t idx = ix.leaf_ids ? ix.leaf_ids[csr] : csr;
-    return (allow[idx >> 6] >> (idx & 63u)) & 1ull;
+    return idx < allow_bits && ((allow[idx >> 6] >> (idx & 63u)) & 1ull);
 }
 
 // Sequential LUT sum for one packed code row against a [S][16] f32 table in LDS.
@@ -308,7 +310,8 @@ __global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(
     TxhIndexDev ix, uint32_t P, uint32_t m, int no_threshold,
     const uint32_t *__restrict__ tokens, const uint32_t *__restrict__ vbase,
     const uint32_t *__restrict__ slot_of, const float *__restrict__ lutq,
-    const uint64_t *__restrict__ allow, uint64_t *__restrict__ thr, uint64_t *__restrict__ pair_thr) {
+    const uint64_t *__restrict__ allow, uint64_t allow_bits, uint64_t *__restrict__ thr,
+    uint64_t *__restrict__ pair_thr) {
     constexpr int S = NW * 8;
     extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];      // [kSampleBuf]
     float *slut = reinterpret_cast<float *>(skeys + kSampleBuf);          // [S*16]
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(
 #pragma unroll
                 for (int wi = 0; wi < NW; ++wi) w[wi] = ix.codes[(size_t)(lb + j) * NW + wi];
                 const uint64_t key = make_key(adc_row_sum<NW>(slut, w), vb + j);
-                if (key <= Tcur && row_allowed(ix, allow, lb + j)) skeys[atomicAdd(&s_misc[0], 1u)] = key;
+                if (key <= Tcur && row_allowed(ix, allow, allow_bits, lb + j)) skeys[atomicAdd(&s_misc[0], 1u)] = key;
             }
             __syncthreads();
             fill = s_misc[0];
@@ -465,6 +468,7 @@ struct ScanArgs {
     uint64_t *cand;
     uint32_t cap;
     const uint64_t *allow;   // optional allow-bitmap (device), bit = datapoint index
+    uint64_t allow_bits;
 };
 
 template <int NW>
@@ -623,7 +627,7 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 6 : 3)) void adc_scan_kern
                             const uint32_t j = c0 + tid + kScanThreads * i;
                             if (j < size) {
                                 const uint64_t key = make_key(acc[p][i], vb + j);
-                                if (key <= T && row_allowed(ix, a.allow, lb + j)) {
+                                if (key <= T && row_allowed(ix, a.allow, a.allow_bits, lb + j)) {
                                     const uint32_t sl = atomicAdd(&ccnt_s[buf][p], 1u);
                                     if (sl < kScanStage) {
                                         ckey_s[buf][p][sl] = key;
@@ -1351,13 +1355,13 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
     const size_t lds_thr = (size_t)kSampleBuf * sizeof(uint64_t) + (size_t)S * 16 * sizeof(float) + 16;
     SCANN_TRY(set_dyn_lds(sample_threshold_kernel<NW>, lds_thr));
     hipLaunchKernelGGL(sample_threshold_kernel<NW>, dim3(w.nq), dim3(kSelectThreads), lds_thr, st,
-                       ix, w.P, w.m, w.no_threshold, w.tokens, w.vbase, w.slot_of, w.lutq, w.allow, w.thr,
+                       ix, w.P, w.m, w.no_threshold, w.tokens, w.vbase, w.slot_of, w.lutq, w.allow, w.allow_bits, w.thr,
                        w.pair_thr);
     LAUNCH_CHECK();
     ScanArgs a;
     a.pair_off = w.pair_off; a.tile_off = w.tile_off; a.pair_q = w.pair_q;
     a.pair_vbase = w.pair_vbase; a.counters = w.counters; a.lutq = w.lutq; a.pair_thr = w.pair_thr;
-    a.cand_cnt = w.cand_cnt; a.cand = w.cand; a.cap = w.cap; a.allow = w.allow;
+    a.cand_cnt = w.cand_cnt; a.cand = w.cand; a.cap = w.cap; a.allow = w.allow; a.allow_bits = w.allow_bits;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

@@ -89,6 +89,24 @@ static void tree_x_hybrid_tests() {
     bool threw = false;
     try { s.search({1, 2, 3}, 5); } catch (const ScannError &e) { threw = e.code == ErrorCode::InvalidArgument; }
     EXPECT(threw);
+    // search_with_filter (mod.rs:245-294) with restricts/allowlist.rs filters
+    std::vector<DatapointIndex> even;
+    for (DatapointIndex i = 0; i < 500; i += 2) even.push_back(i);
+    auto allow = RestrictAllowlist::from_indices(even, 500);
+    EXPECT(allow.num_allowed() == 250 && allow.is_allowed(4) && !allow.is_allowed(5) && !allow.is_allowed(500));
+    auto fr = s.search_with_filter(q, 10, &allow);
+    EXPECT(fr.size() == 10);
+    sorted(fr);
+    for (auto &p : fr) EXPECT(p.first % 2 == 0);
+    auto deny = RestrictDenylist::from_indices({r[0].first, r[1].first}, 500);
+    auto dr = s.search_with_filter(q, 10, &deny);
+    EXPECT(dr.size() == 10);
+    for (auto &p : dr) EXPECT(p.first != r[0].first && p.first != r[1].first);
+    EXPECT(s.search_with_filter(q, 10, nullptr) == r);
+    auto two = RestrictAllowlist::from_indices({7, 11}, 500);   // fewer allowed than k
+    auto tr = s.search_with_filter(q, 10, &two);
+    EXPECT(tr.size() <= 2);
+    for (auto &p : tr) EXPECT(p.first == 7 || p.first == 11);
     bool empty = false;
     try { TreeXHybridSearcher e(cfg); e.build(DenseDataset()); }
     catch (const ScannError &e) { empty = e.code == ErrorCode::InvalidArgument; }

@@ -100,6 +100,67 @@ private:
     uint32_t dim_ = 0, stride_ = 0;
 };
 
+// ---- restricts (restricts/mod.rs:16-45, restricts/allowlist.rs:8-187) ----------------------------
+struct RestrictFilter {
+    virtual ~RestrictFilter() = default;
+    virtual bool is_allowed(DatapointIndex index) const = 0;
+    // Words of an allow-bitmap covering datapoints [0, n): bit i = is_allowed(i).
+    virtual std::vector<uint64_t> to_bitmap(size_t n) const {
+        std::vector<uint64_t> w((n + 63) / 64, 0);
+        for (size_t i = 0; i < n; ++i)
+            if (is_allowed((DatapointIndex)i)) w[i >> 6] |= 1ull << (i & 63);
+        return w;
+    }
+};
+
+class RestrictAllowlist : public RestrictFilter {   // allowlist.rs:8-105
+public:
+    explicit RestrictAllowlist(size_t capacity) : bits_((capacity + 63) / 64, 0), capacity_(capacity) {}
+    static RestrictAllowlist from_indices(const std::vector<DatapointIndex> &indices, size_t capacity) {
+        RestrictAllowlist a(capacity);
+        for (auto i : indices) a.add(i);
+        return a;
+    }
+    void add(DatapointIndex i) {
+        if (i < capacity_ && !get(i)) { bits_[i >> 6] |= 1ull << (i & 63); ++count_; }
+    }
+    void remove(DatapointIndex i) {
+        if (i < capacity_ && get(i)) { bits_[i >> 6] &= ~(1ull << (i & 63)); --count_; }
+    }
+    void clear() { std::fill(bits_.begin(), bits_.end(), 0); count_ = 0; }
+    size_t capacity() const { return capacity_; }
+    size_t num_allowed() const { return count_; }
+    bool is_allowed(DatapointIndex i) const override { return i < capacity_ && get(i); }
+    std::vector<uint64_t> to_bitmap(size_t n) const override {
+        std::vector<uint64_t> w = bits_;
+        w.resize((n + 63) / 64, 0);
+        if (n & 63) w.back() &= (1ull << (n & 63)) - 1;
+        return w;
+    }
+
+private:
+    bool get(DatapointIndex i) const { return (bits_[i >> 6] >> (i & 63)) & 1ull; }
+    std::vector<uint64_t> bits_;
+    size_t capacity_, count_ = 0;
+};
+
+class RestrictDenylist : public RestrictFilter {    // allowlist.rs:107-187
+public:
+    explicit RestrictDenylist(size_t capacity) : deny_(capacity) {}
+    static RestrictDenylist from_indices(const std::vector<DatapointIndex> &indices, size_t capacity) {
+        RestrictDenylist d(capacity);
+        for (auto i : indices) d.deny(i);
+        return d;
+    }
+    void deny(DatapointIndex i) { deny_.add(i); }
+    void allow(DatapointIndex i) { deny_.remove(i); }
+    void clear() { deny_.clear(); }
+    bool is_allowed(DatapointIndex i) const override { return !deny_.is_allowed(i); }
+
+private:
+    RestrictAllowlist deny_;
+};
+
 namespace detail {
 
 struct IndexHandle {
@@ -449,6 +510,20 @@ public:
         if (!ix_.h) throw ScannError::failed_precondition("Partitioner not built");
         return detail::run_search(ix_.h, query.data(), 1, (uint32_t)query.size(), (uint32_t)query.size(),
                                   (uint32_t)k, nullptr)[0];
+    }
+    // mod.rs:245-294: disallowed datapoints are skipped before scoring.  The filter is
+    // materialised once into an allow-bitmap that the scan kernels test.
+    NNResultsVector search_with_filter(const std::vector<float> &query, size_t k,
+                                       const RestrictFilter *filter) const {
+        if (!filter) return search(query, k);
+        if (!ix_.h) throw ScannError::failed_precondition("Partitioner not built");
+        const auto bits = filter->to_bitmap(num_datapoints());
+        scann_hip_search_opts o;
+        scann_hip_search_opts_default(&o);
+        o.allow_bitmap = bits.data();
+        o.allow_bitmap_bits = bits.size() * 64;
+        return detail::run_search(ix_.h, query.data(), 1, (uint32_t)query.size(), (uint32_t)query.size(),
+                                  (uint32_t)k, &o)[0];
     }
     std::vector<NNResultsVector> search_batched(const std::vector<std::vector<float>> &queries, size_t k) const {
         if (!ix_.h) throw ScannError::failed_precondition("Partitioner not built");

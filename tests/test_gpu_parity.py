@@ -453,3 +453,6 @@ def test_ah_allow_bitmap_filter():
                                                np.ascontiguousarray(data.reshape(n, stride)[allowed]),
                                                stride, q[i], 10, 50)
         H.assert_topk_equal_up_to_ties(idx[i], dist[i], allowed[oi].astype(np.uint32), od)
+    # a bitmap shorter than the dataset: indices >= its capacity are not allowed (allowlist.rs:97-100)
+    idx, dist, cnt = index.search_batched(q, 10, opts=o, allow=bits[:32])
+    assert np.all(cnt == 10) and np.all(idx < 2048) and np.all(idx % 7 == 0)
