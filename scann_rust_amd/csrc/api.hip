@@ -3,6 +3,7 @@
 // search entry point runs the HIP kernels or fails.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -35,7 +36,8 @@ enum IndexKind { KIND_BF = 1, KIND_TXH = 2 };
 struct TxhWorkspace {
     DevBuf queries, cdist, tokens, token_dists, vbase, leaf_cnt, leaf_cursor, pair_off, tile_off,
         counters, pair_q, pair_leaf, pair_vbase, pair_thr, slot_of, lutq, thr, cand_cnt, cand, cand_key,
-        cand_idx, cand_dist, cand_exact, cand_row, cand_count, out_idx, out_dist, out_count, allow;
+        cand_idx, cand_dist, cand_exact, cand_row, cand_count, out_idx, out_dist, out_count, allow,
+        sbase, pair_sbase, stile_off, samp;
 };
 
 struct scann_hip_index {
@@ -343,7 +345,7 @@ int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_
 
 // ---- per-call parameter resolution --------------------------------------------------
 struct TxhCallParams {
-    uint32_t P, m, k, cap;
+    uint32_t P, m, k, cap, st, scap;
     int exact_reorder;
     int no_threshold;
 };
@@ -380,23 +382,17 @@ static int resolve_params(const scann_hip_index *ix, uint32_t k, const scann_hip
     if (o->exact_reorder && !ix->tx.rows)  // hasher.rs:194-197
         return fail(SCANN_HIP_FAILED_PRECONDITION, "Dataset not stored");
     const uint64_t ms = std::min<uint64_t>(std::max<uint64_t>(1, max_stream(ix, P)), 0xFFFFFFFFull);
+    uint32_t st, scap;
+    sample_plan(ms, P, &st, &scap);
     uint64_t cap = ms;
     if (!full_cap) {
-        // upper bound of the survivors of the sampled threshold for every stride a query of
-        // this batch can get (sample_stride is monotone in the stream length)
-        const uint32_t st_max = sample_stride((uint32_t)ms);
-        cap = std::min<uint64_t>(ms, m);
-        for (uint32_t st = 1; st <= st_max; ++st) {
-            const uint32_t j = sample_rank(m, st);
-            uint64_t bound;
-            if (j == 0)
-                bound = (uint64_t)st * kSampleTarget;
-            else
-                bound = (uint64_t)((double)j + 8.0 * std::sqrt((double)j) + 16.0) * st + 256;
-            cap = std::max(cap, bound);
-        }
-        cap = std::min(cap, ms);
+        // upper bound of the survivors of the sampled threshold (rank j of a stride-st sample)
+        const uint32_t j = sample_rank(m, st);
+        cap = (uint64_t)((double)j + 8.0 * std::sqrt((double)j) + 16.0) * st + 256;
+        cap = std::min(std::max<uint64_t>(cap, m), ms);
     }
+    out->st = st;
+    out->scap = scap;
     out->P = P;
     out->m = m;
     out->k = k;
@@ -419,6 +415,10 @@ static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallP
     SCANN_TRY(s.tokens.ensure((size_t)nq * P * 4));
     SCANN_TRY(s.token_dists.ensure((size_t)nq * P * 4));
     SCANN_TRY(s.vbase.ensure((size_t)nq * (P + 1) * 4));
+    SCANN_TRY(s.sbase.ensure((size_t)nq * (P + 2) * 4));
+    SCANN_TRY(s.pair_sbase.ensure((size_t)max_slots * 4));
+    SCANN_TRY(s.stile_off.ensure((size_t)(L + 1) * 4));
+    SCANN_TRY(s.samp.ensure((size_t)nq * p.scap * 4));
     SCANN_TRY(s.leaf_cnt.ensure((size_t)L * 4));
     SCANN_TRY(s.leaf_cursor.ensure((size_t)L * 4));
     SCANN_TRY(s.pair_off.ensure((size_t)(L + 1) * 4));
@@ -460,6 +460,20 @@ static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallP
     w->tokens = s.tokens.as<uint32_t>();
     w->token_dists = s.token_dists.as<float>();
     w->vbase = s.vbase.as<uint32_t>();
+    w->st = p.st;
+    w->scap = p.scap;
+    {   // sample tiles: enough of them to fill the chip (the sample pass is 1/st of the scan)
+        const uint64_t quads = ((uint64_t)nq * P + 3) / 4;
+        const uint64_t chunks = std::max<uint64_t>(1, ((uint64_t)p.scap + kScanTP - 1) / kScanTP);
+        uint32_t qpt = kScanQuadsPerTile;
+        while (qpt > 2 && chunks * ((quads + qpt - 1) / qpt) < 4096) qpt >>= 1;
+        if (const char *e = std::getenv("SCANN_HIP_SQPT")) qpt = (uint32_t)std::max(1, std::atoi(e));
+        w->sqpt = qpt;
+    }
+    w->sbase = s.sbase.as<uint32_t>();
+    w->pair_sbase = s.pair_sbase.as<uint32_t>();
+    w->stile_off = s.stile_off.as<uint32_t>();
+    w->samp = s.samp.as<uint32_t>();
     w->leaf_cnt = s.leaf_cnt.as<uint32_t>();
     w->leaf_cursor = s.leaf_cursor.as<uint32_t>();
     w->pair_off = s.pair_off.as<uint32_t>();

@@ -9,29 +9,60 @@ constexpr uint32_t kScanThreads = 256;
 constexpr uint32_t kScanPPT = 2;                          // points per thread per chunk
 constexpr uint32_t kScanTP = kScanThreads * kScanPPT;     // points per tile chunk
 constexpr uint32_t kScanQuadsPerTile = 32;                // query quads per tile
+#ifndef SCANN_SCAN_DEPTH
+#define SCANN_SCAN_DEPTH 1
+#endif
+#ifndef SCANN_SCAN_WAVES
+#define SCANN_SCAN_WAVES 6
+#endif
+constexpr uint32_t kScanDepth = SCANN_SCAN_DEPTH;         // gather software-pipeline depth (subspaces)
+constexpr uint32_t kScanWaves = SCANN_SCAN_WAVES;         // workgroups per CU = waves per SIMD (S <= 32)
 constexpr uint32_t kSortCap = 16384;                      // u64 keys sorted in LDS (select)
-constexpr uint32_t kSampleBuf = 8192;                     // LDS key buffer of the sampler
-constexpr uint32_t kSampleBest = 4096;                    // max rank taken from the sample
-constexpr uint32_t kSampleTarget = 32768;                 // max sample points per query
-constexpr uint32_t kSampleMin = 4096;                     // min sample points per query
+#ifndef SCANN_SAMPLE_TARGET
+#define SCANN_SAMPLE_TARGET 32768
+#endif
+#ifndef SCANN_SAMPLE_MIN
+#define SCANN_SAMPLE_MIN 4096
+#endif
+constexpr uint32_t kSampleTarget = SCANN_SAMPLE_TARGET;   // max sample points per query (LDS of the select)
+constexpr uint32_t kSampleMin = SCANN_SAMPLE_MIN;         // min sample points per query
+constexpr uint32_t kSampleBins = 4096;                    // histogram bins of the threshold select
+constexpr uint32_t kSampleList = 1024;                    // members of the rank's bin ranked exactly
 constexpr uint32_t kMaxPreReorderK = 8192;                // m limit of the LDS select
 constexpr uint32_t kMaxPartitionsToSearch = 4096;
 constexpr uint32_t kMaxLeavesSelect = 16384;              // L limit of the LDS leaf sort
 constexpr uint32_t kSelectThreads = 1024;
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 
-// ---- threshold sampling plan (shared by host buffer sizing and the device sampler) ----
-// A query whose selected leaves hold `total` local points is sampled every `st`-th
-// point; the threshold is the j-th smallest sample key.  j == m gives a deterministic
-// bound (any subset's m-th smallest key bounds the stream's m-th smallest); j < m is a
-// 6-sigma statistical bound that select_rerank VERIFIES (>= m survivors, else the host
-// entry retries without a threshold), so results stay exact either way.
+// ---- threshold sampling plan (shared by host buffer sizing and the device kernels) ----
+// Every st-th point of each selected leaf is scored ahead of the scan (adc_sample_kernel,
+// the same tiled LUT16 gather as the scan); the threshold is the j-th smallest sample
+// distance (threshold_select_kernel).  One stride per batch, so that all queries of a
+// tile share the sampled points' codes.  j == m gives a deterministic bound (any
+// subset's m-th smallest bounds the stream's m-th smallest); j < m is a 6-sigma
+// statistical bound that select_rerank VERIFIES (>= m survivors, else the host entry
+// retries without a threshold), so results stay exact either way.
 __host__ __device__ static inline uint32_t sample_stride(uint32_t total) {
     uint32_t ns = total / 16u;
     if (ns < kSampleMin) ns = kSampleMin;
     if (ns > kSampleTarget) ns = kSampleTarget;
     uint32_t st = (total + ns - 1u) / ns;
     return st ? st : 1u;
+}
+// Stride and per-query sample capacity for a batch whose longest stream (sum of the P
+// largest local leaves) is max_stream: capacity = max_stream / st + P <= kSampleTarget.
+static inline void sample_plan(uint64_t max_stream, uint32_t P, uint32_t *st_out, uint32_t *scap_out) {
+    const uint32_t ms = (uint32_t)(max_stream > 0xFFFFFFFFull ? 0xFFFFFFFFull : max_stream);
+    uint32_t st = sample_stride(ms);
+    for (;;) {
+        const uint64_t scap = (uint64_t)(ms + st - 1u) / st + P;
+        if (scap <= kSampleTarget || P >= kSampleTarget) {
+            *st_out = st;
+            *scap_out = (uint32_t)(scap < 1 ? 1 : scap);
+            return;
+        }
+        st += 1 + st / 8;
+    }
 }
 // 0 = use no threshold.
 __host__ __device__ static inline uint32_t sample_rank(uint32_t m, uint32_t st) {
@@ -42,7 +73,7 @@ __host__ __device__ static inline uint32_t sample_rank(uint32_t m, uint32_t st) 
     uint32_t j = jp >= (float)m ? m : (uint32_t)jp;
     if (j > m) j = m;
     if (j == 0) j = 1;
-    return j > kSampleBest ? 0u : j;
+    return j;
 }
 
 struct TxhIndexDev {
@@ -61,7 +92,10 @@ struct TxhIndexDev {
 };
 
 // counters[] slots
-enum { CNT_TOTAL_QUADS = 0, CNT_TOTAL_TILES = 1, CNT_QUEUE_HEAD = 2, CNT_STATUS = 3, CNT_N = 8 };
+enum {
+    CNT_TOTAL_QUADS = 0, CNT_TOTAL_TILES = 1, CNT_QUEUE_HEAD = 2, CNT_STATUS = 3,
+    CNT_TOTAL_STILES = 4, CNT_SQUEUE_HEAD = 5, CNT_N = 8
+};
 
 struct TxhWork {
     uint32_t nq, q_stride, P, m, k, cap;
@@ -75,6 +109,11 @@ struct TxhWork {
     uint32_t *tokens;          // [nq][P]
     float *token_dists;        // [nq][P]
     uint32_t *vbase;           // [nq][P+1] prefix of global leaf sizes in token order
+    uint32_t st, scap, sqpt;   // sample stride, per-query sample capacity, quads per sample tile
+    uint32_t *sbase;           // [nq][P+2] prefix of per-leaf sample counts; [P]=samples, [P+1]=local points
+    uint32_t *pair_sbase;      // [max_slots]
+    uint32_t *stile_off;       // [L+1] tile table of the sample pass
+    uint32_t *samp;            // [nq][scap] ordered(approx distance) of the sampled points
     uint32_t *leaf_cnt;        // [L]
     uint32_t *leaf_cursor;     // [L]
     uint32_t *pair_off;        // [L+1] (slots, padded to quads)

@@ -76,8 +76,9 @@ __global__ __launch_bounds__(64) void centroid_scores_kernel(
 // =====================================================================================
 __global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
     const float *__restrict__ cdist, uint32_t L, uint32_t n_pow2, uint32_t P,
-    const uint32_t *__restrict__ leaf_gsize, uint32_t *__restrict__ tokens,
-    float *__restrict__ token_dists, uint32_t *__restrict__ vbase) {
+    const uint32_t *__restrict__ leaf_gsize, const uint32_t *__restrict__ leaf_off, uint32_t st,
+    uint32_t *__restrict__ tokens, float *__restrict__ token_dists, uint32_t *__restrict__ vbase,
+    uint32_t *__restrict__ sbase) {
     extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
     const uint32_t q = blockIdx.x;
     for (uint32_t i = threadIdx.x; i < n_pow2; i += blockDim.x) {
@@ -105,18 +106,35 @@ __global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
         }
         vbase[(size_t)q * (P + 1) + P] = vb;
     }
+    if (threadIdx.x == 64) {   // sample slots: every st-th local point of each selected leaf
+        uint32_t sb = 0, tot = 0;
+        for (uint32_t r = 0; r < P; ++r) {
+            const uint32_t leaf = (uint32_t)skeys[r];
+            const uint32_t sz = leaf_off[leaf + 1] - leaf_off[leaf];
+            sbase[(size_t)q * (P + 2) + r] = sb;
+            sb += (sz + st - 1) / st;
+            tot += sz;
+        }
+        sbase[(size_t)q * (P + 2) + P] = sb;
+        sbase[(size_t)q * (P + 2) + P + 1] = tot;
+    }
 }
 
 // AsymmetricHasher mode: one implicit leaf (id 0) for every query.
 __global__ void ah_tokens_kernel(uint32_t nq, const uint32_t *__restrict__ leaf_gsize,
+                                 const uint32_t *__restrict__ leaf_off, uint32_t st,
                                  uint32_t *__restrict__ tokens, float *__restrict__ token_dists,
-                                 uint32_t *__restrict__ vbase) {
+                                 uint32_t *__restrict__ vbase, uint32_t *__restrict__ sbase) {
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     tokens[q] = 0;
     token_dists[q] = 0.0f;
     vbase[2 * q] = 0;
     vbase[2 * q + 1] = leaf_gsize[0];
+    const uint32_t sz = leaf_off[1] - leaf_off[0];
+    sbase[3 * q] = 0;
+    sbase[3 * q + 1] = (sz + st - 1) / st;
+    sbase[3 * q + 2] = sz;
 }
 
 // =====================================================================================
@@ -134,59 +152,79 @@ __global__ void worklist_count_kernel(uint32_t npairs, const uint32_t *__restric
 
 __global__ __launch_bounds__(1024) void worklist_scan_kernel(
     uint32_t L, const uint32_t *__restrict__ leaf_cnt, const uint32_t *__restrict__ leaf_off,
-    uint32_t tp, uint32_t quads_per_tile, uint32_t *__restrict__ pair_off,
-    uint32_t *__restrict__ tile_off, uint32_t *__restrict__ counters) {
-    __shared__ uint32_t s_pairs[1024], s_tiles[1024];
+    uint32_t tp, uint32_t quads_per_tile, uint32_t st, uint32_t squads_per_tile,
+    uint32_t *__restrict__ pair_off, uint32_t *__restrict__ tile_off,
+    uint32_t *__restrict__ stile_off, uint32_t *__restrict__ counters) {
+    __shared__ uint32_t s_pairs[1024], s_tiles[1024], s_stiles[1024];
     const uint32_t t = threadIdx.x;
     const uint32_t per = (L + 1023) / 1024;
     const uint32_t b = t * per, e = min(L, b + per);
-    uint32_t sp = 0, stl = 0;
+    // tiles of the scan (all points) and of the sample pass (every st-th point)
+    auto tiles_of = [&](uint32_t c, uint32_t pad, uint32_t sz, uint32_t *smp) {
+        if (!c) { *smp = 0; return 0u; }
+        const uint32_t ssz = (sz + st - 1) / st;
+        *smp = ((ssz + tp - 1) / tp) * ((pad / 4 + squads_per_tile - 1) / squads_per_tile);
+        return ((sz + tp - 1) / tp) * ((pad / 4 + quads_per_tile - 1) / quads_per_tile);
+    };
+    uint32_t sp = 0, stl = 0, sst = 0;
     for (uint32_t l = b; l < e; ++l) {
         uint32_t c = leaf_cnt[l];
         uint32_t pad = (c + 3u) & ~3u;
         uint32_t sz = leaf_off[l + 1] - leaf_off[l];
+        uint32_t smp;
         sp += pad;
-        stl += c ? ((sz + tp - 1) / tp) * ((pad / 4 + quads_per_tile - 1) / quads_per_tile) : 0u;
+        stl += tiles_of(c, pad, sz, &smp);
+        sst += smp;
     }
     s_pairs[t] = sp;
     s_tiles[t] = stl;
+    s_stiles[t] = sst;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-        uint32_t a = 0, c2 = 0;
+        uint32_t a = 0, c2 = 0, c3 = 0;
         if (t >= off) {
             a = s_pairs[t - off];
             c2 = s_tiles[t - off];
+            c3 = s_stiles[t - off];
         }
         __syncthreads();
         s_pairs[t] += a;
         s_tiles[t] += c2;
+        s_stiles[t] += c3;
         __syncthreads();
     }
-    uint32_t bp = s_pairs[t] - sp, bt = s_tiles[t] - stl;
+    uint32_t bp = s_pairs[t] - sp, bt = s_tiles[t] - stl, bs = s_stiles[t] - sst;
     for (uint32_t l = b; l < e; ++l) {
         uint32_t c = leaf_cnt[l];
         uint32_t pad = (c + 3u) & ~3u;
         uint32_t sz = leaf_off[l + 1] - leaf_off[l];
+        uint32_t smp;
         pair_off[l] = bp;
         tile_off[l] = bt;
+        stile_off[l] = bs;
         bp += pad;
-        bt += c ? ((sz + tp - 1) / tp) * ((pad / 4 + quads_per_tile - 1) / quads_per_tile) : 0u;
+        bt += tiles_of(c, pad, sz, &smp);
+        bs += smp;
     }
     if (t == 1023) {
         pair_off[L] = s_pairs[1023];
         tile_off[L] = s_tiles[1023];
+        stile_off[L] = s_stiles[1023];
         counters[CNT_TOTAL_QUADS] = s_pairs[1023] / 4;
         counters[CNT_TOTAL_TILES] = s_tiles[1023];
+        counters[CNT_TOTAL_STILES] = s_stiles[1023];
     }
 }
 
 __global__ void worklist_fill_kernel(uint32_t nq, uint32_t P, const uint32_t *__restrict__ tokens,
                                      const uint32_t *__restrict__ vbase,
+                                     const uint32_t *__restrict__ sbase,
                                      const uint32_t *__restrict__ leaf_off,
                                      const uint32_t *__restrict__ pair_off,
                                      uint32_t *__restrict__ leaf_cursor,
                                      uint32_t *__restrict__ pair_q, uint32_t *__restrict__ pair_leaf,
                                      uint32_t *__restrict__ pair_vbase,
+                                     uint32_t *__restrict__ pair_sbase,
                                      uint32_t *__restrict__ slot_of) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq * P) return;
@@ -198,6 +236,7 @@ __global__ void worklist_fill_kernel(uint32_t nq, uint32_t P, const uint32_t *__
         pair_q[slot] = q;
         pair_leaf[slot] = leaf;
         pair_vbase[slot] = vbase[(size_t)q * (P + 1) + r];
+        pair_sbase[slot] = sbase[(size_t)q * (P + 2) + r];
     }
     slot_of[i] = slot;
 }
@@ -300,100 +339,6 @@ __device__ __forceinline__ float adc_row_sum(const float *lut, const uint32_t *w
 }
 
 // =====================================================================================
-// K5: threshold from a strided sample (plan: sample_stride / sample_rank in txh.h).
-// One block per query streams up to kSampleTarget sampled points through an LDS buffer
-// that keeps the J best keys seen so far: new keys enter only if <= the current J-th
-// best, and the buffer is sorted and cut back to J whenever it could overflow.
-// =====================================================================================
-template <int NW>
-__global__ __launch_bounds__(kSelectThreads) void sample_threshold_kernel(
-    TxhIndexDev ix, uint32_t P, uint32_t m, int no_threshold,
-    const uint32_t *__restrict__ tokens, const uint32_t *__restrict__ vbase,
-    const uint32_t *__restrict__ slot_of, const float *__restrict__ lutq,
-    const uint64_t *__restrict__ allow, uint64_t allow_bits, uint64_t *__restrict__ thr,
-    uint64_t *__restrict__ pair_thr) {
-    constexpr int S = NW * 8;
-    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];      // [kSampleBuf]
-    float *slut = reinterpret_cast<float *>(skeys + kSampleBuf);          // [S*16]
-    uint32_t *s_misc = reinterpret_cast<uint32_t *>(slut + S * 16);       // [0]=fill [1]=total
-    const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    if (tid == 0) {
-        uint32_t tot = 0;
-        for (uint32_t r = 0; r < P; ++r) {
-            uint32_t leaf = tokens[(size_t)q * P + r];
-            tot += ix.leaf_off[leaf + 1] - ix.leaf_off[leaf];
-        }
-        s_misc[1] = tot;
-        s_misc[0] = 0;
-    }
-    __syncthreads();
-    const uint32_t total = s_misc[1];
-    const uint32_t st = sample_stride(total);
-    const uint32_t J = (no_threshold || total <= m) ? 0u : sample_rank(m, st);
-    // the scan reads the bound per (query, leaf) pair slot: no dependent pair_q -> thr load
-    auto publish = [&](uint64_t T) {
-        if (tid == 0) thr[q] = T;
-        for (uint32_t r = tid; r < P; r += nt) {
-            const uint32_t sl = slot_of[(size_t)q * P + r];
-            if (sl != kInvalid) pair_thr[sl] = T;
-        }
-    };
-    if (J == 0) {   // uniform
-        publish(SCANN_KEY_MAX);
-        return;
-    }
-    uint32_t B = 2048;
-    while (B < 4 * J && B < kSampleBuf) B <<= 1;       // B >= J + nt always (J <= 4096)
-    uint64_t Tcur = SCANN_KEY_MAX;
-    uint32_t fill = 0;
-
-    auto compact = [&]() {   // sort the buffer, keep the J best; every thread calls
-        uint32_t n2 = 1;
-        while (n2 < fill) n2 <<= 1;
-        for (uint32_t i = fill + tid; i < n2; i += nt) skeys[i] = SCANN_KEY_MAX;
-        __syncthreads();
-        bitonic_sort_lds(skeys, n2);
-        if (fill > J) {
-            fill = J;
-            Tcur = skeys[J - 1];
-        }
-        __syncthreads();
-        if (tid == 0) s_misc[0] = fill;
-        __syncthreads();
-    };
-
-    for (uint32_t r = 0; r < P; ++r) {
-        const uint32_t leaf = tokens[(size_t)q * P + r];
-        const uint32_t lb = ix.leaf_off[leaf];
-        const uint32_t sz = ix.leaf_off[leaf + 1] - lb;
-        if (sz == 0) continue;
-        const uint32_t slot = slot_of[(size_t)q * P + r];
-        const float *src = lutq + (size_t)(slot >> 2) * S * 64 + (slot & 3u);
-        for (uint32_t e = tid; e < S * 16; e += nt) slut[e] = src[(size_t)e * 4];
-        __syncthreads();
-        const uint32_t ns = (sz + st - 1) / st;
-        const uint32_t vb = vbase[(size_t)q * (P + 1) + r];
-        for (uint32_t base = 0; base < ns; base += nt) {
-            if (fill + nt > B) compact();
-            const uint32_t i = base + tid;
-            if (i < ns) {
-                const uint32_t j = i * st;
-                uint32_t w[NW];
-#pragma unroll
-                for (int wi = 0; wi < NW; ++wi) w[wi] = ix.codes[(size_t)(lb + j) * NW + wi];
-                const uint64_t key = make_key(adc_row_sum<NW>(slut, w), vb + j);
-                if (key <= Tcur && row_allowed(ix, allow, allow_bits, lb + j)) skeys[atomicAdd(&s_misc[0], 1u)] = key;
-            }
-            __syncthreads();
-            fill = s_misc[0];
-        }
-        __syncthreads();
-    }
-    compact();
-    publish((fill >= J) ? skeys[J - 1] : SCANN_KEY_MAX);
-}
-
-// =====================================================================================
 // K6: ADC scan -- the dominant kernel.  hashes/lut.rs:74-82 driven by the loop at
 // tree_x_hybrid/mod.rs:324-336 / hashes/hasher.rs:179-182.
 //
@@ -422,10 +367,12 @@ __device__ __forceinline__ void scan_quad_compute(const float4 *lut_base,
             asm volatile("" : "+v"(wlo[i][wi]));
             asm volatile("" : "+v"(whi[i][wi]));
         }
-    // Software pipeline, one subspace deep: the NP ds_read_b128 of subspace s+1 are in
-    // flight while subspace s is accumulated.  sched_barrier(0) pins the stage order so
-    // the scheduler cannot hoist every gather to the top (256 VGPRs, occupancy 1).
-    float4 v[2][NP];
+    // Software pipeline, kScanDepth subspaces deep: the NP ds_read_b128 of subspaces
+    // s+1 .. s+D are in flight while subspace s is accumulated.  sched_barrier(0) pins the
+    // stage order so the scheduler cannot hoist every gather to the top (256 VGPRs,
+    // occupancy 1).
+    constexpr int D = (int)kScanDepth;
+    float4 v[D + 1][NP];
     auto issue = [&](int s, int slot) {
         const int wi = s >> 3, b = (s >> 1) & 3, h = s & 1;
 #pragma unroll
@@ -434,6 +381,44 @@ __device__ __forceinline__ void scan_quad_compute(const float4 *lut_base,
             const uint32_t off = (x >> (8 * b)) & 0xFFu;  // code * 16
             v[slot][i] = *reinterpret_cast<const float4 *>(lb + s * 256 + off);
         }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < S) issue(d, d);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (s + D < S) issue(s + D, (s + D) % (D + 1));
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const float4 t = v[s % (D + 1)][i];
+            if (s == 0) {
+                acc[0][i] = t.x; acc[1][i] = t.y; acc[2][i] = t.z; acc[3][i] = t.w;
+            } else {
+                acc[0][i] = acc[0][i] + t.x;
+                acc[1][i] = acc[1][i] + t.y;
+                acc[2][i] = acc[2][i] + t.z;
+                acc[3][i] = acc[3][i] + t.w;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Variant with the LDS byte offsets (code * 16) of every (point, subspace) precomputed once
+// per tile: the quad loop is then ds_read_b128 + 2 v_pk_add_f32 per lookup and nothing else
+// (the byte extraction above costs a third VALU op per lookup, and the VALU is the co-limiter
+// of this kernel).  S * NP address registers: used for S <= 32 at 4 waves/SIMD.
+template <int NW, int NP, int BUF>
+__device__ __forceinline__ void scan_quad_compute_h(const float4 *lut_base,
+                                                    const uint32_t (&ad)[kScanPPT][NW * 8],
+                                                    float (&acc)[4][kScanPPT]) {
+    constexpr int S = NW * 8;
+    const char *lb = reinterpret_cast<const char *>(lut_base + BUF * S * 16);
+    float4 v[2][NP];
+    auto issue = [&](int s, int slot) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            v[slot][i] = *reinterpret_cast<const float4 *>(lb + s * 256 + ad[i][s]);
     };
     issue(0, 0);
 #pragma unroll
@@ -455,6 +440,14 @@ __device__ __forceinline__ void scan_quad_compute(const float4 *lut_base,
     }
 }
 
+// Load through the constant address space: with a wave-uniform address the compiler emits
+// s_load (SMEM, SGPR result) instead of a vector load + v_readfirstlane.  Only for buffers
+// that no thread of the running kernel writes.
+template <typename T>
+__device__ __forceinline__ T uniform_load(const T *p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>((uint64_t)p);
+}
+
 static_assert(kScanPPT <= 4, "adc_scan_kernel's nsub switch handles up to 4 points per thread");
 constexpr uint32_t kScanStage = 128;   // LDS-staged survivors per (quad, query); <= kScanThreads
 static_assert(kScanStage <= kScanThreads, "the flush copies one survivor per thread");
@@ -472,8 +465,9 @@ struct ScanArgs {
 };
 
 template <int NW>
-__global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 6 : 3)) void adc_scan_kernel(TxhIndexDev ix, ScanArgs a) {
+__global__ __launch_bounds__(kScanThreads, (NW <= 4 ? kScanWaves : 3)) void adc_scan_kernel(TxhIndexDev ix, ScanArgs a) {
     constexpr int S = NW * 8;
+    constexpr bool HOIST = false;                                 // see scan_quad_compute_h
     constexpr int LUT4 = S * 16;                                    // float4 per quad
     constexpr int STG = (LUT4 + kScanThreads - 1) / kScanThreads;   // staged float4 / thread
     __shared__ float4 lut_s[2 * LUT4];
@@ -500,16 +494,16 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 6 : 3)) void adc_scan_kern
         uint32_t lo = 0, hi = ix.L;
         while (hi - lo > 1) {
             uint32_t mid = (lo + hi) >> 1;
-            if (a.tile_off[mid] <= tile) lo = mid; else hi = mid;
+            if (uniform_load(a.tile_off + mid) <= tile) lo = mid; else hi = mid;
         }
         const uint32_t leaf = lo;
-        const uint32_t lb = ix.leaf_off[leaf];
-        const uint32_t size = ix.leaf_off[leaf + 1] - lb;
+        const uint32_t lb = uniform_load(ix.leaf_off + leaf);
+        const uint32_t size = uniform_load(ix.leaf_off + leaf + 1) - lb;
         const uint32_t nchunks = (size + kScanTP - 1) / kScanTP;
-        const uint32_t local = tile - a.tile_off[leaf];
+        const uint32_t local = tile - uniform_load(a.tile_off + leaf);
         const uint32_t chunk = local % nchunks, qg = local / nchunks;
-        const uint32_t slot0 = a.pair_off[leaf];
-        const uint32_t nquads = (a.pair_off[leaf + 1] - slot0) >> 2;
+        const uint32_t slot0 = uniform_load(a.pair_off + leaf);
+        const uint32_t nquads = (uniform_load(a.pair_off + leaf + 1) - slot0) >> 2;
         const uint32_t q0 = qg * kScanQuadsPerTile;
         const uint32_t q1 = min(q0 + kScanQuadsPerTile, nquads);
         const uint32_t c0 = chunk * kScanTP;
@@ -518,6 +512,7 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 6 : 3)) void adc_scan_kern
 
         // packed codes of this lane's points -> byte-per-subspace form (code * 16)
         uint32_t wlo[kScanPPT][NW], whi[kScanPPT][NW];
+        uint32_t ad[kScanPPT][HOIST ? S : 1];
 #pragma unroll
         for (int i = 0; i < (int)kScanPPT; ++i) {
             const uint32_t j = c0 + tid + kScanThreads * i;
@@ -538,6 +533,13 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 6 : 3)) void adc_scan_kern
                 wlo[i][wi] = (w[wi] & 0x0F0F0F0Fu) << 4;
                 whi[i][wi] = w[wi] & 0xF0F0F0F0u;
             }
+            if constexpr (HOIST) {
+#pragma unroll
+                for (int sub = 0; sub < S; ++sub) {
+                    const uint32_t x = (sub & 1) ? whi[i][sub >> 3] : wlo[i][sub >> 3];
+                    ad[i][sub] = (x >> (8 * ((sub >> 1) & 3))) & 0xFFu;
+                }
+            }
         }
 
         const float4 *gl = reinterpret_cast<const float4 *>(a.lutq) +
@@ -556,6 +558,20 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 6 : 3)) void adc_scan_kern
                 if (e < (uint32_t)LUT4) lut_s[e] = r[t];
             }
         }
+        // wave-uniform filter parameters of a quad (SGPRs via s_load): query, key base, bound
+        uint32_t f_pq[4], f_vb[4], f_thi[4], f_tlo[4];
+        auto fetch_params = [&](uint32_t qd) {
+            const uint32_t slot = slot0 + qd * 4;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                f_pq[p] = uniform_load(a.pair_q + slot + p);
+                f_vb[p] = uniform_load(a.pair_vbase + slot + p);
+                const uint64_t T = uniform_load(a.pair_thr + slot + p);
+                f_thi[p] = (uint32_t)(T >> 32);
+                f_tlo[p] = (uint32_t)T;
+            }
+        };
+        if (q0 < q1) fetch_params(q0);
         __syncthreads();
 
         for (uint32_t qd = q0; qd <= q1; ++qd) {   // one extra trip flushes the last quad
@@ -584,32 +600,33 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 6 : 3)) void adc_scan_kern
                             16, 0, 0);
                 }
             }
-            // A3. wave-uniform filter parameters of this quad, fetched ahead of the gather
-            uint32_t f_pq[4], f_vb[4], f_thi[4], f_tlo[4];
-            if (live) {
-                const uint32_t slot = slot0 + qd * 4;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    f_pq[p] = __builtin_amdgcn_readfirstlane(a.pair_q[slot + p]);
-                    f_vb[p] = __builtin_amdgcn_readfirstlane(a.pair_vbase[slot + p]);
-                    const uint64_t T = a.pair_thr[slot + p];
-                    f_thi[p] = __builtin_amdgcn_readfirstlane((uint32_t)(T >> 32));
-                    f_tlo[p] = __builtin_amdgcn_readfirstlane((uint32_t)T);
-                }
-            }
 
             if (live) {
                 // B. gather + accumulate
                 float acc[4][kScanPPT];
-                if (buf == 0) {
-                    switch (nsub) {
-                        case 1: scan_quad_compute<NW, 1, 0>(lut_s, wlo, whi, acc); break;
-                        default: scan_quad_compute<NW, (kScanPPT < 2 ? 1 : 2), 0>(lut_s, wlo, whi, acc); break;
+                if constexpr (HOIST) {
+                    if (buf == 0) {
+                        switch (nsub) {
+                            case 1: scan_quad_compute_h<NW, 1, 0>(lut_s, ad, acc); break;
+                            default: scan_quad_compute_h<NW, (kScanPPT < 2 ? 1 : 2), 0>(lut_s, ad, acc); break;
+                        }
+                    } else {
+                        switch (nsub) {
+                            case 1: scan_quad_compute_h<NW, 1, 1>(lut_s, ad, acc); break;
+                            default: scan_quad_compute_h<NW, (kScanPPT < 2 ? 1 : 2), 1>(lut_s, ad, acc); break;
+                        }
                     }
                 } else {
-                    switch (nsub) {
-                        case 1: scan_quad_compute<NW, 1, 1>(lut_s, wlo, whi, acc); break;
-                        default: scan_quad_compute<NW, (kScanPPT < 2 ? 1 : 2), 1>(lut_s, wlo, whi, acc); break;
+                    if (buf == 0) {
+                        switch (nsub) {
+                            case 1: scan_quad_compute<NW, 1, 0>(lut_s, wlo, whi, acc); break;
+                            default: scan_quad_compute<NW, (kScanPPT < 2 ? 1 : 2), 0>(lut_s, wlo, whi, acc); break;
+                        }
+                    } else {
+                        switch (nsub) {
+                            case 1: scan_quad_compute<NW, 1, 1>(lut_s, wlo, whi, acc); break;
+                            default: scan_quad_compute<NW, (kScanPPT < 2 ? 1 : 2), 1>(lut_s, wlo, whi, acc); break;
+                        }
                     }
                 }
                 // threshold filter: survivors go to the LDS stage of this quad
@@ -641,6 +658,8 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 6 : 3)) void adc_scan_kern
                     }
                 }
             }
+            // A3. the next quad's filter parameters (in flight across the barrier below)
+            if (more) fetch_params(qd + 1);
 
             // C. publish the flush parameters, reset the flushed buffer's live counters
             if (tid < 4) {
@@ -665,6 +684,273 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? 6 : 3)) void adc_scan_kern
             __syncthreads();
         }
     }
+}
+
+// =====================================================================================
+// K5: threshold from a strided sample (plan: sample_stride / sample_plan / sample_rank).
+//
+// K5a adc_sample_kernel: the scan's tiled LUT16 gather over every st-th point of each
+// selected leaf.  Tiles = (leaf, chunk of kScanTP SAMPLED points, group of a.qpt query
+// quads); the ordered approximate distance of sample i of (query, leaf) goes to
+// samp[query][sbase(query, leaf) + i].  Points the allow-bitmap rejects are written as
+// 0xFFFFFFFF (absent).
+// K5b threshold_select_kernel: block per query; the j-th smallest sample by one LDS
+// histogram over [min, max] of the sample + an exact rank inside the j-th's bin.
+// =====================================================================================
+struct SampleArgs {
+    const uint32_t *pair_off, *stile_off, *pair_q, *pair_sbase;
+    uint32_t *counters;
+    const float *lutq;
+    uint32_t *samp;
+    uint32_t scap, st, qpt;
+    const uint64_t *allow;
+    uint64_t allow_bits;
+};
+
+template <int NW>
+__global__ __launch_bounds__(kScanThreads, (NW <= 4 ? kScanWaves : 3)) void adc_sample_kernel(TxhIndexDev ix, SampleArgs a) {
+    constexpr int S = NW * 8;
+    constexpr int LUT4 = S * 16;
+    constexpr int STG = (LUT4 + kScanThreads - 1) / kScanThreads;
+    __shared__ float4 lut_s[2 * LUT4];
+    __shared__ uint32_t tile_sh;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t total_tiles = a.counters[CNT_TOTAL_STILES];
+    const uint32_t st = a.st;
+
+    for (;;) {
+        if (tid == 0) tile_sh = atomicAdd(&a.counters[CNT_SQUEUE_HEAD], 1u);
+        __syncthreads();
+        const uint32_t tile = __builtin_amdgcn_readfirstlane(tile_sh);
+        if (tile >= total_tiles) break;
+
+        uint32_t lo = 0, hi = ix.L;   // leaf = largest l with stile_off[l] <= tile
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (a.stile_off[mid] <= tile) lo = mid; else hi = mid;
+        }
+        const uint32_t leaf = lo;
+        const uint32_t lb = ix.leaf_off[leaf];
+        const uint32_t size = ix.leaf_off[leaf + 1] - lb;
+        const uint32_t ssize = (size + st - 1) / st;            // sampled points of the leaf
+        const uint32_t nchunks = (ssize + kScanTP - 1) / kScanTP;
+        const uint32_t local = tile - a.stile_off[leaf];
+        const uint32_t chunk = local % nchunks, qg = local / nchunks;
+        const uint32_t slot0 = a.pair_off[leaf];
+        const uint32_t nquads = (a.pair_off[leaf + 1] - slot0) >> 2;
+        const uint32_t q0 = qg * a.qpt;
+        const uint32_t q1 = min(q0 + a.qpt, nquads);
+        const uint32_t c0 = chunk * kScanTP;
+        const uint32_t npts = min(kScanTP, ssize - c0);
+        const uint32_t nsub = (npts + kScanThreads - 1) / kScanThreads;
+
+        uint32_t wlo[kScanPPT][NW], whi[kScanPPT][NW];
+        bool ok[kScanPPT];
+#pragma unroll
+        for (int i = 0; i < (int)kScanPPT; ++i) {
+            const uint32_t j = c0 + tid + kScanThreads * i;
+            const uint32_t row = lb + (j < ssize ? j * st : 0u);
+            ok[i] = j < ssize && row_allowed(ix, a.allow, a.allow_bits, row);
+            const uint32_t *src = ix.codes + (size_t)row * NW;
+#pragma unroll
+            for (int wi = 0; wi < NW; ++wi) {
+                const uint32_t w = src[wi];
+                wlo[i][wi] = (w & 0x0F0F0F0Fu) << 4;
+                whi[i][wi] = w & 0xF0F0F0F0u;
+            }
+        }
+
+        const float4 *gl = reinterpret_cast<const float4 *>(a.lutq) +
+                           (size_t)((slot0 >> 2) + q0) * LUT4;
+        {
+            float4 r[STG];
+#pragma unroll
+            for (int t = 0; t < STG; ++t) {
+                uint32_t e = tid + t * kScanThreads;
+                if (e < (uint32_t)LUT4) r[t] = gl[e];
+            }
+#pragma unroll
+            for (int t = 0; t < STG; ++t) {
+                uint32_t e = tid + t * kScanThreads;
+                if (e < (uint32_t)LUT4) lut_s[e] = r[t];
+            }
+        }
+        __syncthreads();
+
+        for (uint32_t qd = q0; qd < q1; ++qd) {
+            const uint32_t buf = (qd - q0) & 1u;
+            if (qd + 1 < q1) {   // LDS-DMA prefetch of the next quad's LUT into the idle buffer
+                const float4 *g2 = gl + (size_t)(qd + 1 - q0) * LUT4;
+#pragma unroll
+                for (int t = 0; t < STG; ++t) {
+                    const uint32_t e0 = (tid & ~63u) + t * kScanThreads;   // wave-uniform
+                    if (e0 < (uint32_t)LUT4)
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void *)(g2 + e0 + (tid & 63u)),
+                            (__attribute__((address_space(3))) void *)(&lut_s[(buf ^ 1u) * LUT4 + e0]),
+                            16, 0, 0);
+                }
+            }
+            const uint32_t slot = slot0 + qd * 4;
+            uint32_t f_pq[4], f_sb[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                f_pq[p] = __builtin_amdgcn_readfirstlane(a.pair_q[slot + p]);
+                f_sb[p] = __builtin_amdgcn_readfirstlane(a.pair_sbase[slot + p]);
+            }
+            float acc[4][kScanPPT];
+            if (buf == 0) {
+                switch (nsub) {
+                    case 1: scan_quad_compute<NW, 1, 0>(lut_s, wlo, whi, acc); break;
+                    default: scan_quad_compute<NW, (kScanPPT < 2 ? 1 : 2), 0>(lut_s, wlo, whi, acc); break;
+                }
+            } else {
+                switch (nsub) {
+                    case 1: scan_quad_compute<NW, 1, 1>(lut_s, wlo, whi, acc); break;
+                    default: scan_quad_compute<NW, (kScanPPT < 2 ? 1 : 2), 1>(lut_s, wlo, whi, acc); break;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (f_pq[p] == kInvalid) continue;   // wave-uniform
+                uint32_t *dst = a.samp + (size_t)f_pq[p] * a.scap + f_sb[p];
+#pragma unroll
+                for (int i = 0; i < (int)kScanPPT; ++i) {
+                    const uint32_t j = c0 + tid + kScanThreads * i;
+                    if (i < (int)nsub && j < ssize) dst[j] = ok[i] ? f32_to_ordered(acc[p][i]) : 0xFFFFFFFFu;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA prefetch has landed
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(kSelectThreads) void threshold_select_kernel(
+    uint32_t P, uint32_t m, uint32_t st, int no_threshold, const uint32_t *__restrict__ sbase,
+    const uint32_t *__restrict__ samp, uint32_t scap, const uint32_t *__restrict__ slot_of,
+    uint64_t *__restrict__ thr, uint64_t *__restrict__ pair_thr) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_vals[];   // [scap]
+    uint32_t *s_hist = s_vals + ((scap + 3u) & ~3u);                    // [kSampleBins]
+    uint32_t *s_list = s_hist + kSampleBins;                            // [kSampleList]
+    uint32_t *s_red = s_list + kSampleList;                             // [64]
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = nt >> 6;
+    const uint32_t ns = min(sbase[(size_t)q * (P + 2) + P], scap);
+    const uint32_t total = sbase[(size_t)q * (P + 2) + P + 1];
+    const uint32_t J = (no_threshold || total <= m) ? 0u : sample_rank(m, st);
+    // the scan reads the bound per (query, leaf) pair slot: no dependent pair_q -> thr load
+    auto publish = [&](uint64_t T) {
+        if (tid == 0) thr[q] = T;
+        for (uint32_t r = tid; r < P; r += nt) {
+            const uint32_t sl = slot_of[(size_t)q * P + r];
+            if (sl != kInvalid) pair_thr[sl] = T;
+        }
+    };
+    if (J == 0 || ns < J) {   // block-uniform
+        publish(SCANN_KEY_MAX);
+        return;
+    }
+    // 1. sample -> LDS; min, max and count of the present values
+    uint32_t vmin = 0xFFFFFFFFu, vmax = 0u, cnt = 0;
+    for (uint32_t i = tid; i < ns; i += nt) {
+        const uint32_t v = samp[(size_t)q * scap + i];
+        s_vals[i] = v;
+        if (v != 0xFFFFFFFFu) {
+            vmin = min(vmin, v);
+            vmax = max(vmax, v);
+            ++cnt;
+        }
+    }
+    for (uint32_t i = tid; i < kSampleBins; i += nt) s_hist[i] = 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        vmin = min(vmin, (uint32_t)__shfl_xor((int)vmin, o));
+        vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, o));
+        cnt += (uint32_t)__shfl_xor((int)cnt, o);
+    }
+    if (lane == 0) {
+        s_red[wave] = vmin;
+        s_red[16 + wave] = vmax;
+        s_red[32 + wave] = cnt;
+    }
+    __syncthreads();
+    vmin = 0xFFFFFFFFu; vmax = 0; cnt = 0;
+    for (uint32_t w2 = 0; w2 < nwaves; ++w2) {
+        vmin = min(vmin, s_red[w2]);
+        vmax = max(vmax, s_red[16 + w2]);
+        cnt += s_red[32 + w2];
+    }
+    if (cnt < J) {            // block-uniform (every thread reduced the same values)
+        publish(SCANN_KEY_MAX);
+        return;
+    }
+    // 2. histogram of (v - vmin) >> sh: monotone in v, < kSampleBins bins
+    const uint32_t range = vmax - vmin;
+    uint32_t sh = 0;
+    while ((range >> sh) >= kSampleBins) ++sh;
+    for (uint32_t i = tid; i < ns; i += nt) {
+        const uint32_t v = s_vals[i];
+        if (v != 0xFFFFFFFFu) atomicAdd(&s_hist[(v - vmin) >> sh], 1u);
+    }
+    __syncthreads();
+    // 3. bin of the J-th smallest: block-wide inclusive scan of per-thread bin groups
+    const uint32_t per = (kSampleBins + nt - 1) / nt;
+    const uint32_t b0 = tid * per, b1 = min(b0 + per, kSampleBins);
+    uint32_t mine = 0;
+    for (uint32_t b = b0; b < b1; ++b) mine += s_hist[b];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+        if ((int)lane >= o) incl += up;
+    }
+    __syncthreads();          // s_red is re-used
+    if (lane == 63) s_red[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t w2 = 0; w2 < wave; ++w2) wbase += s_red[w2];
+    incl += wbase;
+    const uint32_t excl = incl - mine;
+    if (excl < J && J <= incl) {   // exactly one thread
+        uint32_t c = excl;
+        for (uint32_t b = b0; b < b1; ++b) {
+            const uint32_t h = s_hist[b];
+            if (c + h >= J) {
+                s_red[48] = b;
+                s_red[49] = J - c;      // 1-based rank inside the bin
+                s_red[50] = h;
+                break;
+            }
+            c += h;
+        }
+        s_red[51] = 0;                  // list fill
+    }
+    __syncthreads();
+    const uint32_t bin = s_red[48], rank = s_red[49], pop = s_red[50];
+    const uint32_t bin_hi = vmin + (uint32_t)min((uint64_t)0xFFFFFFFFull - vmin,
+                                                 (((uint64_t)bin + 1) << sh) - 1);
+    if (pop > kSampleList) {   // crowded bin: its upper edge bounds the J-th smallest
+        publish(((uint64_t)bin_hi << 32) | 0xFFFFFFFFull);
+        return;
+    }
+    // 4. exact rank among the bin's members
+    for (uint32_t i = tid; i < ns; i += nt) {
+        const uint32_t v = s_vals[i];
+        if (v != 0xFFFFFFFFu && ((v - vmin) >> sh) == bin) s_list[atomicAdd(&s_red[51], 1u)] = v;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < pop; i += nt) {
+        const uint32_t v = s_list[i];
+        uint32_t r = 0;
+        for (uint32_t j2 = 0; j2 < pop; ++j2) {
+            const uint32_t u = s_list[j2];
+            r += (u < v || (u == v && j2 < i)) ? 1u : 0u;
+        }
+        if (r + 1 == rank) s_red[52] = v;
+    }
+    __syncthreads();
+    publish(((uint64_t)s_red[52] << 32) | 0xFFFFFFFFull);
 }
 
 // =====================================================================================
@@ -1325,7 +1611,7 @@ static int set_dyn_lds(F kernel, size_t bytes) {
 static int launch_partition_stage(const TxhIndexDev &ix, const TxhWork &w, hipStream_t st) {
     if (ix.ah_mode) {
         hipLaunchKernelGGL(ah_tokens_kernel, dim3(ceil_div_u32(w.nq, 256)), dim3(256), 0, st, w.nq,
-                           ix.leaf_gsize, w.tokens, w.token_dists, w.vbase);
+                           ix.leaf_gsize, ix.leaf_off, w.st, w.tokens, w.token_dists, w.vbase, w.sbase);
         LAUNCH_CHECK();
         return SCANN_HIP_OK;
     }
@@ -1339,7 +1625,8 @@ static int launch_partition_stage(const TxhIndexDev &ix, const TxhWork &w, hipSt
     const size_t lds2 = (size_t)n2 * sizeof(uint64_t);
     SCANN_TRY(set_dyn_lds(select_leaves_kernel, lds2));
     hipLaunchKernelGGL(select_leaves_kernel, dim3(w.nq), dim3(kSelectThreads), lds2, st, w.cdist,
-                       ix.L, n2, w.P, ix.leaf_gsize, w.tokens, w.token_dists, w.vbase);
+                       ix.L, n2, w.P, ix.leaf_gsize, ix.leaf_off, w.st, w.tokens, w.token_dists, w.vbase,
+                       w.sbase);
     LAUNCH_CHECK();
     return SCANN_HIP_OK;
 }
@@ -1351,20 +1638,29 @@ int txh_launch_partition_only(const TxhIndexDev &ix, const TxhWork &w, hipStream
 template <int NW>
 static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream_t st,
                               hipEvent_t ev0, hipEvent_t ev1) {
-    constexpr int S = NW * 8;
-    const size_t lds_thr = (size_t)kSampleBuf * sizeof(uint64_t) + (size_t)S * 16 * sizeof(float) + 16;
-    SCANN_TRY(set_dyn_lds(sample_threshold_kernel<NW>, lds_thr));
-    hipLaunchKernelGGL(sample_threshold_kernel<NW>, dim3(w.nq), dim3(kSelectThreads), lds_thr, st,
-                       ix, w.P, w.m, w.no_threshold, w.tokens, w.vbase, w.slot_of, w.lutq, w.allow, w.allow_bits, w.thr,
-                       w.pair_thr);
-    LAUNCH_CHECK();
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (!w.no_threshold) {
+        SampleArgs sa;
+        sa.pair_off = w.pair_off; sa.stile_off = w.stile_off; sa.pair_q = w.pair_q;
+        sa.pair_sbase = w.pair_sbase; sa.counters = w.counters; sa.lutq = w.lutq; sa.samp = w.samp;
+        sa.scap = w.scap; sa.st = w.st; sa.qpt = w.sqpt; sa.allow = w.allow; sa.allow_bits = w.allow_bits;
+        hipLaunchKernelGGL(adc_sample_kernel<NW>, dim3((uint32_t)cus * 8u), dim3(kScanThreads), 0, st, ix, sa);
+        LAUNCH_CHECK();
+    }
+    {
+        const size_t lds_thr = ((size_t)((w.scap + 3u) & ~3u) + kSampleBins + kSampleList + 64) * 4;
+        const uint32_t nt = w.scap > 8192 ? kSelectThreads : 256u;
+        SCANN_TRY(set_dyn_lds(threshold_select_kernel, lds_thr));
+        hipLaunchKernelGGL(threshold_select_kernel, dim3(w.nq), dim3(nt), lds_thr, st, w.P, w.m, w.st,
+                           w.no_threshold, w.sbase, w.samp, w.scap, w.slot_of, w.thr, w.pair_thr);
+        LAUNCH_CHECK();
+    }
     ScanArgs a;
     a.pair_off = w.pair_off; a.tile_off = w.tile_off; a.pair_q = w.pair_q;
     a.pair_vbase = w.pair_vbase; a.counters = w.counters; a.lutq = w.lutq; a.pair_thr = w.pair_thr;
     a.cand_cnt = w.cand_cnt; a.cand = w.cand; a.cap = w.cap; a.allow = w.allow; a.allow_bits = w.allow_bits;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
     hipLaunchKernelGGL(adc_scan_kernel<NW>, dim3((uint32_t)cus * 8u), dim3(kScanThreads), 0, st, ix, a);
     LAUNCH_CHECK();
@@ -1387,11 +1683,12 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
                        npairs, w.tokens, ix.leaf_off, w.leaf_cnt);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(worklist_scan_kernel, dim3(1), dim3(1024), 0, st, ix.L, w.leaf_cnt,
-                       ix.leaf_off, kScanTP, kScanQuadsPerTile, w.pair_off, w.tile_off, w.counters);
+                       ix.leaf_off, kScanTP, kScanQuadsPerTile, w.st, w.sqpt, w.pair_off, w.tile_off,
+                       w.stile_off, w.counters);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(worklist_fill_kernel, dim3(ceil_div_u32(npairs, 256)), dim3(256), 0, st, w.nq,
-                       w.P, w.tokens, w.vbase, ix.leaf_off, w.pair_off, w.leaf_cursor, w.pair_q,
-                       w.pair_leaf, w.pair_vbase, w.slot_of);
+                       w.P, w.tokens, w.vbase, w.sbase, ix.leaf_off, w.pair_off, w.leaf_cursor, w.pair_q,
+                       w.pair_leaf, w.pair_vbase, w.pair_sbase, w.slot_of);
     LAUNCH_CHECK();
     const size_t lds_lut = (size_t)4 * ix.dim * sizeof(float);
     SCANN_TRY(set_dyn_lds(lut_build_kernel, lds_lut));

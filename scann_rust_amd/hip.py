@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscann_hip.so")
+# SCANN_HIP_LIB: alternative build of the same library (kernel-tuning sweeps)
+LIB_PATH = os.environ.get("SCANN_HIP_LIB") or os.path.join(_HERE, "libscann_hip.so")
 
 OK, INVALID_ARGUMENT, RESOURCE_EXHAUSTED, FAILED_PRECONDITION = 0, 3, 8, 9
 OUT_OF_RANGE, UNIMPLEMENTED, INTERNAL, UNAVAILABLE = 11, 12, 13, 14
