@@ -55,10 +55,10 @@ static inline void sample_plan(uint64_t max_stream, uint32_t P, uint32_t *st_out
     const uint32_t ms = (uint32_t)(max_stream > 0xFFFFFFFFull ? 0xFFFFFFFFull : max_stream);
     uint32_t st = sample_stride(ms);
     for (;;) {
-        const uint64_t scap = (uint64_t)(ms + st - 1u) / st + P;
-        if (scap <= kSampleTarget || P >= kSampleTarget) {
+        const uint64_t scap = (((uint64_t)(ms + st - 1u) / st + P) + 3u) & ~3ull;   // rows 16-B aligned
+        if (scap <= kSampleTarget || P >= kSampleTarget - 4) {
             *st_out = st;
-            *scap_out = (uint32_t)(scap < 1 ? 1 : scap);
+            *scap_out = (uint32_t)(scap < 4 ? 4 : scap);
             return;
         }
         st += 1 + st / 8;

@@ -141,10 +141,31 @@ __global__ void ah_tokens_kernel(uint32_t nq, const uint32_t *__restrict__ leaf_
 // K3: worklist -- group (query, rank) pairs by leaf so that every leaf's codes are read
 // once per batch and shared by all queries that selected it.
 // =====================================================================================
-__global__ void worklist_count_kernel(uint32_t npairs, const uint32_t *__restrict__ tokens,
+// One launch instead of five memsets: zero the per-batch counters, mark all pair slots free.
+__global__ void txh_init_kernel(uint32_t L, uint32_t nq, uint32_t max_slots,
+                                uint32_t *__restrict__ leaf_cnt, uint32_t *__restrict__ leaf_cursor,
+                                uint32_t *__restrict__ counters, uint32_t *__restrict__ cand_cnt,
+                                uint32_t *__restrict__ pair_q) {
+    const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+    for (uint32_t i = i0; i < L; i += step) {
+        leaf_cnt[i] = 0;
+        leaf_cursor[i] = 0;
+    }
+    for (uint32_t i = i0; i < nq; i += step) cand_cnt[i] = 0;
+    for (uint32_t i = i0; i < max_slots; i += step) pair_q[i] = kInvalid;
+    if (i0 < CNT_N) counters[i0] = 0;
+}
+
+// ah != 0: one implicit leaf selected by every query -- no atomics (1024 same-address global
+// atomics cost more than the whole LUT build).
+__global__ void worklist_count_kernel(uint32_t npairs, int ah, const uint32_t *__restrict__ tokens,
                                       const uint32_t *__restrict__ leaf_off,
                                       uint32_t *__restrict__ leaf_cnt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ah) {
+        if (i == 0) leaf_cnt[0] = leaf_off[1] > leaf_off[0] ? npairs : 0u;
+        return;
+    }
     if (i >= npairs) return;
     uint32_t leaf = tokens[i];
     if (leaf_off[leaf + 1] > leaf_off[leaf]) atomicAdd(&leaf_cnt[leaf], 1u);
@@ -216,7 +237,7 @@ __global__ __launch_bounds__(1024) void worklist_scan_kernel(
     }
 }
 
-__global__ void worklist_fill_kernel(uint32_t nq, uint32_t P, const uint32_t *__restrict__ tokens,
+__global__ void worklist_fill_kernel(uint32_t nq, uint32_t P, int ah, const uint32_t *__restrict__ tokens,
                                      const uint32_t *__restrict__ vbase,
                                      const uint32_t *__restrict__ sbase,
                                      const uint32_t *__restrict__ leaf_off,
@@ -232,7 +253,7 @@ __global__ void worklist_fill_kernel(uint32_t nq, uint32_t P, const uint32_t *__
     uint32_t leaf = tokens[i];
     uint32_t slot = kInvalid;
     if (leaf_off[leaf + 1] > leaf_off[leaf]) {
-        slot = pair_off[leaf] + atomicAdd(&leaf_cursor[leaf], 1u);
+        slot = pair_off[leaf] + (ah ? i : atomicAdd(&leaf_cursor[leaf], 1u));
         pair_q[slot] = q;
         pair_leaf[slot] = leaf;
         pair_vbase[slot] = vbase[(size_t)q * (P + 1) + r];
@@ -687,6 +708,138 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? kScanWaves : 3)) void adc_
 }
 
 // =====================================================================================
+// block_select: value of 1-based rank `rank` among vals[0..n) (LDS), ties allowed.  One
+// pass over [min, max] of the values with kSelBins histogram bins ((v - min) >> sh, monotone)
+// finds the rank's bin; a bin of <= kSelList members is ranked exactly by counting,
+// otherwise the bin becomes the new range.  Every thread of the block must call; all get
+// the same result.  Values equal to ~0 are "absent": they sort last and do not widen the
+// range; if fewer than `rank` values are present the result is ~0.
+// hist: LDS u32[kSelBins]; list: LDS T[kSelList]; red: LDS u64[48].
+// =====================================================================================
+constexpr uint32_t kSelBins = kSampleBins;
+constexpr uint32_t kSelList = kSampleList;
+
+template <typename T>
+__device__ __forceinline__ T shfl_xor_t(T v, int d) {
+    if constexpr (sizeof(T) == 8) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d);
+        return ((uint64_t)hi << 32) | lo;
+    } else {
+        return (T)__shfl_xor((int)v, d);
+    }
+}
+
+template <typename T>
+__device__ static T block_select(const T *vals, uint32_t n, uint32_t rank, uint32_t *hist, T *list,
+                                 uint64_t *red) {
+    const uint32_t tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nt >> 6;
+    constexpr T kAbsent = ~(T)0;
+    T vmin = kAbsent, vmax = 0;
+    uint32_t present = 0;
+    for (uint32_t i = tid; i < n; i += nt) {
+        const T v = vals[i];
+        if (v != kAbsent) {
+            vmin = v < vmin ? v : vmin;
+            vmax = v > vmax ? v : vmax;
+            ++present;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const T a = shfl_xor_t(vmin, o), b = shfl_xor_t(vmax, o);
+        vmin = a < vmin ? a : vmin;
+        vmax = b > vmax ? b : vmax;
+        present += (uint32_t)__shfl_xor((int)present, o);
+    }
+    uint32_t *red32 = reinterpret_cast<uint32_t *>(red + 32);   // [0..15] wave sums, 16.. results
+    if (lane == 0) {
+        red[wave] = vmin;
+        red[16 + wave] = vmax;
+        red32[wave] = present;
+    }
+    __syncthreads();
+    present = 0;
+    for (uint32_t w2 = 0; w2 < nwaves; ++w2) {
+        const T a = (T)red[w2], b = (T)red[16 + w2];
+        vmin = a < vmin ? a : vmin;
+        vmax = b > vmax ? b : vmax;
+        present += red32[w2];
+    }
+    if (present < rank) return kAbsent;   // block-uniform
+    for (;;) {
+        const T range = vmax - vmin;
+        uint32_t sh = 0;
+        while ((range >> sh) >= (T)kSelBins) ++sh;
+        __syncthreads();          // previous readers of hist / red32 are done
+        for (uint32_t i = tid; i < kSelBins; i += nt) hist[i] = 0;
+        if (tid == 0) red32[20] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += nt) {
+            const T v = vals[i];
+            if (v >= vmin && v <= vmax) atomicAdd(&hist[(uint32_t)((v - vmin) >> sh)], 1u);
+        }
+        __syncthreads();
+        // bin of the rank: block-wide inclusive scan over per-thread groups of bins
+        const uint32_t per = (kSelBins + nt - 1) / nt;
+        const uint32_t b0 = tid * per, b1 = min(b0 + per, kSelBins);
+        uint32_t mine = 0;
+        for (uint32_t b = b0; b < b1; ++b) mine += hist[b];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+            if ((int)lane >= o) incl += up;
+        }
+        if (lane == 63) red32[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (uint32_t w2 = 0; w2 < wave; ++w2) wbase += red32[w2];
+        incl += wbase;
+        const uint32_t excl = incl - mine;
+        if (excl < rank && rank <= incl) {   // exactly one thread
+            uint32_t c = excl;
+            for (uint32_t b = b0; b < b1; ++b) {
+                const uint32_t h = hist[b];
+                if (c + h >= rank) {
+                    red32[16] = b;
+                    red32[17] = rank - c;      // 1-based rank inside the bin
+                    red32[18] = h;
+                    break;
+                }
+                c += h;
+            }
+        }
+        __syncthreads();
+        const uint32_t bin = red32[16], rk = red32[17], pop = red32[18];
+        const T lo = vmin + ((T)bin << sh);
+        T hi = lo + (((T)1 << sh) - 1);
+        if (hi > vmax || hi < lo) hi = vmax;
+        if (sh == 0) return lo;
+        if (pop <= kSelList) {
+            for (uint32_t i = tid; i < n; i += nt) {
+                const T v = vals[i];
+                if (v >= lo && v <= hi) list[atomicAdd(&red32[20], 1u)] = v;
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < pop; i += nt) {
+                const T v = list[i];
+                uint32_t r = 0;
+                for (uint32_t j2 = 0; j2 < pop; ++j2) {
+                    const T u = list[j2];
+                    r += (u < v || (u == v && j2 < i)) ? 1u : 0u;
+                }
+                if (r + 1 == rk) red[24] = v;
+            }
+            __syncthreads();
+            return (T)red[24];
+        }
+        vmin = lo;
+        vmax = hi;
+        rank = rk;
+    }
+}
+
+// =====================================================================================
 // K5: threshold from a strided sample (plan: sample_stride / sample_plan / sample_rank).
 //
 // K5a adc_sample_kernel: the scan's tiled LUT16 gather over every st-th point of each
@@ -830,12 +983,11 @@ __global__ __launch_bounds__(kSelectThreads) void threshold_select_kernel(
     uint32_t P, uint32_t m, uint32_t st, int no_threshold, const uint32_t *__restrict__ sbase,
     const uint32_t *__restrict__ samp, uint32_t scap, const uint32_t *__restrict__ slot_of,
     uint64_t *__restrict__ thr, uint64_t *__restrict__ pair_thr) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_vals[];   // [scap]
-    uint32_t *s_hist = s_vals + ((scap + 3u) & ~3u);                    // [kSampleBins]
-    uint32_t *s_list = s_hist + kSampleBins;                            // [kSampleList]
-    uint32_t *s_red = s_list + kSampleList;                             // [64]
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_vals[];   // [scap rounded to 4]
+    uint32_t *s_hist = s_vals + ((scap + 3u) & ~3u);                    // [kSelBins]
+    uint32_t *s_list = s_hist + kSelBins;                               // [kSelList]
+    uint64_t *s_red = reinterpret_cast<uint64_t *>(s_list + kSelList);  // [48]
     const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = nt >> 6;
     const uint32_t ns = min(sbase[(size_t)q * (P + 2) + P], scap);
     const uint32_t total = sbase[(size_t)q * (P + 2) + P + 1];
     const uint32_t J = (no_threshold || total <= m) ? 0u : sample_rank(m, st);
@@ -851,106 +1003,33 @@ __global__ __launch_bounds__(kSelectThreads) void threshold_select_kernel(
         publish(SCANN_KEY_MAX);
         return;
     }
-    // 1. sample -> LDS; min, max and count of the present values
-    uint32_t vmin = 0xFFFFFFFFu, vmax = 0u, cnt = 0;
-    for (uint32_t i = tid; i < ns; i += nt) {
-        const uint32_t v = samp[(size_t)q * scap + i];
-        s_vals[i] = v;
-        if (v != 0xFFFFFFFFu) {
-            vmin = min(vmin, v);
-            vmax = max(vmax, v);
-            ++cnt;
+    // sample -> LDS (16-byte loads; rows of samp are 16-byte aligned: scap % 4 == 0)
+    const uint4 *src = reinterpret_cast<const uint4 *>(samp + (size_t)q * scap);
+    const uint32_t n4 = (ns + 3u) >> 2;
+    for (uint32_t i0 = 0; i0 < n4; i0 += 4 * nt) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + u * nt + tid;
+            v[u] = i < n4 ? src[i] : make_uint4(~0u, ~0u, ~0u, ~0u);
         }
-    }
-    for (uint32_t i = tid; i < kSampleBins; i += nt) s_hist[i] = 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        vmin = min(vmin, (uint32_t)__shfl_xor((int)vmin, o));
-        vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, o));
-        cnt += (uint32_t)__shfl_xor((int)cnt, o);
-    }
-    if (lane == 0) {
-        s_red[wave] = vmin;
-        s_red[16 + wave] = vmax;
-        s_red[32 + wave] = cnt;
-    }
-    __syncthreads();
-    vmin = 0xFFFFFFFFu; vmax = 0; cnt = 0;
-    for (uint32_t w2 = 0; w2 < nwaves; ++w2) {
-        vmin = min(vmin, s_red[w2]);
-        vmax = max(vmax, s_red[16 + w2]);
-        cnt += s_red[32 + w2];
-    }
-    if (cnt < J) {            // block-uniform (every thread reduced the same values)
-        publish(SCANN_KEY_MAX);
-        return;
-    }
-    // 2. histogram of (v - vmin) >> sh: monotone in v, < kSampleBins bins
-    const uint32_t range = vmax - vmin;
-    uint32_t sh = 0;
-    while ((range >> sh) >= kSampleBins) ++sh;
-    for (uint32_t i = tid; i < ns; i += nt) {
-        const uint32_t v = s_vals[i];
-        if (v != 0xFFFFFFFFu) atomicAdd(&s_hist[(v - vmin) >> sh], 1u);
-    }
-    __syncthreads();
-    // 3. bin of the J-th smallest: block-wide inclusive scan of per-thread bin groups
-    const uint32_t per = (kSampleBins + nt - 1) / nt;
-    const uint32_t b0 = tid * per, b1 = min(b0 + per, kSampleBins);
-    uint32_t mine = 0;
-    for (uint32_t b = b0; b < b1; ++b) mine += s_hist[b];
-    uint32_t incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
-        if ((int)lane >= o) incl += up;
-    }
-    __syncthreads();          // s_red is re-used
-    if (lane == 63) s_red[wave] = incl;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (uint32_t w2 = 0; w2 < wave; ++w2) wbase += s_red[w2];
-    incl += wbase;
-    const uint32_t excl = incl - mine;
-    if (excl < J && J <= incl) {   // exactly one thread
-        uint32_t c = excl;
-        for (uint32_t b = b0; b < b1; ++b) {
-            const uint32_t h = s_hist[b];
-            if (c + h >= J) {
-                s_red[48] = b;
-                s_red[49] = J - c;      // 1-based rank inside the bin
-                s_red[50] = h;
-                break;
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + u * nt + tid;
+            if (i < n4) {
+                // entries past ns (row padding) count as absent
+                if (4 * i + 1 >= ns) v[u].y = ~0u;
+                if (4 * i + 2 >= ns) v[u].z = ~0u;
+                if (4 * i + 3 >= ns) v[u].w = ~0u;
+                reinterpret_cast<uint4 *>(s_vals)[i] = v[u];
             }
-            c += h;
         }
-        s_red[51] = 0;                  // list fill
     }
     __syncthreads();
-    const uint32_t bin = s_red[48], rank = s_red[49], pop = s_red[50];
-    const uint32_t bin_hi = vmin + (uint32_t)min((uint64_t)0xFFFFFFFFull - vmin,
-                                                 (((uint64_t)bin + 1) << sh) - 1);
-    if (pop > kSampleList) {   // crowded bin: its upper edge bounds the J-th smallest
-        publish(((uint64_t)bin_hi << 32) | 0xFFFFFFFFull);
-        return;
-    }
-    // 4. exact rank among the bin's members
-    for (uint32_t i = tid; i < ns; i += nt) {
-        const uint32_t v = s_vals[i];
-        if (v != 0xFFFFFFFFu && ((v - vmin) >> sh) == bin) s_list[atomicAdd(&s_red[51], 1u)] = v;
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < pop; i += nt) {
-        const uint32_t v = s_list[i];
-        uint32_t r = 0;
-        for (uint32_t j2 = 0; j2 < pop; ++j2) {
-            const uint32_t u = s_list[j2];
-            r += (u < v || (u == v && j2 < i)) ? 1u : 0u;
-        }
-        if (r + 1 == rank) s_red[52] = v;
-    }
-    __syncthreads();
-    publish(((uint64_t)s_red[52] << 32) | 0xFFFFFFFFull);
+    // absent samples (0xFFFFFFFF: rejected by the allow-bitmap, padding) sort last; the bound
+    // is MAX if the J-th smallest is one of them
+    const uint32_t v = block_select<uint32_t>(s_vals, 4 * n4, J, s_hist, s_list, s_red);
+    publish(v == 0xFFFFFFFFu ? SCANN_KEY_MAX : (((uint64_t)v << 32) | 0xFFFFFFFFull));
 }
 
 // =====================================================================================
@@ -1010,53 +1089,6 @@ __device__ static uint32_t block_compact_le(uint64_t *list, uint32_t cnt, uint64
         __syncthreads();
     }
     return *s_base;
-}
-
-// Key of rank r (0-based) among the n unique u64 keys in LDS, by MSB-first radix select:
-// 8 passes of (256-bin histogram of the active keys -> bin holding rank r).  hist: LDS
-// [258].  Every thread of the block must call; returns the same value in every thread.
-__device__ static uint64_t block_radix_select(const uint64_t *keys, uint32_t n, uint32_t r,
-                                              uint32_t *hist) {
-    const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    uint64_t prefix = 0, mask = 0;
-    uint32_t rem = r;
-    for (int pass = 0; pass < 8; ++pass) {
-        const int shift = 56 - 8 * pass;
-        for (uint32_t i = tid; i < 256; i += nt) hist[i] = 0;
-        __syncthreads();
-        for (uint32_t i = tid; i < n; i += nt) {
-            const uint64_t kx = keys[i];
-            if ((kx & mask) == prefix) atomicAdd(&hist[(uint32_t)(kx >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid < 64) {   // one wave: lane l owns bins 4l .. 4l+3
-            const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2],
-                           c3 = hist[4 * tid + 3];
-            const uint32_t sum = c0 + c1 + c2 + c3;
-            uint32_t incl = sum;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(incl, d, 64);
-                if ((int)tid >= d) incl += o;
-            }
-            const uint32_t excl = incl - sum;
-            if (rem >= excl && rem < incl) {
-                uint32_t b = 0, before = excl;
-                if (rem >= before + c0) { before += c0; b = 1;
-                    if (rem >= before + c1) { before += c1; b = 2;
-                        if (rem >= before + c2) { before += c2; b = 3; } } }
-                hist[256] = 4 * tid + b;
-                hist[257] = rem - before;
-            }
-        }
-        __syncthreads();
-        const uint32_t bin = hist[256];
-        rem = hist[257];
-        prefix |= (uint64_t)bin << shift;
-        mask |= 0xFFull << shift;
-        __syncthreads();
-    }
-    return prefix;
 }
 
 __device__ static void select_fail(const SelectArgs &a, uint32_t q, uint32_t status) {
@@ -1129,15 +1161,19 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
     };
 
     if (a.unsorted) {
-        // Selection without a sort: radix-select the m-th smallest key, keep keys <= it.
+        // Selection without a sort: the m-th smallest key by histogram select, keep keys <= it.
         // The final stage orders by (exact, merge key), which equals (exact, approx rank).
         for (uint32_t i = tid; i < cnt; i += nt) skeys[i] = list[i];
         __syncthreads();
-        uint32_t *hist = s_basep + 4;
-        const uint64_t T = cnt > m ? block_radix_select(skeys, cnt, m - 1, hist) : SCANN_KEY_MAX;
-        const uint32_t wave = tid >> 6, nwv = nt >> 6;
-        uint32_t base_slot = 0;
-        for (uint32_t b = 0; b < cnt; b += nt) {
+        uint32_t *hist = reinterpret_cast<uint32_t *>(s_basep + 4);
+        uint64_t *slist = reinterpret_cast<uint64_t *>(hist + kSelBins);
+        uint64_t *sred = slist + kSelList;
+        const uint64_t T = cnt > m ? block_select<uint64_t>(skeys, cnt, m, hist, slist, sred) : SCANN_KEY_MAX;
+        __syncthreads();
+        uint32_t *s_slot = reinterpret_cast<uint32_t *>(sred);   // output cursor
+        if (tid == 0) *s_slot = 0;
+        __syncthreads();
+        for (uint32_t b = 0; b < cnt; b += nt) {   // wave-aggregated slot allocation, any order
             const uint32_t i = b + tid;
             uint64_t key = 0;
             bool keep = false;
@@ -1147,16 +1183,10 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
             }
             uint32_t wtot;
             const uint32_t wpre = wave_prefix_count(keep, &wtot);
-            if ((tid & 63u) == 0) s_wave[wave] = wtot;
-            __syncthreads();
-            uint32_t off = base_slot, tot = 0;
-            for (uint32_t w2 = 0; w2 < nwv; ++w2) {
-                if (w2 < wave) off += s_wave[w2];
-                tot += s_wave[w2];
-            }
-            if (keep) decode(key, off + wpre);
-            base_slot += tot;
-            __syncthreads();
+            uint32_t base = 0;
+            if ((tid & 63u) == 0 && wtot) base = atomicAdd(s_slot, wtot);
+            base = (uint32_t)__shfl((int)base, 0);
+            if (keep) decode(key, base + wpre);
         }
         if (tid == 0) a.cand_count[q] = nsel;
         return;
@@ -1284,21 +1314,56 @@ __global__ __launch_bounds__(kSelectThreads) void final_sort_kernel(
     if (tid == 0) out_count[q] = nout;
 }
 
-// K9b: the same ordering without a sort, for small k and unsorted candidates: k rounds of a
-// block-wide arg-min over (ordered(exact), merge key) -- the merge key is monotone in the
-// approximate rank, so this is exactly the stable sort's order.
+// K9b: the same ordering without a sort, for small k and unsorted candidates: arg-min rounds
+// over (ordered(exact), merge key) -- the merge key is monotone in the approximate rank, so
+// this is exactly the stable sort's order.  Two levels without block-wide rounds: every wave
+// extracts the k best of its share with wave shuffles only, then wave 0 extracts the k best
+// of the (waves x k) finalists.
 constexpr uint32_t kTopkMaxK = 64;
+
+// One arg-min round over the per-lane best (b_eb, b_kk, b_sl) of a wave; returns the winner
+// in every lane.  Exact-distance ties are rare: reduce the 32-bit distance first and fall
+// back to the 96-bit reduction only when several lanes tie.
+__device__ __forceinline__ void wave_argmin96(uint32_t &b_eb, uint64_t &b_kk, uint32_t &b_sl) {
+    uint32_t mn = b_eb;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, d));
+    const unsigned long long tie = __ballot(b_eb == mn);
+    if (__popcll(tie) == 1) {
+        const int src = __ffsll((long long)tie) - 1;
+        b_eb = mn;
+        b_sl = (uint32_t)__shfl((int)b_sl, src);
+        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)b_kk, src);
+        const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(b_kk >> 32), src);
+        b_kk = ((uint64_t)hi << 32) | lo;
+        return;
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o_eb = (uint32_t)__shfl_xor((int)b_eb, d), o_sl = (uint32_t)__shfl_xor((int)b_sl, d);
+        const uint64_t o_kk = shfl_xor_t<uint64_t>(b_kk, d);
+        if (o_eb < b_eb || (o_eb == b_eb && o_kk < b_kk)) {
+            b_eb = o_eb;
+            b_kk = o_kk;
+            b_sl = o_sl;
+        }
+    }
+}
+
 __global__ __launch_bounds__(kSelectThreads) void final_topk_kernel(
     uint32_t m, uint32_t k, const uint32_t *__restrict__ cand_count,
     const uint32_t *__restrict__ cand_idx, const uint64_t *__restrict__ cand_key,
     const float *__restrict__ cand_exact, uint32_t *__restrict__ out_idx,
     float *__restrict__ out_dist, uint32_t *__restrict__ out_count) {
     constexpr int E = kMaxPreReorderK / kSelectThreads;   // candidates per thread
-    __shared__ uint32_t s_eb[kSelectThreads / 64];
-    __shared__ uint64_t s_kk[kSelectThreads / 64];
-    __shared__ uint32_t s_sl[kSelectThreads / 64];
+    constexpr int NWV = kSelectThreads / 64;
+    constexpr int E2 = NWV * kTopkMaxK / 64;              // finalists per lane of wave 0
+    __shared__ uint32_t s_eb[NWV * kTopkMaxK];
+    __shared__ uint64_t s_kk[NWV * kTopkMaxK];
+    __shared__ uint32_t s_sl[NWV * kTopkMaxK];
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t nsel = cand_count[q];
+    const uint32_t nout = min(k, nsel);
     uint32_t eb[E];
     uint64_t kk[E];
 #pragma unroll
@@ -1308,54 +1373,70 @@ __global__ __launch_bounds__(kSelectThreads) void final_topk_kernel(
         eb[e] = alive ? f32_to_ordered(cand_exact[(size_t)q * m + slot]) : 0xFFFFFFFFu;
         kk[e] = alive ? cand_key[(size_t)q * m + slot] : SCANN_KEY_MAX;
     }
-    const uint32_t nout = min(k, nsel);
+    // level 1: the wave's nout best
     for (uint32_t r = 0; r < nout; ++r) {
-        uint32_t b_eb = 0xFFFFFFFFu, b_sl = 0;
+        uint32_t b_eb = 0xFFFFFFFFu, b_sl = 0xFFFFFFFFu;
         uint64_t b_kk = SCANN_KEY_MAX;
 #pragma unroll
         for (int e = 0; e < E; ++e)
-            if (eb[e] < b_eb || (eb[e] == b_eb && kk[e] < b_kk)) {
+            if ((uint32_t)e * kSelectThreads < nsel && (eb[e] < b_eb || (eb[e] == b_eb && kk[e] < b_kk))) {
                 b_eb = eb[e];
                 b_kk = kk[e];
                 b_sl = e * kSelectThreads + tid;
             }
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o_eb = __shfl_xor(b_eb, d, 64), o_sl = __shfl_xor(b_sl, d, 64);
-            const uint64_t o_kk = __shfl_xor(b_kk, d, 64);
-            if (o_eb < b_eb || (o_eb == b_eb && o_kk < b_kk)) {
-                b_eb = o_eb;
-                b_kk = o_kk;
-                b_sl = o_sl;
-            }
-        }
-        if (lane == 0) {
-            s_eb[wave] = b_eb;
-            s_kk[wave] = b_kk;
-            s_sl[wave] = b_sl;
-        }
-        __syncthreads();
-        uint32_t g_eb = s_eb[0], g_sl = s_sl[0];
-        uint64_t g_kk = s_kk[0];
-#pragma unroll
-        for (int w2 = 1; w2 < (int)(kSelectThreads / 64); ++w2)
-            if (s_eb[w2] < g_eb || (s_eb[w2] == g_eb && s_kk[w2] < g_kk)) {
-                g_eb = s_eb[w2];
-                g_kk = s_kk[w2];
-                g_sl = s_sl[w2];
-            }
-        if ((g_sl & (kSelectThreads - 1)) == tid) {
-            const uint32_t we = g_sl / kSelectThreads;
+        wave_argmin96(b_eb, b_kk, b_sl);
+        if (b_sl != 0xFFFFFFFFu && (b_sl & (kSelectThreads - 1)) == tid) {
+            const uint32_t we = b_sl / kSelectThreads;
 #pragma unroll
             for (int e = 0; e < E; ++e)
                 if ((uint32_t)e == we) {
                     eb[e] = 0xFFFFFFFFu;
                     kk[e] = SCANN_KEY_MAX;
                 }
-            out_idx[(size_t)q * k + r] = cand_idx[(size_t)q * m + g_sl];
-            out_dist[(size_t)q * k + r] = ordered_to_f32(g_eb);
         }
-        __syncthreads();
+        if (lane == 0) {
+            s_eb[wave * nout + r] = b_eb;
+            s_kk[wave * nout + r] = b_kk;
+            s_sl[wave * nout + r] = b_sl;
+        }
+    }
+    __syncthreads();
+    // level 2: wave 0 takes the nout best of the NWV * nout finalists
+    if (wave == 0) {
+        const uint32_t nfin = NWV * nout;
+        uint32_t feb[E2], fsl[E2];
+        uint64_t fkk[E2];
+#pragma unroll
+        for (int e = 0; e < E2; ++e) {
+            const uint32_t i = e * 64 + lane;
+            const bool alive = i < nfin;
+            feb[e] = alive ? s_eb[i] : 0xFFFFFFFFu;
+            fkk[e] = alive ? s_kk[i] : SCANN_KEY_MAX;
+            fsl[e] = alive ? s_sl[i] : 0xFFFFFFFFu;
+        }
+        for (uint32_t r = 0; r < nout; ++r) {
+            uint32_t b_eb = 0xFFFFFFFFu, b_sl = 0xFFFFFFFFu;
+            uint64_t b_kk = SCANN_KEY_MAX;
+#pragma unroll
+            for (int e = 0; e < E2; ++e)
+                if ((uint32_t)e * 64 < nfin && (feb[e] < b_eb || (feb[e] == b_eb && fkk[e] < b_kk))) {
+                    b_eb = feb[e];
+                    b_kk = fkk[e];
+                    b_sl = fsl[e];
+                }
+            wave_argmin96(b_eb, b_kk, b_sl);
+#pragma unroll
+            for (int e = 0; e < E2; ++e)
+                if (fsl[e] == b_sl) {   // slots are unique: exactly one lane/element matches
+                    feb[e] = 0xFFFFFFFFu;
+                    fkk[e] = SCANN_KEY_MAX;
+                    fsl[e] = 0xFFFFFFFEu;
+                }
+            if (lane == 0) {
+                out_idx[(size_t)q * k + r] = cand_idx[(size_t)q * m + b_sl];
+                out_dist[(size_t)q * k + r] = ordered_to_f32(b_eb);
+            }
+        }
     }
     for (uint32_t i = nout + tid; i < k; i += blockDim.x) {
         out_idx[(size_t)q * k + i] = kInvalid;
@@ -1650,7 +1731,7 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
         LAUNCH_CHECK();
     }
     {
-        const size_t lds_thr = ((size_t)((w.scap + 3u) & ~3u) + kSampleBins + kSampleList + 64) * 4;
+        const size_t lds_thr = ((size_t)((w.scap + 3u) & ~3u) + kSelBins + kSelList) * 4 + 48 * 8;
         const uint32_t nt = w.scap > 8192 ? kSelectThreads : 256u;
         SCANN_TRY(set_dyn_lds(threshold_select_kernel, lds_thr));
         hipLaunchKernelGGL(threshold_select_kernel, dim3(w.nq), dim3(nt), lds_thr, st, w.P, w.m, w.st,
@@ -1671,23 +1752,25 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
 int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, hipStream_t st,
                       hipEvent_t ev0, hipEvent_t ev1) {
     if (w.nq == 0) return SCANN_HIP_OK;
-    SCANN_HIP_CHECK(hipMemsetAsync(w.leaf_cnt, 0, (size_t)ix.L * 4, st));
-    SCANN_HIP_CHECK(hipMemsetAsync(w.leaf_cursor, 0, (size_t)ix.L * 4, st));
-    SCANN_HIP_CHECK(hipMemsetAsync(w.counters, 0, CNT_N * 4, st));
-    SCANN_HIP_CHECK(hipMemsetAsync(w.cand_cnt, 0, (size_t)w.nq * 4, st));
-    SCANN_HIP_CHECK(hipMemsetAsync(w.pair_q, 0xFF, (size_t)w.max_slots * 4, st));
+    {
+        const uint32_t work = std::max(std::max(ix.L, w.nq), w.max_slots);
+        hipLaunchKernelGGL(txh_init_kernel, dim3(std::min(1024u, ceil_div_u32(work, 256))), dim3(256), 0, st,
+                           ix.L, w.nq, w.max_slots, w.leaf_cnt, w.leaf_cursor, w.counters, w.cand_cnt,
+                           w.pair_q);
+        LAUNCH_CHECK();
+    }
     SCANN_TRY(launch_partition_stage(ix, w, st));
 
     const uint32_t npairs = w.nq * w.P;
     hipLaunchKernelGGL(worklist_count_kernel, dim3(ceil_div_u32(npairs, 256)), dim3(256), 0, st,
-                       npairs, w.tokens, ix.leaf_off, w.leaf_cnt);
+                       npairs, ix.ah_mode, w.tokens, ix.leaf_off, w.leaf_cnt);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(worklist_scan_kernel, dim3(1), dim3(1024), 0, st, ix.L, w.leaf_cnt,
                        ix.leaf_off, kScanTP, kScanQuadsPerTile, w.st, w.sqpt, w.pair_off, w.tile_off,
                        w.stile_off, w.counters);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(worklist_fill_kernel, dim3(ceil_div_u32(npairs, 256)), dim3(256), 0, st, w.nq,
-                       w.P, w.tokens, w.vbase, w.sbase, ix.leaf_off, w.pair_off, w.leaf_cursor, w.pair_q,
+                       w.P, ix.ah_mode, w.tokens, w.vbase, w.sbase, ix.leaf_off, w.pair_off, w.leaf_cursor, w.pair_q,
                        w.pair_leaf, w.pair_vbase, w.pair_sbase, w.slot_of);
     LAUNCH_CHECK();
     const size_t lds_lut = (size_t)4 * ix.dim * sizeof(float);
@@ -1717,7 +1800,8 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
     s.cand_idx = w.cand_idx; s.cand_dist = w.cand_dist; s.cand_exact = w.cand_exact;
     s.cand_count = w.cand_count; s.out_idx = w.out_idx; s.out_dist = w.out_dist;
     s.out_count = w.out_count;
-    const size_t lds_sel = (size_t)kSortCap * 8 + (size_t)(kSelectThreads / 64 + 4 + 260) * 4;
+    const size_t lds_sel = (size_t)kSortCap * 8 + (size_t)(kSelectThreads / 64 + 4) * 4 +
+                           (size_t)kSelBins * 4 + (size_t)kSelList * 8 + 48 * 8;
     SCANN_TRY(set_dyn_lds(select_rerank_kernel, lds_sel));
     hipLaunchKernelGGL(select_rerank_kernel, dim3(w.nq), dim3(kSelectThreads), lds_sel, st, ix, s);
     LAUNCH_CHECK();
