@@ -423,7 +423,7 @@ static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallP
     SCANN_TRY(s.leaf_cursor.ensure((size_t)L * 4));
     SCANN_TRY(s.pair_off.ensure((size_t)(L + 1) * 4));
     SCANN_TRY(s.tile_off.ensure((size_t)(L + 1) * 4));
-    SCANN_TRY(s.counters.ensure(CNT_N * 4));
+    SCANN_TRY(s.counters.ensure(CNT_WORDS * 4));
     SCANN_TRY(s.pair_q.ensure((size_t)max_slots * 4));
     SCANN_TRY(s.pair_leaf.ensure((size_t)max_slots * 4));
     SCANN_TRY(s.pair_vbase.ensure((size_t)max_slots * 4));
@@ -469,6 +469,8 @@ static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallP
         while (qpt > 2 && chunks * ((quads + qpt - 1) / qpt) < 4096) qpt >>= 1;
         if (const char *e = std::getenv("SCANN_HIP_SQPT")) qpt = (uint32_t)std::max(1, std::atoi(e));
         w->sqpt = qpt;
+        w->qpt = kScanQuadsPerTile;
+        if (const char *e = std::getenv("SCANN_HIP_QPT")) w->qpt = (uint32_t)std::max(1, std::atoi(e));
     }
     w->sbase = s.sbase.as<uint32_t>();
     w->pair_sbase = s.pair_sbase.as<uint32_t>();

@@ -94,7 +94,12 @@ struct TxhIndexDev {
 // counters[] slots
 enum {
     CNT_TOTAL_QUADS = 0, CNT_TOTAL_TILES = 1, CNT_QUEUE_HEAD = 2, CNT_STATUS = 3,
-    CNT_TOTAL_STILES = 4, CNT_SQUEUE_HEAD = 5, CNT_N = 8
+    CNT_TOTAL_STILES = 4, CNT_SQUEUE_HEAD = 5, CNT_N = 8,
+    // eight scan-tile queues, one 128-byte line each: WGs of XCD x (blockIdx % 8) pull tiles
+    // t = x (mod 8) from queue x first and steal from the others when it runs dry.  One
+    // shared counter made every tile grab a ~100 ns serialized cross-XCD atomic.
+    CNT_XQ = 32, CNT_XQ_STRIDE = 32, CNT_XS = CNT_XQ + 8 * CNT_XQ_STRIDE /* sample pass */,
+    CNT_WORDS = CNT_XS + 8 * CNT_XQ_STRIDE
 };
 
 struct TxhWork {
@@ -110,6 +115,7 @@ struct TxhWork {
     float *token_dists;        // [nq][P]
     uint32_t *vbase;           // [nq][P+1] prefix of global leaf sizes in token order
     uint32_t st, scap, sqpt;   // sample stride, per-query sample capacity, quads per sample tile
+    uint32_t qpt;              // quads per scan tile
     uint32_t *sbase;           // [nq][P+2] prefix of per-leaf sample counts; [P]=samples, [P+1]=local points
     uint32_t *pair_sbase;      // [max_slots]
     uint32_t *stile_off;       // [L+1] tile table of the sample pass

@@ -153,7 +153,7 @@ __global__ void txh_init_kernel(uint32_t L, uint32_t nq, uint32_t max_slots,
     }
     for (uint32_t i = i0; i < nq; i += step) cand_cnt[i] = 0;
     for (uint32_t i = i0; i < max_slots; i += step) pair_q[i] = kInvalid;
-    if (i0 < CNT_N) counters[i0] = 0;
+    for (uint32_t i = i0; i < CNT_WORDS; i += step) counters[i] = 0;
 }
 
 // ah != 0: one implicit leaf selected by every query -- no atomics (1024 same-address global
@@ -469,6 +469,21 @@ __device__ __forceinline__ T uniform_load(const T *p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) T *>((uint64_t)p);
 }
 
+// Next tile of this workgroup: XCD x (blockIdx % 8) owns tiles t = x (mod 8) in queue x and
+// steals from the other queues when its own is dry.  kInvalid = no tiles left.
+__device__ __forceinline__ uint32_t grab_tile(uint32_t *queues, uint32_t total_tiles) {
+    const uint32_t xcd = blockIdx.x & 7u;
+    for (uint32_t a2 = 0; a2 < 8u; ++a2) {
+        const uint32_t x = (xcd + a2) & 7u;
+        const uint32_t nx = (total_tiles + 7u - x) >> 3;   // tiles = x (mod 8)
+        uint32_t *ctr = queues + x * CNT_XQ_STRIDE;
+        if (a2 && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nx) continue;
+        const uint32_t l = atomicAdd(ctr, 1u);
+        if (l < nx) return l * 8u + x;
+    }
+    return kInvalid;
+}
+
 static_assert(kScanPPT <= 4, "adc_scan_kernel's nsub switch handles up to 4 points per thread");
 constexpr uint32_t kScanStage = 128;   // LDS-staged survivors per (quad, query); <= kScanThreads
 static_assert(kScanStage <= kScanThreads, "the flush copies one survivor per thread");
@@ -481,6 +496,7 @@ struct ScanArgs {
     uint32_t *cand_cnt;
     uint64_t *cand;
     uint32_t cap;
+    uint32_t qpt;            // query quads per tile
     const uint64_t *allow;   // optional allow-bitmap (device), bit = datapoint index
     uint64_t allow_bits;
 };
@@ -506,10 +522,10 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? kScanWaves : 3)) void adc_
     if (tid < 8) ccnt_s[tid >> 2][tid & 3u] = 0;
 
     for (;;) {
-        if (tid == 0) tile_sh = atomicAdd(&a.counters[CNT_QUEUE_HEAD], 1u);
+        if (tid == 0) tile_sh = grab_tile(a.counters + CNT_XQ, total_tiles);
         __syncthreads();
         const uint32_t tile = __builtin_amdgcn_readfirstlane(tile_sh);
-        if (tile >= total_tiles) break;
+        if (tile == kInvalid) break;
 
         // leaf = largest l with tile_off[l] <= tile
         uint32_t lo = 0, hi = ix.L;
@@ -525,8 +541,8 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? kScanWaves : 3)) void adc_
         const uint32_t chunk = local % nchunks, qg = local / nchunks;
         const uint32_t slot0 = uniform_load(a.pair_off + leaf);
         const uint32_t nquads = (uniform_load(a.pair_off + leaf + 1) - slot0) >> 2;
-        const uint32_t q0 = qg * kScanQuadsPerTile;
-        const uint32_t q1 = min(q0 + kScanQuadsPerTile, nquads);
+        const uint32_t q0 = qg * a.qpt;
+        const uint32_t q1 = min(q0 + a.qpt, nquads);
         const uint32_t c0 = chunk * kScanTP;
         const uint32_t npts = min(kScanTP, size - c0);
         const uint32_t nsub = (npts + kScanThreads - 1) / kScanThreads;
@@ -872,10 +888,10 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? kScanWaves : 3)) void adc_
     const uint32_t st = a.st;
 
     for (;;) {
-        if (tid == 0) tile_sh = atomicAdd(&a.counters[CNT_SQUEUE_HEAD], 1u);
+        if (tid == 0) tile_sh = grab_tile(a.counters + CNT_XS, total_tiles);
         __syncthreads();
         const uint32_t tile = __builtin_amdgcn_readfirstlane(tile_sh);
-        if (tile >= total_tiles) break;
+        if (tile == kInvalid) break;
 
         uint32_t lo = 0, hi = ix.L;   // leaf = largest l with stile_off[l] <= tile
         while (hi - lo > 1) {
@@ -1741,9 +1757,11 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
     ScanArgs a;
     a.pair_off = w.pair_off; a.tile_off = w.tile_off; a.pair_q = w.pair_q;
     a.pair_vbase = w.pair_vbase; a.counters = w.counters; a.lutq = w.lutq; a.pair_thr = w.pair_thr;
-    a.cand_cnt = w.cand_cnt; a.cand = w.cand; a.cap = w.cap; a.allow = w.allow; a.allow_bits = w.allow_bits;
+    a.cand_cnt = w.cand_cnt; a.cand = w.cand; a.cap = w.cap; a.qpt = w.qpt; a.allow = w.allow; a.allow_bits = w.allow_bits;
     if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
-    hipLaunchKernelGGL(adc_scan_kernel<NW>, dim3((uint32_t)cus * 8u), dim3(kScanThreads), 0, st, ix, a);
+    uint32_t wgs = (uint32_t)cus * 8u;
+    if (const char *e = std::getenv("SCANN_HIP_WGS")) wgs = (uint32_t)cus * (uint32_t)std::max(1, std::atoi(e));
+    hipLaunchKernelGGL(adc_scan_kernel<NW>, dim3(wgs), dim3(kScanThreads), 0, st, ix, a);
     LAUNCH_CHECK();
     if (ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
     return SCANN_HIP_OK;
@@ -1766,7 +1784,7 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
                        npairs, ix.ah_mode, w.tokens, ix.leaf_off, w.leaf_cnt);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(worklist_scan_kernel, dim3(1), dim3(1024), 0, st, ix.L, w.leaf_cnt,
-                       ix.leaf_off, kScanTP, kScanQuadsPerTile, w.st, w.sqpt, w.pair_off, w.tile_off,
+                       ix.leaf_off, kScanTP, w.qpt, w.st, w.sqpt, w.pair_off, w.tile_off,
                        w.stile_off, w.counters);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(worklist_fill_kernel, dim3(ceil_div_u32(npairs, 256)), dim3(256), 0, st, w.nq,
