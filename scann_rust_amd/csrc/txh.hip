@@ -16,12 +16,153 @@
 namespace scann {
 
 // =====================================================================================
+// block_select: value of 1-based rank `rank` among vals[0..n) (LDS), ties allowed.  One
+// pass over [min, max] of the values with kSelBins histogram bins ((v - min) >> sh, monotone)
+// finds the rank's bin; a bin of <= kSelList members is ranked exactly by counting,
+// otherwise the bin becomes the new range.  Every thread of the block must call; all get
+// the same result.  Values equal to ~0 are "absent": they sort last and do not widen the
+// range; if fewer than `rank` values are present the result is ~0.
+// hist: LDS u32[cfg.bins]; list: LDS T[cfg.list]; red: LDS u64[48].
+// =====================================================================================
+struct SelCfg {
+    uint32_t bins, list;
+};
+// Histogram bins / exact-rank list size for selecting among at most n values: small inputs
+// take small tables so that several blocks share a CU's LDS.
+__host__ __device__ static inline SelCfg sel_cfg(uint32_t n) {
+    SelCfg c;
+    c.bins = n <= 4096u ? 1024u : kSampleBins;
+    c.list = n <= 4096u ? 256u : kSampleList;
+    return c;
+}
+
+template <typename T>
+__device__ __forceinline__ T shfl_xor_t(T v, int d) {
+    if constexpr (sizeof(T) == 8) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d);
+        return ((uint64_t)hi << 32) | lo;
+    } else {
+        return (T)__shfl_xor((int)v, d);
+    }
+}
+
+template <typename T>
+__device__ static T block_select(const T *vals, uint32_t n, uint32_t rank, SelCfg cfg, uint32_t *hist,
+                                 T *list, uint64_t *red) {
+    const uint32_t kSelBins = cfg.bins, kSelList = cfg.list;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nt >> 6;
+    constexpr T kAbsent = ~(T)0;
+    T vmin = kAbsent, vmax = 0;
+    uint32_t present = 0;
+    for (uint32_t i = tid; i < n; i += nt) {
+        const T v = vals[i];
+        if (v != kAbsent) {
+            vmin = v < vmin ? v : vmin;
+            vmax = v > vmax ? v : vmax;
+            ++present;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const T a = shfl_xor_t(vmin, o), b = shfl_xor_t(vmax, o);
+        vmin = a < vmin ? a : vmin;
+        vmax = b > vmax ? b : vmax;
+        present += (uint32_t)__shfl_xor((int)present, o);
+    }
+    uint32_t *red32 = reinterpret_cast<uint32_t *>(red + 32);   // [0..15] wave sums, 16.. results
+    if (lane == 0) {
+        red[wave] = vmin;
+        red[16 + wave] = vmax;
+        red32[wave] = present;
+    }
+    __syncthreads();
+    present = 0;
+    for (uint32_t w2 = 0; w2 < nwaves; ++w2) {
+        const T a = (T)red[w2], b = (T)red[16 + w2];
+        vmin = a < vmin ? a : vmin;
+        vmax = b > vmax ? b : vmax;
+        present += red32[w2];
+    }
+    if (present < rank) return kAbsent;   // block-uniform
+    for (;;) {
+        const T range = vmax - vmin;
+        uint32_t sh = 0;
+        while ((range >> sh) >= (T)kSelBins) ++sh;
+        __syncthreads();          // previous readers of hist / red32 are done
+        for (uint32_t i = tid; i < kSelBins; i += nt) hist[i] = 0;
+        if (tid == 0) red32[20] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += nt) {
+            const T v = vals[i];
+            if (v >= vmin && v <= vmax) atomicAdd(&hist[(uint32_t)((v - vmin) >> sh)], 1u);
+        }
+        __syncthreads();
+        // bin of the rank: block-wide inclusive scan over per-thread groups of bins
+        const uint32_t per = (kSelBins + nt - 1) / nt;
+        const uint32_t b0 = tid * per, b1 = min(b0 + per, kSelBins);
+        uint32_t mine = 0;
+        for (uint32_t b = b0; b < b1; ++b) mine += hist[b];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+            if ((int)lane >= o) incl += up;
+        }
+        if (lane == 63) red32[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (uint32_t w2 = 0; w2 < wave; ++w2) wbase += red32[w2];
+        incl += wbase;
+        const uint32_t excl = incl - mine;
+        if (excl < rank && rank <= incl) {   // exactly one thread
+            uint32_t c = excl;
+            for (uint32_t b = b0; b < b1; ++b) {
+                const uint32_t h = hist[b];
+                if (c + h >= rank) {
+                    red32[16] = b;
+                    red32[17] = rank - c;      // 1-based rank inside the bin
+                    red32[18] = h;
+                    break;
+                }
+                c += h;
+            }
+        }
+        __syncthreads();
+        const uint32_t bin = red32[16], rk = red32[17], pop = red32[18];
+        const T lo = vmin + ((T)bin << sh);
+        T hi = lo + (((T)1 << sh) - 1);
+        if (hi > vmax || hi < lo) hi = vmax;
+        if (sh == 0) return lo;
+        if (pop <= kSelList) {
+            for (uint32_t i = tid; i < n; i += nt) {
+                const T v = vals[i];
+                if (v >= lo && v <= hi) list[atomicAdd(&red32[20], 1u)] = v;
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < pop; i += nt) {
+                const T v = list[i];
+                uint32_t r = 0;
+                for (uint32_t j2 = 0; j2 < pop; ++j2) {
+                    const T u = list[j2];
+                    r += (u < v || (u == v && j2 < i)) ? 1u : 0u;
+                }
+                if (r + 1 == rk) red[24] = v;
+            }
+            __syncthreads();
+            return (T)red[24];
+        }
+        vmin = lo;
+        vmax = hi;
+        rank = rk;
+    }
+}
+
+// =====================================================================================
 // K1: centroid scores.  partitioning/tree_partitioner.rs:175-192: strictly sequential
 // scalar sum of (q_j - c_j)^2, no FMA.  One thread per centroid, QT queries per block
 // broadcast from LDS.
 // =====================================================================================
-constexpr int kCsQT = 16;
-
+template <int kCsQT>
 __global__ __launch_bounds__(64) void centroid_scores_kernel(
     const float *__restrict__ centers, uint32_t L, uint32_t dim,
     const float *__restrict__ queries, uint32_t nq, uint32_t q_stride,
@@ -75,13 +216,22 @@ __global__ __launch_bounds__(64) void centroid_scores_kernel(
 // stable order explicit; NaN sorts last as OrderedFloat does.
 // =====================================================================================
 __global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
-    const float *__restrict__ cdist, uint32_t L, uint32_t n_pow2, uint32_t P,
+    const float *__restrict__ cdist, uint32_t L, uint32_t n_pow2, uint32_t P, uint32_t p_pow2,
     const uint32_t *__restrict__ leaf_gsize, const uint32_t *__restrict__ leaf_off, uint32_t st,
     uint32_t *__restrict__ tokens, float *__restrict__ token_dists, uint32_t *__restrict__ vbase,
     uint32_t *__restrict__ sbase) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
-    const uint32_t q = blockIdx.x;
-    for (uint32_t i = threadIdx.x; i < n_pow2; i += blockDim.x) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];    // [n_pow2]
+    uint64_t *s_top = skeys + n_pow2;                                   // [p_pow2] (select path)
+    const SelCfg cfg = sel_cfg(L);
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_top + p_pow2);    // [cfg.bins]
+    uint64_t *s_list = reinterpret_cast<uint64_t *>(s_hist + cfg.bins); // [cfg.list]
+    uint64_t *s_red = s_list + cfg.list;                                // [48]
+    uint32_t *s_scan = reinterpret_cast<uint32_t *>(s_red + 48);        // [3][kSelectThreads / 64] + cursor
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = nt >> 6;
+    const bool select_path = p_pow2 != 0;
+    const uint32_t nfill = select_path ? L : n_pow2;
+    for (uint32_t i = tid; i < nfill; i += nt) {
         uint64_t key = SCANN_KEY_MAX;
         if (i < L) {
             float d = cdist[(size_t)q * L + i];
@@ -91,32 +241,83 @@ __global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
         skeys[i] = key;
     }
     __syncthreads();
-    bitonic_sort_lds(skeys, n_pow2);
-    for (uint32_t r = threadIdx.x; r < P; r += blockDim.x) {
-        uint64_t key = skeys[r];
+    const uint64_t *sorted = skeys;
+    if (select_path) {
+        // P << L: the P-th smallest key by histogram select, then sort only the P survivors
+        // (keys are unique: exactly P of them are <= the P-th smallest)
+        const uint64_t T = block_select<uint64_t>(skeys, L, P, cfg, s_hist, s_list, s_red);
+        for (uint32_t i = tid; i < p_pow2; i += nt) s_top[i] = SCANN_KEY_MAX;
+        if (tid == 0) s_scan[48] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < L; i += nt) {
+            const uint64_t key = skeys[i];
+            if (key <= T) s_top[atomicAdd(&s_scan[48], 1u)] = key;
+        }
+        __syncthreads();
+        bitonic_sort_lds(s_top, p_pow2);
+        sorted = s_top;
+    } else {
+        bitonic_sort_lds(skeys, n_pow2);
+    }
+    for (uint32_t r = tid; r < P; r += nt) {
+        uint64_t key = sorted[r];
         uint32_t id = (uint32_t)key;
         tokens[(size_t)q * P + r] = id;
         token_dists[(size_t)q * P + r] = cdist[(size_t)q * L + id];
     }
-    if (threadIdx.x == 0) {
-        uint32_t vb = 0;
-        for (uint32_t r = 0; r < P; ++r) {
-            vbase[(size_t)q * (P + 1) + r] = vb;
-            vb += leaf_gsize[(uint32_t)skeys[r]];
-        }
-        vbase[(size_t)q * (P + 1) + P] = vb;
+    // exclusive prefixes over the P tokens: global leaf sizes (merge-key base), sample counts
+    // (every st-th local point of each selected leaf) and local points
+    const uint32_t per = (P + nt - 1) / nt;
+    const uint32_t r0 = min(P, tid * per), r1 = min(P, r0 + per);
+    uint32_t a_g = 0, a_s = 0, a_t = 0;
+    for (uint32_t r = r0; r < r1; ++r) {
+        const uint32_t leaf = (uint32_t)sorted[r];
+        const uint32_t sz = leaf_off[leaf + 1] - leaf_off[leaf];
+        a_g += leaf_gsize[leaf];
+        a_s += (sz + st - 1) / st;
+        a_t += sz;
     }
-    if (threadIdx.x == 64) {   // sample slots: every st-th local point of each selected leaf
-        uint32_t sb = 0, tot = 0;
-        for (uint32_t r = 0; r < P; ++r) {
-            const uint32_t leaf = (uint32_t)skeys[r];
-            const uint32_t sz = leaf_off[leaf + 1] - leaf_off[leaf];
-            sbase[(size_t)q * (P + 2) + r] = sb;
-            sb += (sz + st - 1) / st;
-            tot += sz;
+    uint32_t i_g = a_g, i_s = a_s, i_t = a_t;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u_g = (uint32_t)__shfl_up((int)i_g, o), u_s = (uint32_t)__shfl_up((int)i_s, o),
+                       u_t = (uint32_t)__shfl_up((int)i_t, o);
+        if ((int)lane >= o) {
+            i_g += u_g;
+            i_s += u_s;
+            i_t += u_t;
         }
-        sbase[(size_t)q * (P + 2) + P] = sb;
-        sbase[(size_t)q * (P + 2) + P + 1] = tot;
+    }
+    if (lane == 63) {
+        s_scan[wave] = i_g;
+        s_scan[16 + wave] = i_s;
+        s_scan[32 + wave] = i_t;
+    }
+    __syncthreads();
+    uint32_t b_g = 0, b_s = 0, b_t = 0, t_g = 0, t_s = 0, t_t = 0;
+    for (uint32_t w2 = 0; w2 < nwaves; ++w2) {
+        if (w2 < wave) {
+            b_g += s_scan[w2];
+            b_s += s_scan[16 + w2];
+            b_t += s_scan[32 + w2];
+        }
+        t_g += s_scan[w2];
+        t_s += s_scan[16 + w2];
+        t_t += s_scan[32 + w2];
+    }
+    uint32_t vb = b_g + i_g - a_g, sb = b_s + i_s - a_s;
+    for (uint32_t r = r0; r < r1; ++r) {
+        const uint32_t leaf = (uint32_t)sorted[r];
+        const uint32_t sz = leaf_off[leaf + 1] - leaf_off[leaf];
+        vbase[(size_t)q * (P + 1) + r] = vb;
+        sbase[(size_t)q * (P + 2) + r] = sb;
+        vb += leaf_gsize[leaf];
+        sb += (sz + st - 1) / st;
+    }
+    if (tid == 0) {
+        vbase[(size_t)q * (P + 1) + P] = t_g;
+        sbase[(size_t)q * (P + 2) + P] = t_s;
+        sbase[(size_t)q * (P + 2) + P + 1] = t_t;
     }
 }
 
@@ -724,138 +925,6 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? kScanWaves : 3)) void adc_
 }
 
 // =====================================================================================
-// block_select: value of 1-based rank `rank` among vals[0..n) (LDS), ties allowed.  One
-// pass over [min, max] of the values with kSelBins histogram bins ((v - min) >> sh, monotone)
-// finds the rank's bin; a bin of <= kSelList members is ranked exactly by counting,
-// otherwise the bin becomes the new range.  Every thread of the block must call; all get
-// the same result.  Values equal to ~0 are "absent": they sort last and do not widen the
-// range; if fewer than `rank` values are present the result is ~0.
-// hist: LDS u32[kSelBins]; list: LDS T[kSelList]; red: LDS u64[48].
-// =====================================================================================
-constexpr uint32_t kSelBins = kSampleBins;
-constexpr uint32_t kSelList = kSampleList;
-
-template <typename T>
-__device__ __forceinline__ T shfl_xor_t(T v, int d) {
-    if constexpr (sizeof(T) == 8) {
-        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d);
-        return ((uint64_t)hi << 32) | lo;
-    } else {
-        return (T)__shfl_xor((int)v, d);
-    }
-}
-
-template <typename T>
-__device__ static T block_select(const T *vals, uint32_t n, uint32_t rank, uint32_t *hist, T *list,
-                                 uint64_t *red) {
-    const uint32_t tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nt >> 6;
-    constexpr T kAbsent = ~(T)0;
-    T vmin = kAbsent, vmax = 0;
-    uint32_t present = 0;
-    for (uint32_t i = tid; i < n; i += nt) {
-        const T v = vals[i];
-        if (v != kAbsent) {
-            vmin = v < vmin ? v : vmin;
-            vmax = v > vmax ? v : vmax;
-            ++present;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const T a = shfl_xor_t(vmin, o), b = shfl_xor_t(vmax, o);
-        vmin = a < vmin ? a : vmin;
-        vmax = b > vmax ? b : vmax;
-        present += (uint32_t)__shfl_xor((int)present, o);
-    }
-    uint32_t *red32 = reinterpret_cast<uint32_t *>(red + 32);   // [0..15] wave sums, 16.. results
-    if (lane == 0) {
-        red[wave] = vmin;
-        red[16 + wave] = vmax;
-        red32[wave] = present;
-    }
-    __syncthreads();
-    present = 0;
-    for (uint32_t w2 = 0; w2 < nwaves; ++w2) {
-        const T a = (T)red[w2], b = (T)red[16 + w2];
-        vmin = a < vmin ? a : vmin;
-        vmax = b > vmax ? b : vmax;
-        present += red32[w2];
-    }
-    if (present < rank) return kAbsent;   // block-uniform
-    for (;;) {
-        const T range = vmax - vmin;
-        uint32_t sh = 0;
-        while ((range >> sh) >= (T)kSelBins) ++sh;
-        __syncthreads();          // previous readers of hist / red32 are done
-        for (uint32_t i = tid; i < kSelBins; i += nt) hist[i] = 0;
-        if (tid == 0) red32[20] = 0;
-        __syncthreads();
-        for (uint32_t i = tid; i < n; i += nt) {
-            const T v = vals[i];
-            if (v >= vmin && v <= vmax) atomicAdd(&hist[(uint32_t)((v - vmin) >> sh)], 1u);
-        }
-        __syncthreads();
-        // bin of the rank: block-wide inclusive scan over per-thread groups of bins
-        const uint32_t per = (kSelBins + nt - 1) / nt;
-        const uint32_t b0 = tid * per, b1 = min(b0 + per, kSelBins);
-        uint32_t mine = 0;
-        for (uint32_t b = b0; b < b1; ++b) mine += hist[b];
-        uint32_t incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
-            if ((int)lane >= o) incl += up;
-        }
-        if (lane == 63) red32[wave] = incl;
-        __syncthreads();
-        uint32_t wbase = 0;
-        for (uint32_t w2 = 0; w2 < wave; ++w2) wbase += red32[w2];
-        incl += wbase;
-        const uint32_t excl = incl - mine;
-        if (excl < rank && rank <= incl) {   // exactly one thread
-            uint32_t c = excl;
-            for (uint32_t b = b0; b < b1; ++b) {
-                const uint32_t h = hist[b];
-                if (c + h >= rank) {
-                    red32[16] = b;
-                    red32[17] = rank - c;      // 1-based rank inside the bin
-                    red32[18] = h;
-                    break;
-                }
-                c += h;
-            }
-        }
-        __syncthreads();
-        const uint32_t bin = red32[16], rk = red32[17], pop = red32[18];
-        const T lo = vmin + ((T)bin << sh);
-        T hi = lo + (((T)1 << sh) - 1);
-        if (hi > vmax || hi < lo) hi = vmax;
-        if (sh == 0) return lo;
-        if (pop <= kSelList) {
-            for (uint32_t i = tid; i < n; i += nt) {
-                const T v = vals[i];
-                if (v >= lo && v <= hi) list[atomicAdd(&red32[20], 1u)] = v;
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < pop; i += nt) {
-                const T v = list[i];
-                uint32_t r = 0;
-                for (uint32_t j2 = 0; j2 < pop; ++j2) {
-                    const T u = list[j2];
-                    r += (u < v || (u == v && j2 < i)) ? 1u : 0u;
-                }
-                if (r + 1 == rk) red[24] = v;
-            }
-            __syncthreads();
-            return (T)red[24];
-        }
-        vmin = lo;
-        vmax = hi;
-        rank = rk;
-    }
-}
-
-// =====================================================================================
 // K5: threshold from a strided sample (plan: sample_stride / sample_plan / sample_rank).
 //
 // K5a adc_sample_kernel: the scan's tiled LUT16 gather over every st-th point of each
@@ -1000,9 +1069,10 @@ __global__ __launch_bounds__(kSelectThreads) void threshold_select_kernel(
     const uint32_t *__restrict__ samp, uint32_t scap, const uint32_t *__restrict__ slot_of,
     uint64_t *__restrict__ thr, uint64_t *__restrict__ pair_thr) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_vals[];   // [scap rounded to 4]
-    uint32_t *s_hist = s_vals + ((scap + 3u) & ~3u);                    // [kSelBins]
-    uint32_t *s_list = s_hist + kSelBins;                               // [kSelList]
-    uint64_t *s_red = reinterpret_cast<uint64_t *>(s_list + kSelList);  // [48]
+    const SelCfg cfg = sel_cfg(scap);
+    uint32_t *s_hist = s_vals + ((scap + 3u) & ~3u);                    // [cfg.bins]
+    uint32_t *s_list = s_hist + cfg.bins;                               // [cfg.list]
+    uint64_t *s_red = reinterpret_cast<uint64_t *>(s_list + cfg.list);  // [48]
     const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const uint32_t ns = min(sbase[(size_t)q * (P + 2) + P], scap);
     const uint32_t total = sbase[(size_t)q * (P + 2) + P + 1];
@@ -1044,7 +1114,7 @@ __global__ __launch_bounds__(kSelectThreads) void threshold_select_kernel(
     __syncthreads();
     // absent samples (0xFFFFFFFF: rejected by the allow-bitmap, padding) sort last; the bound
     // is MAX if the J-th smallest is one of them
-    const uint32_t v = block_select<uint32_t>(s_vals, 4 * n4, J, s_hist, s_list, s_red);
+    const uint32_t v = block_select<uint32_t>(s_vals, 4 * n4, J, cfg, s_hist, s_list, s_red);
     publish(v == 0xFFFFFFFFu ? SCANN_KEY_MAX : (((uint64_t)v << 32) | 0xFFFFFFFFull));
 }
 
@@ -1054,8 +1124,11 @@ __global__ __launch_bounds__(kSelectThreads) void threshold_select_kernel(
 //   reference's AVX2 arithmetic (simd/x86.rs:139-165: 8 FMA lane chains, fixed hsum
 //   tree, scalar tail) -> stable sort by exact -> first k.
 // =====================================================================================
+constexpr uint32_t kDecodeStage = 512;   // selected leaves whose decode tables are staged in LDS
+
 struct SelectArgs {
     uint32_t P, m, k, cap;
+    uint32_t lds_keys;   // capacity of the LDS key array (<= kSortCap)
     int exact_reorder, local_only;
     int unsorted;   // candidates may leave in any order (final stage orders by 96-bit keys)
     const float *queries;
@@ -1117,8 +1190,13 @@ __device__ static void select_fail(const SelectArgs &a, uint32_t q, uint32_t sta
 
 __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexDev ix,
                                                                        SelectArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];      // [kSortCap]
-    uint32_t *s_wave = reinterpret_cast<uint32_t *>(skeys + kSortCap);    // [kSelectThreads/64]
+    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];      // [a.lds_keys]
+    const uint32_t sort_cap = a.lds_keys;
+    const SelCfg cfg = sel_cfg(sort_cap);
+    uint32_t *s_dvb = reinterpret_cast<uint32_t *>(skeys + sort_cap) + (kSelectThreads / 64 + 4) + cfg.bins +
+                      2 * cfg.list + 96;                                  // [kDecodeStage]
+    uint32_t *s_drow = s_dvb + kDecodeStage;                              // [kDecodeStage]
+    uint32_t *s_wave = reinterpret_cast<uint32_t *>(skeys + sort_cap);    // [kSelectThreads/64]
     uint32_t *s_basep = s_wave + kSelectThreads / 64;                     // [4]
     const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const uint32_t m = a.m, k = a.k;
@@ -1136,8 +1214,8 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
     }
     uint64_t *list = a.cand + (size_t)q * a.cap;
 
-    while (cnt > kSortCap) {  // thin with a sampled bound until the list fits in LDS
-        const uint32_t stride = (cnt + kSortCap - 1) / kSortCap;
+    while (cnt > sort_cap) {  // thin with a sampled bound until the list fits in LDS
+        const uint32_t stride = (cnt + sort_cap - 1) / sort_cap;
         const uint32_t ns = (cnt + stride - 1) / stride;
         uint32_t n2 = 1;
         while (n2 < ns) n2 <<= 1;
@@ -1152,28 +1230,49 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
         if (nc >= cnt) break;  // no progress (cannot happen for m <= kMaxPreReorderK)
         cnt = nc;
     }
-    if (cnt > kSortCap) {
+    if (cnt > sort_cap) {
         select_fail(a, q, (uint32_t)SCANN_HIP_RESOURCE_EXHAUSTED);
         return;
     }
 
     const uint32_t nsel = min(m, cnt);   // truncate(pre_reorder_k)  mod.rs:290
+    // decode tables of this query (key base and first CSR row of each selected leaf) in LDS:
+    // the per-candidate chain vbase -> token -> leaf_off -> leaf_ids is otherwise four
+    // dependent global loads
     const uint32_t *vb = a.vbase + (size_t)q * (a.P + 1);
+    const bool staged = a.P <= kDecodeStage;
+    if (staged) {
+        for (uint32_t r = tid; r < a.P; r += nt) {
+            s_dvb[r] = vb[r];
+            s_drow[r] = ix.leaf_off[a.tokens[(size_t)q * a.P + r]];
+        }
+        __syncthreads();
+    }
     auto decode = [&](uint64_t key, uint32_t i) {
         // merge key -> (rank, position in leaf) -> CSR row -> datapoint index
         const uint32_t vpos = (uint32_t)key;
         uint32_t lo = 0, hi = a.P;
-        while (hi - lo > 1) {
-            uint32_t mid = (lo + hi) >> 1;
-            if (vb[mid] <= vpos) lo = mid; else hi = mid;
+        uint32_t csr;
+        if (staged) {
+            while (hi - lo > 1) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (s_dvb[mid] <= vpos) lo = mid; else hi = mid;
+            }
+            csr = s_drow[lo] + (vpos - s_dvb[lo]);
+        } else {
+            while (hi - lo > 1) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (vb[mid] <= vpos) lo = mid; else hi = mid;
+            }
+            csr = ix.leaf_off[a.tokens[(size_t)q * a.P + lo]] + (vpos - vb[lo]);
         }
-        const uint32_t leaf = a.tokens[(size_t)q * a.P + lo];
-        const uint32_t csr = ix.leaf_off[leaf] + (vpos - vb[lo]);
+        {
         const uint32_t idx = ix.leaf_ids ? ix.leaf_ids[csr] : csr;
         a.cand_row[(size_t)q * m + i] = ix.rows_csr ? csr : idx;
         a.cand_key[(size_t)q * m + i] = key;
         a.cand_idx[(size_t)q * m + i] = idx;
         a.cand_dist[(size_t)q * m + i] = ordered_to_f32((uint32_t)(key >> 32));
+        }
     };
 
     if (a.unsorted) {
@@ -1182,9 +1281,9 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
         for (uint32_t i = tid; i < cnt; i += nt) skeys[i] = list[i];
         __syncthreads();
         uint32_t *hist = reinterpret_cast<uint32_t *>(s_basep + 4);
-        uint64_t *slist = reinterpret_cast<uint64_t *>(hist + kSelBins);
-        uint64_t *sred = slist + kSelList;
-        const uint64_t T = cnt > m ? block_select<uint64_t>(skeys, cnt, m, hist, slist, sred) : SCANN_KEY_MAX;
+        uint64_t *slist = reinterpret_cast<uint64_t *>(hist + cfg.bins);
+        uint64_t *sred = slist + cfg.list;
+        const uint64_t T = cnt > m ? block_select<uint64_t>(skeys, cnt, m, cfg, hist, slist, sred) : SCANN_KEY_MAX;
         __syncthreads();
         uint32_t *s_slot = reinterpret_cast<uint32_t *>(sred);   // output cursor
         if (tid == 0) *s_slot = 0;
@@ -1214,22 +1313,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
     __syncthreads();
     bitonic_sort_lds(skeys, n2);
 
-    for (uint32_t i = tid; i < nsel; i += nt) {
-        const uint64_t key = skeys[i];
-        const uint32_t vpos = (uint32_t)key;
-        uint32_t lo = 0, hi = a.P;
-        while (hi - lo > 1) {
-            uint32_t mid = (lo + hi) >> 1;
-            if (vb[mid] <= vpos) lo = mid; else hi = mid;
-        }
-        const uint32_t leaf = a.tokens[(size_t)q * a.P + lo];
-        const uint32_t csr = ix.leaf_off[leaf] + (vpos - vb[lo]);
-        const uint32_t idx = ix.leaf_ids ? ix.leaf_ids[csr] : csr;
-        a.cand_row[(size_t)q * m + i] = ix.rows_csr ? csr : idx;
-        a.cand_key[(size_t)q * m + i] = key;
-        a.cand_idx[(size_t)q * m + i] = idx;
-        a.cand_dist[(size_t)q * m + i] = ordered_to_f32((uint32_t)(key >> 32));
-    }
+    for (uint32_t i = tid; i < nsel; i += nt) decode(skeys[i], i);
     if (tid == 0) a.cand_count[q] = nsel;
 
     if (!a.exact_reorder) {  // AsymmetricHasher::search: k best by approximate distance
@@ -1366,13 +1450,14 @@ __device__ __forceinline__ void wave_argmin96(uint32_t &b_eb, uint64_t &b_kk, ui
     }
 }
 
-__global__ __launch_bounds__(kSelectThreads) void final_topk_kernel(
+template <int NT>
+__global__ __launch_bounds__(NT) void final_topk_kernel(
     uint32_t m, uint32_t k, const uint32_t *__restrict__ cand_count,
     const uint32_t *__restrict__ cand_idx, const uint64_t *__restrict__ cand_key,
     const float *__restrict__ cand_exact, uint32_t *__restrict__ out_idx,
     float *__restrict__ out_dist, uint32_t *__restrict__ out_count) {
-    constexpr int E = kMaxPreReorderK / kSelectThreads;   // candidates per thread
-    constexpr int NWV = kSelectThreads / 64;
+    constexpr int E = 8;                                  // candidates per thread: m <= 8 * NT
+    constexpr int NWV = NT / 64;
     constexpr int E2 = NWV * kTopkMaxK / 64;              // finalists per lane of wave 0
     __shared__ uint32_t s_eb[NWV * kTopkMaxK];
     __shared__ uint64_t s_kk[NWV * kTopkMaxK];
@@ -1384,7 +1469,7 @@ __global__ __launch_bounds__(kSelectThreads) void final_topk_kernel(
     uint64_t kk[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const uint32_t slot = e * kSelectThreads + tid;
+        const uint32_t slot = e * (uint32_t)NT + tid;
         const bool alive = slot < nsel;
         eb[e] = alive ? f32_to_ordered(cand_exact[(size_t)q * m + slot]) : 0xFFFFFFFFu;
         kk[e] = alive ? cand_key[(size_t)q * m + slot] : SCANN_KEY_MAX;
@@ -1395,14 +1480,14 @@ __global__ __launch_bounds__(kSelectThreads) void final_topk_kernel(
         uint64_t b_kk = SCANN_KEY_MAX;
 #pragma unroll
         for (int e = 0; e < E; ++e)
-            if ((uint32_t)e * kSelectThreads < nsel && (eb[e] < b_eb || (eb[e] == b_eb && kk[e] < b_kk))) {
+            if ((uint32_t)e * (uint32_t)NT < nsel && (eb[e] < b_eb || (eb[e] == b_eb && kk[e] < b_kk))) {
                 b_eb = eb[e];
                 b_kk = kk[e];
-                b_sl = e * kSelectThreads + tid;
+                b_sl = e * (uint32_t)NT + tid;
             }
         wave_argmin96(b_eb, b_kk, b_sl);
-        if (b_sl != 0xFFFFFFFFu && (b_sl & (kSelectThreads - 1)) == tid) {
-            const uint32_t we = b_sl / kSelectThreads;
+        if (b_sl != 0xFFFFFFFFu && (b_sl & ((uint32_t)NT - 1)) == tid) {
+            const uint32_t we = b_sl / (uint32_t)NT;
 #pragma unroll
             for (int e = 0; e < E; ++e)
                 if ((uint32_t)e == we) {
@@ -1712,18 +1797,33 @@ static int launch_partition_stage(const TxhIndexDev &ix, const TxhWork &w, hipSt
         LAUNCH_CHECK();
         return SCANN_HIP_OK;
     }
-    const size_t lds1 = (size_t)kCsQT * ix.dim * sizeof(float);
-    SCANN_TRY(set_dyn_lds(centroid_scores_kernel, lds1));
-    hipLaunchKernelGGL(centroid_scores_kernel, dim3(ceil_div_u32(ix.L, 64), ceil_div_u32(w.nq, kCsQT)),
-                       dim3(64), lds1, st, ix.centers, ix.L, ix.dim, w.queries, w.nq, w.q_stride,
-                       w.cdist);
+    // queries per single-wave block: fewer when the grid would not fill the chip (one thread per
+    // centroid, so a block's work is 64 centroids x QT queries)
+    const uint64_t waves16 = (uint64_t)ceil_div_u32(ix.L, 64) * ceil_div_u32(w.nq, 16);
+    if (waves16 >= 8192) {
+        const size_t lds1 = (size_t)16 * ix.dim * sizeof(float);
+        SCANN_TRY(set_dyn_lds(centroid_scores_kernel<16>, lds1));
+        hipLaunchKernelGGL(centroid_scores_kernel<16>, dim3(ceil_div_u32(ix.L, 64), ceil_div_u32(w.nq, 16)),
+                           dim3(64), lds1, st, ix.centers, ix.L, ix.dim, w.queries, w.nq, w.q_stride,
+                           w.cdist);
+    } else {
+        const size_t lds1 = (size_t)4 * ix.dim * sizeof(float);
+        SCANN_TRY(set_dyn_lds(centroid_scores_kernel<4>, lds1));
+        hipLaunchKernelGGL(centroid_scores_kernel<4>, dim3(ceil_div_u32(ix.L, 64), ceil_div_u32(w.nq, 4)),
+                           dim3(64), lds1, st, ix.centers, ix.L, ix.dim, w.queries, w.nq, w.q_stride,
+                           w.cdist);
+    }
     LAUNCH_CHECK();
     const uint32_t n2 = next_pow2_u32(ix.L);
-    const size_t lds2 = (size_t)n2 * sizeof(uint64_t);
+    // select path when P is small against L: rank-select the P-th key, sort P keys instead of L
+    const uint32_t p2 = (w.P * 4u <= n2) ? next_pow2_u32(std::max(1u, w.P)) : 0u;
+    const SelCfg lcfg = sel_cfg(ix.L);
+    const size_t lds2 = (size_t)(n2 + p2) * sizeof(uint64_t) + (size_t)lcfg.bins * 4 + (size_t)lcfg.list * 8 +
+                        48 * 8 + 64 * 4;
     SCANN_TRY(set_dyn_lds(select_leaves_kernel, lds2));
-    hipLaunchKernelGGL(select_leaves_kernel, dim3(w.nq), dim3(kSelectThreads), lds2, st, w.cdist,
-                       ix.L, n2, w.P, ix.leaf_gsize, ix.leaf_off, w.st, w.tokens, w.token_dists, w.vbase,
-                       w.sbase);
+    hipLaunchKernelGGL(select_leaves_kernel, dim3(w.nq), dim3(p2 && ix.L <= 4096 ? 256u : kSelectThreads), lds2, st,
+                       w.cdist, ix.L, n2, w.P, p2, ix.leaf_gsize, ix.leaf_off, w.st, w.tokens, w.token_dists,
+                       w.vbase, w.sbase);
     LAUNCH_CHECK();
     return SCANN_HIP_OK;
 }
@@ -1747,7 +1847,8 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
         LAUNCH_CHECK();
     }
     {
-        const size_t lds_thr = ((size_t)((w.scap + 3u) & ~3u) + kSelBins + kSelList) * 4 + 48 * 8;
+        const SelCfg tcfg = sel_cfg(w.scap);
+        const size_t lds_thr = ((size_t)((w.scap + 3u) & ~3u) + tcfg.bins + tcfg.list) * 4 + 48 * 8;
         const uint32_t nt = w.scap > 8192 ? kSelectThreads : 256u;
         SCANN_TRY(set_dyn_lds(threshold_select_kernel, lds_thr));
         hipLaunchKernelGGL(threshold_select_kernel, dim3(w.nq), dim3(nt), lds_thr, st, w.P, w.m, w.st,
@@ -1818,10 +1919,16 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
     s.cand_idx = w.cand_idx; s.cand_dist = w.cand_dist; s.cand_exact = w.cand_exact;
     s.cand_count = w.cand_count; s.out_idx = w.out_idx; s.out_dist = w.out_dist;
     s.out_count = w.out_count;
-    const size_t lds_sel = (size_t)kSortCap * 8 + (size_t)(kSelectThreads / 64 + 4) * 4 +
-                           (size_t)kSelBins * 4 + (size_t)kSelList * 8 + 48 * 8;
+    // LDS key array: the candidate capacity rounded up to a power of two (bitonic path), at
+    // most kSortCap; small lists run with 256-thread blocks so several fit a CU
+    const uint32_t lds_keys = std::min(kSortCap, next_pow2_u32(std::max(w.cap, 64u)));
+    s.lds_keys = lds_keys;
+    const SelCfg scfg = sel_cfg(lds_keys);
+    const size_t lds_sel = (size_t)lds_keys * 8 + (size_t)(kSelectThreads / 64 + 4) * 4 +
+                           (size_t)scfg.bins * 4 + (size_t)scfg.list * 8 + 48 * 8 + 2 * kDecodeStage * 4;
+    const uint32_t sel_threads = lds_keys <= 4096 ? 256u : kSelectThreads;
     SCANN_TRY(set_dyn_lds(select_rerank_kernel, lds_sel));
-    hipLaunchKernelGGL(select_rerank_kernel, dim3(w.nq), dim3(kSelectThreads), lds_sel, st, ix, s);
+    hipLaunchKernelGGL(select_rerank_kernel, dim3(w.nq), dim3(sel_threads), lds_sel, st, ix, s);
     LAUNCH_CHECK();
     if (!w.exact_reorder) return SCANN_HIP_OK;
     const size_t lds_rr = (size_t)ix.dim * 4;
@@ -1831,9 +1938,13 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
     LAUNCH_CHECK();
     if (local_only) return SCANN_HIP_OK;
     if (unsorted) {
-        hipLaunchKernelGGL(final_topk_kernel, dim3(w.nq), dim3(kSelectThreads), 0, st, w.m, w.k,
-                           w.cand_count, w.cand_idx, w.cand_key, w.cand_exact, w.out_idx, w.out_dist,
-                           w.out_count);
+        if (w.m <= 2048) {
+            hipLaunchKernelGGL(final_topk_kernel<256>, dim3(w.nq), dim3(256), 0, st, w.m, w.k, w.cand_count,
+                               w.cand_idx, w.cand_key, w.cand_exact, w.out_idx, w.out_dist, w.out_count);
+        } else {
+            hipLaunchKernelGGL(final_topk_kernel<1024>, dim3(w.nq), dim3(1024), 0, st, w.m, w.k, w.cand_count,
+                               w.cand_idx, w.cand_key, w.cand_exact, w.out_idx, w.out_dist, w.out_count);
+        }
         LAUNCH_CHECK();
         return SCANN_HIP_OK;
     }
