@@ -184,13 +184,20 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    def all_gather(dst, src):
+    def all_gather_start(dst, src):
+        """Enqueue the gather of this step's packed candidates; returns a handle for
+        all_gather_finish.  NCCL/RCCL: asynchronous on the process group's own stream, so the
+        next step's local stage overlaps the transfer."""
         if args.backend == "nccl":
-            dist.all_gather_into_tensor(dst, src)
-        else:   # rehearsal path: stage through host memory
-            parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(world)]
-            dist.all_gather(parts, src.cpu())
-            dst.copy_(torch.stack(parts).to(dst.device))
+            return dist.all_gather_into_tensor(dst, src, async_op=True)
+        parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(world)]   # rehearsal path
+        dist.all_gather(parts, src.cpu())
+        dst.copy_(torch.stack(parts).to(dst.device))
+        return None
+
+    def all_gather_finish(work):
+        if work is not None:
+            work.wait()   # the current stream waits for the collective; the host does not block
 
     L = hip.load()
     n, dim, S, K, k, Q = args.n, args.dim, args.subspaces, 16, args.k, args.batch
@@ -311,12 +318,24 @@ def main():
             kb, ib, cb = Q * m_local * 8, Q * m_local * 4, Q * 4
             sec = [0, kb, kb + ib, kb + 2 * ib]
             pack_bytes = (kb + 2 * ib + cb + 255) // 256 * 256
-            pack = torch.zeros((pack_bytes,), dtype=torch.uint8, device=device)
-            g_pack = torch.zeros((world, pack_bytes), dtype=torch.uint8, device=device)
+            # double-buffered: step i+1's local stage runs while step i's gather is in flight
+            packs = [torch.zeros((pack_bytes,), dtype=torch.uint8, device=device) for _ in range(2)]
+            g_packs = [torch.zeros((world, pack_bytes), dtype=torch.uint8, device=device) for _ in range(2)]
             mstatus = torch.zeros((1,), dtype=torch.int32, device=device)
+            pending = []
 
             def sect(t, i):
                 return ctypes.c_void_p(t.data_ptr() + sec[i])
+
+            def finish_step():
+                work, b = pending.pop(0)
+                all_gather_finish(work)
+                g_pack = g_packs[b]
+                hip.check(L.scann_hip_txh_merge_device(hip.context(local_rank), world, Q, m_local, m,
+                                                       k, pack_bytes, sect(g_pack, 0), sect(g_pack, 1),
+                                                       sect(g_pack, 2), sect(g_pack, 3), dev_ptr(out_idx),
+                                                       dev_ptr(out_dist), dev_ptr(out_cnt),
+                                                       dev_ptr(mstatus), sptr))
         hip.check(L.scann_hip_index_reserve(index.h, Q, k, ctypes.byref(lopts)))
 
         def step(i):
@@ -326,20 +345,27 @@ def main():
                                                             ctypes.byref(lopts), dev_ptr(out_idx),
                                                             dev_ptr(out_dist), dev_ptr(out_cnt), sptr))
             else:
+                # software pipeline over steps: local stage(i) -> gather(i) in flight ->
+                # [merge(i-1)] ; the last merge is drained by flush_steps()
+                b = i & 1
+                pack = packs[b]
                 hip.check(L.scann_hip_txh_search_local_device(index.h, dev_ptr(qd), Q, dim, k,
                                                               ctypes.byref(lopts), sect(pack, 0),
                                                               sect(pack, 1), sect(pack, 2),
                                                               sect(pack, 3), sptr))
-                all_gather(g_pack, pack)
-                hip.check(L.scann_hip_txh_merge_device(hip.context(local_rank), world, Q, m_local, m,
-                                                       k, pack_bytes, sect(g_pack, 0), sect(g_pack, 1),
-                                                       sect(g_pack, 2), sect(g_pack, 3), dev_ptr(out_idx),
-                                                       dev_ptr(out_dist), dev_ptr(out_cnt),
-                                                       dev_ptr(mstatus), sptr))
+                work = all_gather_start(g_packs[b], pack)
+                if pending:
+                    finish_step()
+                pending.append((work, b))
+
+        def flush_steps():
+            while world > 1 and pending:
+                finish_step()
 
         # ---------------- warmup, then EXACTLY K timed steps -------------------------------
         for i in range(args.warmup):
             step(i)
+        flush_steps()
         torch.cuda.synchronize()
         hip.check(L.scann_hip_index_last_device_status(index.h, sptr))
         index.enable_timing(True)
@@ -349,6 +375,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(i)
+        flush_steps()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -461,7 +488,11 @@ def main():
                                     "%d B per query (N_local*S/2 codes + S*16*4 LUT + k*8 out) x %d "
                                     "queries per launch (rank 0)") % (algo_bytes_per_query, Q)}
         tr = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tr):
+        # PMC-measured HBM bytes per launch (profiles/traffic.json, collected with rocprofv3 --pmc
+        # on this workload's default configuration only: single GPU, 1M x 128, batch 1024)
+        default_cfg = world == 1 and n == 1_000_000 and dim == 128 and Q == 1024 and \
+            (args.workload != "ah" or m == 5000) and args.workload != "txh"
+        if os.path.exists(tr) and default_cfg:
             try:
                 roof["traffic"] = json.load(open(tr)).get(args.workload)
             except Exception:
