@@ -350,25 +350,35 @@ __global__ __launch_bounds__(kBfSelectThreads) void bf_threshold_kernel(
     const float *__restrict__ sample, uint32_t ns, uint32_t row_mult, uint32_t k, int direct,
     uint64_t *__restrict__ thr, uint32_t *__restrict__ out_idx, float *__restrict__ out_dist,
     uint32_t *__restrict__ out_count) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
+    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];   // [next_pow2(ns)]
     const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     uint32_t n2 = 1;
     while (n2 < ns) n2 <<= 1;
+    if (!direct) {
+        // the k-th smallest sample key bounds the k-th smallest key of the whole dataset; a
+        // histogram rank-select finds it without sorting the 8192 samples
+        const SelCfg cfg = sel_cfg(ns);
+        uint32_t *s_hist = reinterpret_cast<uint32_t *>(skeys + n2);
+        uint64_t *s_list = reinterpret_cast<uint64_t *>(s_hist + cfg.bins);
+        uint64_t *s_red = s_list + cfg.list;
+        for (uint32_t i = tid; i < ns; i += nt) skeys[i] = make_key(sample[(size_t)q * ns + i], i * row_mult);
+        __syncthreads();
+        uint64_t T = SCANN_KEY_MAX;
+        if (ns >= k && k > 0) T = block_select<uint64_t>(skeys, ns, k, cfg, s_hist, s_list, s_red);
+        if (tid == 0) thr[q] = T;
+        return;
+    }
     for (uint32_t i = tid; i < n2; i += nt)
         skeys[i] = (i < ns) ? make_key(sample[(size_t)q * ns + i], i * row_mult) : SCANN_KEY_MAX;
     __syncthreads();
     bitonic_sort_lds(skeys, n2);
-    if (direct) {
-        const uint32_t nout = min(k, ns);
-        for (uint32_t i = tid; i < k; i += nt) {
-            out_idx[(size_t)q * k + i] = (i < nout) ? (uint32_t)skeys[i] : kBfInvalid;
-            out_dist[(size_t)q * k + i] =
-                (i < nout) ? ordered_to_f32((uint32_t)(skeys[i] >> 32)) : __builtin_inff();
-        }
-        if (tid == 0) out_count[q] = nout;
-    } else if (tid == 0) {
-        thr[q] = (ns >= k && k > 0) ? skeys[k - 1] : SCANN_KEY_MAX;
+    const uint32_t nout = min(k, ns);
+    for (uint32_t i = tid; i < k; i += nt) {
+        out_idx[(size_t)q * k + i] = (i < nout) ? (uint32_t)skeys[i] : kBfInvalid;
+        out_dist[(size_t)q * k + i] =
+            (i < nout) ? ordered_to_f32((uint32_t)(skeys[i] >> 32)) : __builtin_inff();
     }
+    if (tid == 0) out_count[q] = nout;
 }
 
 // In-place stable compaction (keys <= T) by one block.
@@ -436,16 +446,33 @@ __global__ __launch_bounds__(kBfSelectThreads) void bf_select_kernel(
         }
         return;
     }
-    uint32_t n2 = 1;
-    while (n2 < cnt) n2 <<= 1;
-    for (uint32_t i = tid; i < n2; i += nt) skeys[i] = (i < cnt) ? list[i] : SCANN_KEY_MAX;
-    __syncthreads();
-    bitonic_sort_lds(skeys, n2);
+    // the k smallest of the cnt survivors: rank-select the k-th key, sort only those k
     const uint32_t nout = min(k, cnt);
+    uint32_t k2 = 1;
+    while (k2 < nout) k2 <<= 1;
+    const SelCfg cfg = sel_cfg(kBfSortCap);
+    uint64_t *s_top = reinterpret_cast<uint64_t *>(s_base + 4);            // [kBfMaxK]
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_top + kBfMaxK);
+    uint64_t *s_list = reinterpret_cast<uint64_t *>(s_hist + cfg.bins);
+    uint64_t *s_red = s_list + cfg.list;
+    for (uint32_t i = tid; i < cnt; i += nt) skeys[i] = list[i];
+    for (uint32_t i = tid; i < k2; i += nt) s_top[i] = SCANN_KEY_MAX;
+    if (tid == 0) *s_base = 0;
+    __syncthreads();
+    if (nout) {
+        const uint64_t T = cnt > nout ? block_select<uint64_t>(skeys, cnt, nout, cfg, s_hist, s_list, s_red)
+                                      : SCANN_KEY_MAX;
+        for (uint32_t i = tid; i < cnt; i += nt) {
+            const uint64_t key = skeys[i];
+            if (key <= T) s_top[atomicAdd(s_base, 1u)] = key;   // exactly nout keys (unique)
+        }
+        __syncthreads();
+        bitonic_sort_lds(s_top, k2);
+    }
     for (uint32_t i = tid; i < k; i += nt) {
-        out_idx[(size_t)q * k + i] = (i < nout) ? (uint32_t)skeys[i] : kBfInvalid;
+        out_idx[(size_t)q * k + i] = (i < nout) ? (uint32_t)s_top[i] : kBfInvalid;
         out_dist[(size_t)q * k + i] =
-            (i < nout) ? ordered_to_f32((uint32_t)(skeys[i] >> 32)) : __builtin_inff();
+            (i < nout) ? ordered_to_f32((uint32_t)(s_top[i] >> 32)) : __builtin_inff();
     }
     if (tid == 0) out_count[q] = nout;
 }
@@ -597,7 +624,8 @@ static int enqueue_search(const BfIndexDev &ix, BfWorkspace &w, const BfPlan &pl
     if (pl.direct && ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
     SCANN_TRY(launch_pass(ix, a, st));
     if (pl.direct && ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
-    const size_t lds_thr = (size_t)next_pow2_u32(pl.ns) * 8;
+    const SelCfg tcfg = sel_cfg(pl.ns);
+    const size_t lds_thr = (size_t)next_pow2_u32(pl.ns) * 8 + (size_t)tcfg.bins * 4 + (size_t)tcfg.list * 8 + 48 * 8;
     SCANN_TRY(set_dyn_lds(bf_threshold_kernel, lds_thr));
     hipLaunchKernelGGL(bf_threshold_kernel, dim3(nq), dim3(kBfSelectThreads), lds_thr, st,
                        w.sample.as<float>(), pl.ns, pl.rs, pl.k, pl.direct ? 1 : 0,
@@ -619,7 +647,9 @@ static int enqueue_search(const BfIndexDev &ix, BfWorkspace &w, const BfPlan &pl
     if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
     SCANN_TRY(launch_pass(ix, b, st));
     if (ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
-    const size_t lds_sel = (size_t)kBfSortCap * 8 + (kBfSelectThreads / 64 + 4) * 4;
+    const SelCfg scfg = sel_cfg(kBfSortCap);
+    const size_t lds_sel = (size_t)kBfSortCap * 8 + (kBfSelectThreads / 64 + 4) * 4 + (size_t)kBfMaxK * 8 +
+                           (size_t)scfg.bins * 4 + (size_t)scfg.list * 8 + 48 * 8;
     SCANN_TRY(set_dyn_lds(bf_select_kernel, lds_sel));
     hipLaunchKernelGGL(bf_select_kernel, dim3(nq), dim3(kBfSelectThreads), lds_sel, st, pl.k, pl.cap,
                        w.cand_cnt.as<uint32_t>(), w.cand.as<uint64_t>(), w.counters.as<uint32_t>(),

@@ -117,6 +117,152 @@ __device__ static inline uint32_t wave_prefix_count(bool pred, uint32_t *total) 
     *total = (uint32_t)__popcll(m);
     return (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
+
+constexpr uint32_t kSelBinsMax = 4096;   // histogram bins of block_select (large inputs)
+constexpr uint32_t kSelListMax = 1024;   // members of the rank's bin ranked exactly
+
+// =====================================================================================
+// block_select: value of 1-based rank `rank` among vals[0..n) (LDS), ties allowed.  One
+// pass over [min, max] of the values with kSelBins histogram bins ((v - min) >> sh, monotone)
+// finds the rank's bin; a bin of <= kSelList members is ranked exactly by counting,
+// otherwise the bin becomes the new range.  Every thread of the block must call; all get
+// the same result.  Values equal to ~0 are "absent": they sort last and do not widen the
+// range; if fewer than `rank` values are present the result is ~0.
+// hist: LDS u32[cfg.bins]; list: LDS T[cfg.list]; red: LDS u64[48].
+// =====================================================================================
+struct SelCfg {
+    uint32_t bins, list;
+};
+// Histogram bins / exact-rank list size for selecting among at most n values: small inputs
+// take small tables so that several blocks share a CU's LDS.
+__host__ __device__ static inline SelCfg sel_cfg(uint32_t n) {
+    SelCfg c;
+    c.bins = n <= 4096u ? 1024u : kSelBinsMax;
+    c.list = n <= 4096u ? 256u : kSelListMax;
+    return c;
+}
+
+template <typename T>
+__device__ __forceinline__ T shfl_xor_t(T v, int d) {
+    if constexpr (sizeof(T) == 8) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d);
+        return ((uint64_t)hi << 32) | lo;
+    } else {
+        return (T)__shfl_xor((int)v, d);
+    }
+}
+
+template <typename T>
+__device__ static T block_select(const T *vals, uint32_t n, uint32_t rank, SelCfg cfg, uint32_t *hist,
+                                 T *list, uint64_t *red) {
+    const uint32_t kSelBins = cfg.bins, kSelList = cfg.list;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nt >> 6;
+    constexpr T kAbsent = ~(T)0;
+    T vmin = kAbsent, vmax = 0;
+    uint32_t present = 0;
+    for (uint32_t i = tid; i < n; i += nt) {
+        const T v = vals[i];
+        if (v != kAbsent) {
+            vmin = v < vmin ? v : vmin;
+            vmax = v > vmax ? v : vmax;
+            ++present;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const T a = shfl_xor_t(vmin, o), b = shfl_xor_t(vmax, o);
+        vmin = a < vmin ? a : vmin;
+        vmax = b > vmax ? b : vmax;
+        present += (uint32_t)__shfl_xor((int)present, o);
+    }
+    uint32_t *red32 = reinterpret_cast<uint32_t *>(red + 32);   // [0..15] wave sums, 16.. results
+    if (lane == 0) {
+        red[wave] = vmin;
+        red[16 + wave] = vmax;
+        red32[wave] = present;
+    }
+    __syncthreads();
+    present = 0;
+    for (uint32_t w2 = 0; w2 < nwaves; ++w2) {
+        const T a = (T)red[w2], b = (T)red[16 + w2];
+        vmin = a < vmin ? a : vmin;
+        vmax = b > vmax ? b : vmax;
+        present += red32[w2];
+    }
+    if (present < rank) return kAbsent;   // block-uniform
+    for (;;) {
+        const T range = vmax - vmin;
+        uint32_t sh = 0;
+        while ((range >> sh) >= (T)kSelBins) ++sh;
+        __syncthreads();          // previous readers of hist / red32 are done
+        for (uint32_t i = tid; i < kSelBins; i += nt) hist[i] = 0;
+        if (tid == 0) red32[20] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += nt) {
+            const T v = vals[i];
+            if (v >= vmin && v <= vmax) atomicAdd(&hist[(uint32_t)((v - vmin) >> sh)], 1u);
+        }
+        __syncthreads();
+        // bin of the rank: block-wide inclusive scan over per-thread groups of bins
+        const uint32_t per = (kSelBins + nt - 1) / nt;
+        const uint32_t b0 = tid * per, b1 = min(b0 + per, kSelBins);
+        uint32_t mine = 0;
+        for (uint32_t b = b0; b < b1; ++b) mine += hist[b];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+            if ((int)lane >= o) incl += up;
+        }
+        if (lane == 63) red32[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (uint32_t w2 = 0; w2 < wave; ++w2) wbase += red32[w2];
+        incl += wbase;
+        const uint32_t excl = incl - mine;
+        if (excl < rank && rank <= incl) {   // exactly one thread
+            uint32_t c = excl;
+            for (uint32_t b = b0; b < b1; ++b) {
+                const uint32_t h = hist[b];
+                if (c + h >= rank) {
+                    red32[16] = b;
+                    red32[17] = rank - c;      // 1-based rank inside the bin
+                    red32[18] = h;
+                    break;
+                }
+                c += h;
+            }
+        }
+        __syncthreads();
+        const uint32_t bin = red32[16], rk = red32[17], pop = red32[18];
+        const T lo = vmin + ((T)bin << sh);
+        T hi = lo + (((T)1 << sh) - 1);
+        if (hi > vmax || hi < lo) hi = vmax;
+        if (sh == 0) return lo;
+        if (pop <= kSelList) {
+            for (uint32_t i = tid; i < n; i += nt) {
+                const T v = vals[i];
+                if (v >= lo && v <= hi) list[atomicAdd(&red32[20], 1u)] = v;
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < pop; i += nt) {
+                const T v = list[i];
+                uint32_t r = 0;
+                for (uint32_t j2 = 0; j2 < pop; ++j2) {
+                    const T u = list[j2];
+                    r += (u < v || (u == v && j2 < i)) ? 1u : 0u;
+                }
+                if (r + 1 == rk) red[24] = v;
+            }
+            __syncthreads();
+            return (T)red[24];
+        }
+        vmin = lo;
+        vmax = hi;
+        rank = rk;
+    }
+}
+
 #endif
 
 }  // namespace scann

@@ -26,8 +26,6 @@ constexpr uint32_t kSortCap = 16384;                      // u64 keys sorted in 
 #endif
 constexpr uint32_t kSampleTarget = SCANN_SAMPLE_TARGET;   // max sample points per query (LDS of the select)
 constexpr uint32_t kSampleMin = SCANN_SAMPLE_MIN;         // min sample points per query
-constexpr uint32_t kSampleBins = 4096;                    // histogram bins of the threshold select
-constexpr uint32_t kSampleList = 1024;                    // members of the rank's bin ranked exactly
 constexpr uint32_t kMaxPreReorderK = 8192;                // m limit of the LDS select
 constexpr uint32_t kMaxPartitionsToSearch = 4096;
 constexpr uint32_t kMaxLeavesSelect = 16384;              // L limit of the LDS leaf sort
