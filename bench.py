@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--num-points", dest="n", type=int, default=1_000_000)
     p.add_argument("--dim", type=int, default=128)
     p.add_argument("--subspaces", type=int, default=32)
+    p.add_argument("--num-codes", type=int, default=16,
+                   help="codes per subspace: <= 16 = LUT16 (4-bit), <= 256 = byte codes")
     p.add_argument("--batch", type=int, default=1024)
     p.add_argument("--k", type=int, default=10)
     p.add_argument("--pre-reorder-k", type=int, default=5000)
@@ -200,7 +202,7 @@ def main():
             work.wait()   # the current stream waits for the collective; the host does not block
 
     L = hip.load()
-    n, dim, S, K, k, Q = args.n, args.dim, args.subspaces, 16, args.k, args.batch
+    n, dim, S, K, k, Q = args.n, args.dim, args.subspaces, args.num_codes, args.k, args.batch
     m = args.pre_reorder_k
     stride = hip.compute_stride(dim)
     stream = torch.cuda.current_stream().cuda_stream
@@ -233,7 +235,8 @@ def main():
         data = txh_state["data"]
     log("data %.1fs (n_local=%d)" % (time.time() - t0, n_loc))
 
-    workload_name = {"ah": "AsymmetricHasher LUT16 S=%d K=16 + exact re-rank" % S,
+    workload_name = {"ah": "AsymmetricHasher %s S=%d K=%d + exact re-rank"
+                           % ("LUT16" if K <= 16 else "byte codes", S, K),
                      "bf_dot": "BruteForceSearcher.search_batched DotProduct (f32 MFMA)",
                      "txh": "Tree-X-Hybrid L=%d P=%d LUT16 S=%d + exact re-rank"
                             % (args.leaves, args.partitions_to_search, S)}[args.workload]
@@ -286,7 +289,8 @@ def main():
                     partitions_to_search=world, pre_reorder_multiplier=float(m) / k,
                     data_is_csr_order=True, device=local_rank)
             # 16 002 128 B at N = 1; per launch a rank scans its n_loc points
-            algo_bytes_per_query = n_loc * (S // 2) + S * 16 * 4 + k * 8
+            code_bytes = S // 2 if K <= 16 else S
+            algo_bytes_per_query = n_loc * code_bytes + S * K * 4 + k * 8
         opts.pre_reorder_k = m
         opts.exact_reorder = 1
     log("index %.1fs" % (time.time() - t0))
@@ -485,7 +489,7 @@ def main():
                     "kernel_ms": kernel_ms,
                     "algorithmic": ("%d B per query (scanned codes + LUTs of the selected leaves) x %d "
                                     "queries per launch (rank 0)" if args.workload == "txh" else
-                                    "%d B per query (N_local*S/2 codes + S*16*4 LUT + k*8 out) x %d "
+                                    "%d B per query (N_local*code_bytes + S*K*4 LUT + k*8 out) x %d "
                                     "queries per launch (rank 0)") % (algo_bytes_per_query, Q)}
         tr = os.path.join(ROOT, "profiles", "traffic.json")
         # PMC-measured HBM bytes per launch (profiles/traffic.json, collected with rocprofv3 --pmc

@@ -115,7 +115,8 @@ typedef struct {
     uint64_t n_local;
     const float *codebook;
     uint32_t num_subspaces;      /* S */
-    uint32_t num_codes;          /* K <= 16 (LUT16) */
+    uint32_t num_codes;          /* K <= 16: LUT16 (4-bit codes, S in {8,16,24,32,48,64});
+                                  * 16 < K <= 256: byte codes (S in {4,8,16}) */
     uint32_t dims_per_subspace;  /* dsub; S * dsub must equal dim (codebook.rs:154-159) */
     const uint8_t *codes;
     int32_t codes_packed4;

@@ -227,10 +227,16 @@ int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_
         return fail(SCANN_HIP_INVALID_ARGUMENT,
                     "Dimensionality " + std::to_string(d->dim) +
                         " must be divisible by num_subspaces " + std::to_string(S));
-    if (K == 0 || K > 16)
-        return fail(SCANN_HIP_UNIMPLEMENTED, "LUT16 path requires 1 <= num_codes <= 16");
-    if (S % 8 != 0 || S > 64 || S == 40 || S == 56)
-        return fail(SCANN_HIP_UNIMPLEMENTED, "num_subspaces must be 8,16,24,32,48 or 64");
+    if (K == 0 || K > 256)
+        return fail(SCANN_HIP_UNIMPLEMENTED, "num_codes must be 1..256");
+    // K <= 16: 4-bit packed codes + 16-slot tables (LUT16); else bytes + 256-slot tables
+    const uint32_t bits = K <= 16 ? 4u : 8u;
+    if (bits == 4 && (S % 8 != 0 || S > 64 || S == 40 || S == 56))
+        return fail(SCANN_HIP_UNIMPLEMENTED, "num_subspaces must be 8,16,24,32,48 or 64 for num_codes <= 16");
+    if (bits == 8 && S != 4 && S != 8 && S != 16)
+        return fail(SCANN_HIP_UNIMPLEMENTED, "num_subspaces must be 4, 8 or 16 for 16 < num_codes <= 256");
+    if (bits == 8 && d->codes_packed4)
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "codes_packed4 needs num_codes <= 16");
     if (!ah) {
         if (!d->centers || !d->leaf_offsets || !d->leaf_ids)
             return fail(SCANN_HIP_INVALID_ARGUMENT, "centers/leaf_offsets/leaf_ids null");
@@ -258,7 +264,7 @@ int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_
     if (s != SCANN_HIP_OK) return bail(s);
 
     const uint32_t L = ah ? 1u : d->num_partitions;
-    const uint32_t nw = S / 8;
+    const uint32_t nw = bits == 4 ? S / 8 : S / 4;
     const uint64_t n = d->n_local;
 
     // leaf tables
@@ -298,7 +304,8 @@ int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_
                 if (c[sidx] >= K) {
                     return bail(fail(SCANN_HIP_INVALID_ARGUMENT, "code value >= num_codes"));
                 }
-                w[sidx >> 3] |= (uint32_t)(c[sidx] & 0x0F) << (4 * (sidx & 7u));
+                if (bits == 4) w[sidx >> 3] |= (uint32_t)(c[sidx] & 0x0F) << (4 * (sidx & 7u));
+                else w[sidx >> 2] |= (uint32_t)c[sidx] << (8 * (sidx & 3u));
             }
         }
         code_words = words.data();
@@ -325,6 +332,8 @@ int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_
     t.K = K;
     t.dsub = dsub;
     t.nw = nw;
+    t.code_bits = bits;
+    t.kp = bits == 4 ? 16u : 256u;
     t.n_local = n;
     t.centers = ah ? nullptr : ix->d_centers.as<float>();
     t.leaf_off = ix->d_leaf_off.as<uint32_t>();
@@ -429,7 +438,7 @@ static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallP
     SCANN_TRY(s.pair_vbase.ensure((size_t)max_slots * 4));
     SCANN_TRY(s.pair_thr.ensure((size_t)max_slots * 8));
     SCANN_TRY(s.slot_of.ensure((size_t)nq * P * 4));
-    SCANN_TRY(s.lutq.ensure((size_t)max_quads * t.S * 16 * 4 * 4));
+    SCANN_TRY(s.lutq.ensure((size_t)max_quads * t.S * t.kp * 4 * 4));
     SCANN_TRY(s.thr.ensure((size_t)nq * 8));
     SCANN_TRY(s.cand_cnt.ensure((size_t)nq * 4));
     SCANN_TRY(s.cand.ensure((size_t)nq * p.cap * 8));

@@ -76,6 +76,7 @@ __host__ __device__ static inline uint32_t sample_rank(uint32_t m, uint32_t st) 
 
 struct TxhIndexDev {
     uint32_t dim, stride, L, S, K, dsub, nw;
+    uint32_t code_bits, kp;       // 4-bit codes / 16 table slots (K <= 16) or 8-bit / 256 slots
     uint64_t n_local;
     const float *centers;         // [L][dim]; nullptr in AsymmetricHasher mode
     const uint32_t *leaf_off;     // [L+1] local CSR offsets

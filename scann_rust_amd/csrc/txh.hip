@@ -152,12 +152,11 @@ __global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
         s_scan[32 + wave] = i_t;
     }
     __syncthreads();
-    uint32_t b_g = 0, b_s = 0, b_t = 0, t_g = 0, t_s = 0, t_t = 0;
+    uint32_t b_g = 0, b_s = 0, t_g = 0, t_s = 0, t_t = 0;
     for (uint32_t w2 = 0; w2 < nwaves; ++w2) {
         if (w2 < wave) {
             b_g += s_scan[w2];
             b_s += s_scan[16 + w2];
-            b_t += s_scan[32 + w2];
         }
         t_g += s_scan[w2];
         t_s += s_scan[16 + w2];
@@ -325,7 +324,8 @@ __global__ void worklist_fill_kernel(uint32_t nq, uint32_t P, int ah, const uint
 // K4: LUT build.  tree_x_hybrid/mod.rs:309-319 + hashes/lut.rs:47-70 +
 // hashes/codebook.rs:98-115: q' = q - centroid (if residual); LUT[s][c] = sequential
 // scalar sum over dsub of (q'_j - cb_j)^2.  Output layout is quad-interleaved
-// [quad][s][16][4] so that the scan reads four queries' entries with one ds_read_b128.
+// [quad][s][kp][4] (kp = 16 or 256 slots) so that the scan reads four queries' entries with
+// one ds_read_b128.
 // =====================================================================================
 __global__ __launch_bounds__(256) void lut_build_kernel(
     TxhIndexDev ix, const float *__restrict__ queries, uint32_t q_stride,
@@ -346,10 +346,10 @@ __global__ __launch_bounds__(256) void lut_build_kernel(
         qres[i] = v;
     }
     __syncthreads();
-    const uint32_t S = ix.S, K = ix.K, dsub = ix.dsub;
-    float4 *out = reinterpret_cast<float4 *>(lutq) + (size_t)quad * S * 16;
-    for (uint32_t e = threadIdx.x; e < S * 16; e += blockDim.x) {
-        uint32_t s = e >> 4, c = e & 15u;
+    const uint32_t S = ix.S, K = ix.K, dsub = ix.dsub, kp = ix.kp;   // kp = 16 or 256 table slots
+    float4 *out = reinterpret_cast<float4 *>(lutq) + (size_t)quad * S * kp;
+    for (uint32_t e = threadIdx.x; e < S * kp; e += blockDim.x) {
+        uint32_t s = e / kp, c = e - s * kp;
         float r[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (c < K) {
             const float *cb = ix.codebook + ((size_t)s * K + c) * dsub;
@@ -401,23 +401,6 @@ __device__ __forceinline__ bool row_allowed(const TxhIndexDev &ix, const uint64_
     return idx < allow_bits && ((allow[idx >> 6] >> (idx & 63u)) & 1ull);
 }
 
-// Sequential LUT sum for one packed code row against a [S][16] f32 table in LDS.
-// hashes/lut.rs:74-82: sum = 0.0; for s ascending: sum += lut[s][code[s]].
-template <int NW>
-__device__ __forceinline__ float adc_row_sum(const float *lut, const uint32_t *w) {
-    float acc = 0.0f;
-#pragma unroll
-    for (int wi = 0; wi < NW; ++wi) {
-        uint32_t x = w[wi];
-#pragma unroll
-        for (int nb = 0; nb < 8; ++nb) {
-            uint32_t code = (x >> (4 * nb)) & 15u;
-            acc = acc + lut[(wi * 8 + nb) * 16 + code];
-        }
-    }
-    return acc;
-}
-
 // =====================================================================================
 // K6: ADC scan -- the dominant kernel.  hashes/lut.rs:74-82 driven by the loop at
 // tree_x_hybrid/mod.rs:324-336 / hashes/hasher.rs:179-182.
@@ -431,22 +414,71 @@ __device__ __forceinline__ float adc_row_sum(const float *lut, const uint32_t *w
 // the query's candidate list.  Tiles are pulled from an atomic queue so ragged leaves
 // balance across the 256 CUs.
 // =====================================================================================
-template <int NW, int NP, int BUF>
+// Code layouts the scan understands.  BITS = 4: K <= 16, 8 subspaces per u32 word
+// (PackedCodes4Bit, hashes/lut16.rs:43-61), 16-entry tables.  BITS = 8: 16 < K <= 256 (the
+// reference's default 256 x 8 codebooks, hashes/hasher.rs:36-46), one byte per subspace, 4
+// subspaces per word, 256-entry tables.  A subspace's quad-interleaved table is KP x 16 B.
+template <int S_, int BITS_>
+struct Codec {
+    static constexpr int S = S_, BITS = BITS_;
+    static constexpr int NWORDS = BITS == 4 ? S / 8 : S / 4;      // packed u32 words per point
+    static constexpr int REGS = BITS == 4 ? 2 * NWORDS : NWORDS;  // registers per point in the scan
+    static constexpr int KP = BITS == 4 ? 16 : 256;               // table entries per subspace
+    static constexpr int SUB_BYTES = KP * 16;
+    static constexpr int LUT4 = S * KP;                           // float4 per quad
+    static_assert((S - 1) * SUB_BYTES < 65536, "ds_read immediate offset");
+    // workgroups per CU the kernel is built for (LDS: two LUT buffers + survivor stage)
+    static constexpr int WGS = BITS == 4 ? (S <= 32 ? (int)kScanWaves : 3)
+                                         : (2 * LUT4 * 16 + 12288 <= 40 * 1024 ? 4
+                                            : 2 * LUT4 * 16 + 12288 <= 80 * 1024 ? 2 : 1);
+    // packed words -> register form: 4-bit codes pre-shifted to "code * 16" bytes
+    __device__ static __forceinline__ void unpack(const uint32_t (&w)[NWORDS], uint32_t (&r)[REGS]) {
+        if constexpr (BITS == 4) {
+#pragma unroll
+            for (int wi = 0; wi < NWORDS; ++wi) {
+                r[2 * wi] = (w[wi] & 0x0F0F0F0Fu) << 4;
+                r[2 * wi + 1] = w[wi] & 0xF0F0F0F0u;
+            }
+        } else {
+#pragma unroll
+            for (int wi = 0; wi < NWORDS; ++wi) r[wi] = w[wi];
+        }
+    }
+    // byte offset of subspace s's code inside that subspace's table (code * 16)
+    __device__ static __forceinline__ uint32_t offset(const uint32_t (&r)[REGS], int s) {
+        if constexpr (BITS == 4) {
+            const int wi = s >> 3, b = (s >> 1) & 3, h = s & 1;
+            return (r[2 * wi + h] >> (8 * b)) & 0xFFu;
+        } else {
+            return ((r[s >> 2] >> (8 * (s & 3))) & 0xFFu) << 4;
+        }
+    }
+    __device__ static __forceinline__ void load_words(const uint32_t *src, uint32_t (&w)[NWORDS]) {
+        if constexpr (NWORDS == 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(src);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else if constexpr (NWORDS == 2) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(src);
+            w[0] = v.x; w[1] = v.y;
+        } else {
+#pragma unroll
+            for (int wi = 0; wi < NWORDS; ++wi) w[wi] = src[wi];
+        }
+    }
+};
+
+template <typename C, int NP, int BUF>
 __device__ __forceinline__ void scan_quad_compute(const float4 *lut_base,
-                                                  uint32_t (&wlo)[kScanPPT][NW],
-                                                  uint32_t (&whi)[kScanPPT][NW],
+                                                  uint32_t (&regs)[kScanPPT][C::REGS],
                                                   float (&acc)[4][kScanPPT]) {
-    constexpr int S = NW * 8;
-    const char *lb = reinterpret_cast<const char *>(lut_base + BUF * S * 16);
+    constexpr int S = C::S;
+    const char *lb = reinterpret_cast<const char *>(lut_base + BUF * C::LUT4);
     // The byte extractions below are invariant across the quad loop; without this
     // (instruction-free) barrier LICM hoists all S*NP of them into registers and spills.
 #pragma unroll
     for (int i = 0; i < NP; ++i)
 #pragma unroll
-        for (int wi = 0; wi < NW; ++wi) {
-            asm volatile("" : "+v"(wlo[i][wi]));
-            asm volatile("" : "+v"(whi[i][wi]));
-        }
+        for (int ri = 0; ri < C::REGS; ++ri) asm volatile("" : "+v"(regs[i][ri]));
     // Software pipeline, kScanDepth subspaces deep: the NP ds_read_b128 of subspaces
     // s+1 .. s+D are in flight while subspace s is accumulated.  sched_barrier(0) pins the
     // stage order so the scheduler cannot hoist every gather to the top (256 VGPRs,
@@ -454,13 +486,9 @@ __device__ __forceinline__ void scan_quad_compute(const float4 *lut_base,
     constexpr int D = (int)kScanDepth;
     float4 v[D + 1][NP];
     auto issue = [&](int s, int slot) {
-        const int wi = s >> 3, b = (s >> 1) & 3, h = s & 1;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const uint32_t x = h ? whi[i][wi] : wlo[i][wi];
-            const uint32_t off = (x >> (8 * b)) & 0xFFu;  // code * 16
-            v[slot][i] = *reinterpret_cast<const float4 *>(lb + s * 256 + off);
-        }
+        for (int i = 0; i < NP; ++i)
+            v[slot][i] = *reinterpret_cast<const float4 *>(lb + s * C::SUB_BYTES + C::offset(regs[i], s));
     };
 #pragma unroll
     for (int d = 0; d < D; ++d)
@@ -484,39 +512,13 @@ __device__ __forceinline__ void scan_quad_compute(const float4 *lut_base,
     }
 }
 
-// Variant with the LDS byte offsets (code * 16) of every (point, subspace) precomputed once
-// per tile: the quad loop is then ds_read_b128 + 2 v_pk_add_f32 per lookup and nothing else
-// (the byte extraction above costs a third VALU op per lookup, and the VALU is the co-limiter
-// of this kernel).  S * NP address registers: used for S <= 32 at 4 waves/SIMD.
-template <int NW, int NP, int BUF>
-__device__ __forceinline__ void scan_quad_compute_h(const float4 *lut_base,
-                                                    const uint32_t (&ad)[kScanPPT][NW * 8],
-                                                    float (&acc)[4][kScanPPT]) {
-    constexpr int S = NW * 8;
-    const char *lb = reinterpret_cast<const char *>(lut_base + BUF * S * 16);
-    float4 v[2][NP];
-    auto issue = [&](int s, int slot) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i)
-            v[slot][i] = *reinterpret_cast<const float4 *>(lb + s * 256 + ad[i][s]);
-    };
-    issue(0, 0);
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        if (s + 1 < S) issue(s + 1, (s + 1) & 1);
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const float4 t = v[s & 1][i];
-            if (s == 0) {
-                acc[0][i] = t.x; acc[1][i] = t.y; acc[2][i] = t.z; acc[3][i] = t.w;
-            } else {
-                acc[0][i] = acc[0][i] + t.x;
-                acc[1][i] = acc[1][i] + t.y;
-                acc[2][i] = acc[2][i] + t.z;
-                acc[3][i] = acc[3][i] + t.w;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+template <typename C, int BUF>
+__device__ __forceinline__ void scan_quad_dispatch(const float4 *lut_s, uint32_t nsub,
+                                                   uint32_t (&regs)[kScanPPT][C::REGS],
+                                                   float (&acc)[4][kScanPPT]) {
+    switch (nsub) {
+        case 1: scan_quad_compute<C, 1, BUF>(lut_s, regs, acc); break;
+        default: scan_quad_compute<C, (kScanPPT < 2 ? 1 : 2), BUF>(lut_s, regs, acc); break;
     }
 }
 
@@ -560,22 +562,26 @@ struct ScanArgs {
     uint64_t allow_bits;
 };
 
-template <int NW>
-__global__ __launch_bounds__(kScanThreads, (NW <= 4 ? kScanWaves : 3)) void adc_scan_kernel(TxhIndexDev ix, ScanArgs a) {
-    constexpr int S = NW * 8;
-    constexpr bool HOIST = false;                                 // see scan_quad_compute_h
-    constexpr int LUT4 = S * 16;                                    // float4 per quad
+// LDS of the scan kernels (dynamic: two LUT buffers first, 16-byte aligned)
+template <typename C>
+__host__ __device__ constexpr size_t scan_lds_bytes() {
+    return (size_t)2 * C::LUT4 * 16 + (size_t)2 * 4 * kScanStage * 8 + 8 * 4 + 3 * 4 * 4 + 16;
+}
+
+template <typename C>
+__global__ __launch_bounds__(kScanThreads, C::WGS) void adc_scan_kernel(TxhIndexDev ix, ScanArgs a) {
+    constexpr int LUT4 = C::LUT4;                                   // float4 per quad
     constexpr int STG = (LUT4 + kScanThreads - 1) / kScanThreads;   // staged float4 / thread
-    __shared__ float4 lut_s[2 * LUT4];
+    extern __shared__ __attribute__((aligned(16))) float4 lut_s[];  // [2 * LUT4]
     // Survivors are staged per (quad, query) in LDS and flushed one quad later with ONE
     // returning global atomic per query, issued before the next quad's gather so its
     // latency hides under the compute (a per-lane returning atomic stalls the wave ~1 us).
-    __shared__ uint64_t ckey_s[2][4][kScanStage];
-    __shared__ uint32_t ccnt_s[2][4];     // live counters (LDS atomics)
-    __shared__ uint32_t cfrozen_s[4];     // counts of the buffer being flushed
-    __shared__ uint32_t cbase_s[4];       // its global base slots
-    __shared__ uint32_t cq_s[4];          // its query ids
-    __shared__ uint32_t tile_sh;
+    uint64_t (*ckey_s)[4][kScanStage] = reinterpret_cast<uint64_t (*)[4][kScanStage]>(lut_s + 2 * LUT4);
+    uint32_t (*ccnt_s)[4] = reinterpret_cast<uint32_t (*)[4]>(ckey_s + 2);   // live counters (LDS atomics)
+    uint32_t *cfrozen_s = reinterpret_cast<uint32_t *>(ccnt_s + 2);            // counts of the buffer being flushed
+    uint32_t *cbase_s = cfrozen_s + 4;                                         // its global base slots
+    uint32_t *cq_s = cbase_s + 4;                                              // its query ids
+    uint32_t &tile_sh = cq_s[4];
     const uint32_t tid = threadIdx.x;
     const uint32_t total_tiles = a.counters[CNT_TOTAL_TILES];
     if (tid < 8) ccnt_s[tid >> 2][tid & 3u] = 0;
@@ -606,36 +612,14 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? kScanWaves : 3)) void adc_
         const uint32_t npts = min(kScanTP, size - c0);
         const uint32_t nsub = (npts + kScanThreads - 1) / kScanThreads;
 
-        // packed codes of this lane's points -> byte-per-subspace form (code * 16)
-        uint32_t wlo[kScanPPT][NW], whi[kScanPPT][NW];
-        uint32_t ad[kScanPPT][HOIST ? S : 1];
+        // packed codes of this lane's points in the codec's register form
+        uint32_t regs[kScanPPT][C::REGS];
 #pragma unroll
         for (int i = 0; i < (int)kScanPPT; ++i) {
             const uint32_t j = c0 + tid + kScanThreads * i;
-            const uint32_t *src = ix.codes + (size_t)(lb + (j < size ? j : 0)) * NW;
-            uint32_t w[NW];
-            if constexpr (NW == 4) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(src);
-                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            } else if constexpr (NW == 2) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(src);
-                w[0] = v.x; w[1] = v.y;
-            } else {
-#pragma unroll
-                for (int wi = 0; wi < NW; ++wi) w[wi] = src[wi];
-            }
-#pragma unroll
-            for (int wi = 0; wi < NW; ++wi) {
-                wlo[i][wi] = (w[wi] & 0x0F0F0F0Fu) << 4;
-                whi[i][wi] = w[wi] & 0xF0F0F0F0u;
-            }
-            if constexpr (HOIST) {
-#pragma unroll
-                for (int sub = 0; sub < S; ++sub) {
-                    const uint32_t x = (sub & 1) ? whi[i][sub >> 3] : wlo[i][sub >> 3];
-                    ad[i][sub] = (x >> (8 * ((sub >> 1) & 3))) & 0xFFu;
-                }
-            }
+            uint32_t w[C::NWORDS];
+            C::load_words(ix.codes + (size_t)(lb + (j < size ? j : 0)) * C::NWORDS, w);
+            C::unpack(w, regs[i]);
         }
 
         const float4 *gl = reinterpret_cast<const float4 *>(a.lutq) +
@@ -700,31 +684,8 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? kScanWaves : 3)) void adc_
             if (live) {
                 // B. gather + accumulate
                 float acc[4][kScanPPT];
-                if constexpr (HOIST) {
-                    if (buf == 0) {
-                        switch (nsub) {
-                            case 1: scan_quad_compute_h<NW, 1, 0>(lut_s, ad, acc); break;
-                            default: scan_quad_compute_h<NW, (kScanPPT < 2 ? 1 : 2), 0>(lut_s, ad, acc); break;
-                        }
-                    } else {
-                        switch (nsub) {
-                            case 1: scan_quad_compute_h<NW, 1, 1>(lut_s, ad, acc); break;
-                            default: scan_quad_compute_h<NW, (kScanPPT < 2 ? 1 : 2), 1>(lut_s, ad, acc); break;
-                        }
-                    }
-                } else {
-                    if (buf == 0) {
-                        switch (nsub) {
-                            case 1: scan_quad_compute<NW, 1, 0>(lut_s, wlo, whi, acc); break;
-                            default: scan_quad_compute<NW, (kScanPPT < 2 ? 1 : 2), 0>(lut_s, wlo, whi, acc); break;
-                        }
-                    } else {
-                        switch (nsub) {
-                            case 1: scan_quad_compute<NW, 1, 1>(lut_s, wlo, whi, acc); break;
-                            default: scan_quad_compute<NW, (kScanPPT < 2 ? 1 : 2), 1>(lut_s, wlo, whi, acc); break;
-                        }
-                    }
-                }
+                if (buf == 0) scan_quad_dispatch<C, 0>(lut_s, nsub, regs, acc);
+                else scan_quad_dispatch<C, 1>(lut_s, nsub, regs, acc);
                 // threshold filter: survivors go to the LDS stage of this quad
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
@@ -803,13 +764,12 @@ struct SampleArgs {
     uint64_t allow_bits;
 };
 
-template <int NW>
-__global__ __launch_bounds__(kScanThreads, (NW <= 4 ? kScanWaves : 3)) void adc_sample_kernel(TxhIndexDev ix, SampleArgs a) {
-    constexpr int S = NW * 8;
-    constexpr int LUT4 = S * 16;
+template <typename C>
+__global__ __launch_bounds__(kScanThreads, C::WGS) void adc_sample_kernel(TxhIndexDev ix, SampleArgs a) {
+    constexpr int LUT4 = C::LUT4;
     constexpr int STG = (LUT4 + kScanThreads - 1) / kScanThreads;
-    __shared__ float4 lut_s[2 * LUT4];
-    __shared__ uint32_t tile_sh;
+    extern __shared__ __attribute__((aligned(16))) float4 lut_s[];   // [2 * LUT4] + tile slot
+    uint32_t &tile_sh = *reinterpret_cast<uint32_t *>(lut_s + 2 * LUT4);
     const uint32_t tid = threadIdx.x;
     const uint32_t total_tiles = a.counters[CNT_TOTAL_STILES];
     const uint32_t st = a.st;
@@ -840,20 +800,16 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? kScanWaves : 3)) void adc_
         const uint32_t npts = min(kScanTP, ssize - c0);
         const uint32_t nsub = (npts + kScanThreads - 1) / kScanThreads;
 
-        uint32_t wlo[kScanPPT][NW], whi[kScanPPT][NW];
+        uint32_t regs[kScanPPT][C::REGS];
         bool ok[kScanPPT];
 #pragma unroll
         for (int i = 0; i < (int)kScanPPT; ++i) {
             const uint32_t j = c0 + tid + kScanThreads * i;
             const uint32_t row = lb + (j < ssize ? j * st : 0u);
             ok[i] = j < ssize && row_allowed(ix, a.allow, a.allow_bits, row);
-            const uint32_t *src = ix.codes + (size_t)row * NW;
-#pragma unroll
-            for (int wi = 0; wi < NW; ++wi) {
-                const uint32_t w = src[wi];
-                wlo[i][wi] = (w & 0x0F0F0F0Fu) << 4;
-                whi[i][wi] = w & 0xF0F0F0F0u;
-            }
+            uint32_t w[C::NWORDS];
+            C::load_words(ix.codes + (size_t)row * C::NWORDS, w);
+            C::unpack(w, regs[i]);
         }
 
         const float4 *gl = reinterpret_cast<const float4 *>(a.lutq) +
@@ -895,17 +851,8 @@ __global__ __launch_bounds__(kScanThreads, (NW <= 4 ? kScanWaves : 3)) void adc_
                 f_sb[p] = __builtin_amdgcn_readfirstlane(a.pair_sbase[slot + p]);
             }
             float acc[4][kScanPPT];
-            if (buf == 0) {
-                switch (nsub) {
-                    case 1: scan_quad_compute<NW, 1, 0>(lut_s, wlo, whi, acc); break;
-                    default: scan_quad_compute<NW, (kScanPPT < 2 ? 1 : 2), 0>(lut_s, wlo, whi, acc); break;
-                }
-            } else {
-                switch (nsub) {
-                    case 1: scan_quad_compute<NW, 1, 1>(lut_s, wlo, whi, acc); break;
-                    default: scan_quad_compute<NW, (kScanPPT < 2 ? 1 : 2), 1>(lut_s, wlo, whi, acc); break;
-                }
-            }
+            if (buf == 0) scan_quad_dispatch<C, 0>(lut_s, nsub, regs, acc);
+            else scan_quad_dispatch<C, 1>(lut_s, nsub, regs, acc);
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 if (f_pq[p] == kInvalid) continue;   // wave-uniform
@@ -1550,24 +1497,24 @@ __global__ __launch_bounds__(kSelectThreads) void merge_kernel(
 // Building blocks exposed through the C ABI
 // =====================================================================================
 // All-pairs ADC distances for explicit f32 LUTs [nq][S][K]: out [nq][n_local].
-template <int NW>
+// hashes/lut.rs:74-82: sum = 0.0; for s ascending: sum += lut[s][code[s]].
 __global__ __launch_bounds__(256) void adc_distances_kernel(TxhIndexDev ix,
                                                             const float *__restrict__ luts,
                                                             float *__restrict__ out) {
-    constexpr int S = NW * 8;
-    __shared__ float slut[S * 16];
-    const uint32_t q = blockIdx.y;
-    for (uint32_t e = threadIdx.x; e < S * 16; e += blockDim.x) {
-        uint32_t s = e >> 4, c = e & 15u;
-        slut[e] = (c < ix.K) ? luts[((size_t)q * S + s) * ix.K + c] : 0.0f;
-    }
+    extern __shared__ float slut[];   // [S][K]
+    const uint32_t q = blockIdx.y, S = ix.S, K = ix.K, nw = ix.nw;
+    const uint32_t bits = ix.code_bits, per = 32u / bits, mask = (1u << bits) - 1u;
+    for (uint32_t e = threadIdx.x; e < S * K; e += blockDim.x) slut[e] = luts[(size_t)q * S * K + e];
     __syncthreads();
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ix.n_local;
          i += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t w[NW];
-#pragma unroll
-        for (int wi = 0; wi < NW; ++wi) w[wi] = ix.codes[i * NW + wi];
-        out[(size_t)q * ix.n_local + i] = adc_row_sum<NW>(slut, w);
+        float acc = 0.0f;
+        for (uint32_t sub = 0; sub < S; ++sub) {
+            const uint32_t w = ix.codes[i * nw + sub / per];
+            const uint32_t code = (w >> (bits * (sub % per))) & mask;
+            acc = acc + slut[sub * K + (code < K ? code : 0u)];
+        }
+        out[(size_t)q * ix.n_local + i] = acc;
     }
 }
 
@@ -1690,7 +1637,7 @@ int txh_launch_partition_only(const TxhIndexDev &ix, const TxhWork &w, hipStream
     return launch_partition_stage(ix, w, st);
 }
 
-template <int NW>
+template <typename C>
 static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream_t st,
                               hipEvent_t ev0, hipEvent_t ev1) {
     int dev = 0, cus = 256;
@@ -1701,7 +1648,9 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
         sa.pair_off = w.pair_off; sa.stile_off = w.stile_off; sa.pair_q = w.pair_q;
         sa.pair_sbase = w.pair_sbase; sa.counters = w.counters; sa.lutq = w.lutq; sa.samp = w.samp;
         sa.scap = w.scap; sa.st = w.st; sa.qpt = w.sqpt; sa.allow = w.allow; sa.allow_bits = w.allow_bits;
-        hipLaunchKernelGGL(adc_sample_kernel<NW>, dim3((uint32_t)cus * 8u), dim3(kScanThreads), 0, st, ix, sa);
+        const size_t lds_smp = (size_t)2 * C::LUT4 * 16 + 16;
+        SCANN_TRY(set_dyn_lds(adc_sample_kernel<C>, lds_smp));
+        hipLaunchKernelGGL(adc_sample_kernel<C>, dim3((uint32_t)cus * 8u), dim3(kScanThreads), lds_smp, st, ix, sa);
         LAUNCH_CHECK();
     }
     {
@@ -1720,7 +1669,8 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
     if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
     uint32_t wgs = (uint32_t)cus * 8u;
     if (const char *e = std::getenv("SCANN_HIP_WGS")) wgs = (uint32_t)cus * (uint32_t)std::max(1, std::atoi(e));
-    hipLaunchKernelGGL(adc_scan_kernel<NW>, dim3(wgs), dim3(kScanThreads), 0, st, ix, a);
+    SCANN_TRY(set_dyn_lds(adc_scan_kernel<C>, scan_lds_bytes<C>()));
+    hipLaunchKernelGGL(adc_scan_kernel<C>, dim3(wgs), dim3(kScanThreads), scan_lds_bytes<C>(), st, ix, a);
     LAUNCH_CHECK();
     if (ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
     return SCANN_HIP_OK;
@@ -1756,14 +1706,19 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
                        w.q_stride, w.pair_q, w.pair_leaf, w.counters, w.lutq);
     LAUNCH_CHECK();
 
-    switch (ix.nw) {
-        case 1: SCANN_TRY(launch_scan_stages<1>(ix, w, st, ev0, ev1)); break;
-        case 2: SCANN_TRY(launch_scan_stages<2>(ix, w, st, ev0, ev1)); break;
-        case 3: SCANN_TRY(launch_scan_stages<3>(ix, w, st, ev0, ev1)); break;
-        case 4: SCANN_TRY(launch_scan_stages<4>(ix, w, st, ev0, ev1)); break;
-        case 6: SCANN_TRY(launch_scan_stages<6>(ix, w, st, ev0, ev1)); break;
-        case 8: SCANN_TRY(launch_scan_stages<8>(ix, w, st, ev0, ev1)); break;
-        default: return fail(SCANN_HIP_UNIMPLEMENTED, "num_subspaces must be 8,16,24,32,48 or 64");
+    switch (ix.code_bits * 1000 + ix.S) {
+        case 4008: SCANN_TRY((launch_scan_stages<Codec<8, 4>>(ix, w, st, ev0, ev1))); break;
+        case 4016: SCANN_TRY((launch_scan_stages<Codec<16, 4>>(ix, w, st, ev0, ev1))); break;
+        case 4024: SCANN_TRY((launch_scan_stages<Codec<24, 4>>(ix, w, st, ev0, ev1))); break;
+        case 4032: SCANN_TRY((launch_scan_stages<Codec<32, 4>>(ix, w, st, ev0, ev1))); break;
+        case 4048: SCANN_TRY((launch_scan_stages<Codec<48, 4>>(ix, w, st, ev0, ev1))); break;
+        case 4064: SCANN_TRY((launch_scan_stages<Codec<64, 4>>(ix, w, st, ev0, ev1))); break;
+        case 8004: SCANN_TRY((launch_scan_stages<Codec<4, 8>>(ix, w, st, ev0, ev1))); break;
+        case 8008: SCANN_TRY((launch_scan_stages<Codec<8, 8>>(ix, w, st, ev0, ev1))); break;
+        case 8016: SCANN_TRY((launch_scan_stages<Codec<16, 8>>(ix, w, st, ev0, ev1))); break;
+        default:
+            return fail(SCANN_HIP_UNIMPLEMENTED,
+                        "num_subspaces must be 8,16,24,32,48,64 (num_codes <= 16) or 4,8,16 (num_codes <= 256)");
     }
 
     SelectArgs s;
@@ -1850,15 +1805,9 @@ int txh_launch_adc_distances(const TxhIndexDev &ix, const float *d_luts, uint32_
     if (nq == 0 || ix.n_local == 0) return SCANN_HIP_OK;
     const uint32_t gx = (uint32_t)std::min<uint64_t>(ceil_div_u64(ix.n_local, 256), 4096);
     dim3 grid(gx, nq);
-    switch (ix.nw) {
-        case 1: hipLaunchKernelGGL(adc_distances_kernel<1>, grid, dim3(256), 0, st, ix, d_luts, d_out); break;
-        case 2: hipLaunchKernelGGL(adc_distances_kernel<2>, grid, dim3(256), 0, st, ix, d_luts, d_out); break;
-        case 3: hipLaunchKernelGGL(adc_distances_kernel<3>, grid, dim3(256), 0, st, ix, d_luts, d_out); break;
-        case 4: hipLaunchKernelGGL(adc_distances_kernel<4>, grid, dim3(256), 0, st, ix, d_luts, d_out); break;
-        case 6: hipLaunchKernelGGL(adc_distances_kernel<6>, grid, dim3(256), 0, st, ix, d_luts, d_out); break;
-        case 8: hipLaunchKernelGGL(adc_distances_kernel<8>, grid, dim3(256), 0, st, ix, d_luts, d_out); break;
-        default: return fail(SCANN_HIP_UNIMPLEMENTED, "num_subspaces must be 8,16,24,32,48 or 64");
-    }
+    const size_t lds = (size_t)ix.S * ix.K * sizeof(float);
+    SCANN_TRY(set_dyn_lds(adc_distances_kernel, lds));
+    hipLaunchKernelGGL(adc_distances_kernel, grid, dim3(256), lds, st, ix, d_luts, d_out);
     LAUNCH_CHECK();
     return SCANN_HIP_OK;
 }

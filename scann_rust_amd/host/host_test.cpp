@@ -107,6 +107,13 @@ static void tree_x_hybrid_tests() {
     auto tr = s.search_with_filter(q, 10, &two);
     EXPECT(tr.size() <= 2);
     for (auto &p : tr) EXPECT(p.first == 7 || p.first == 11);
+    // TreeXHybridConfig::default(): 100 partitions, search 10, 256 codes x 8 subspaces (mod.rs:37-48)
+    TreeXHybridSearcher dflt{TreeXHybridConfig()};
+    dflt.build(sin_dataset(3000, 32));
+    EXPECT(dflt.num_partitions() == 100);
+    auto dr2 = dflt.search(q, 10);
+    EXPECT(dr2.size() == 10);
+    sorted(dr2);
     bool empty = false;
     try { TreeXHybridSearcher e(cfg); e.build(DenseDataset()); }
     catch (const ScannError &e) { empty = e.code == ErrorCode::InvalidArgument; }

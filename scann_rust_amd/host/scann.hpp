@@ -334,7 +334,7 @@ private:
 };
 
 // ---- AsymmetricHasher (hashes/hasher.rs) ---------------------------------------------------
-struct AsymmetricHasherConfig {      // hasher.rs:19-69 (default 256 x 8; the GPU path needs K <= 16)
+struct AsymmetricHasherConfig {      // hasher.rs:19-69 (default 256 x 8: byte codes; K <= 16 takes the LUT16 path)
     size_t num_codes = 256, num_subspaces = 8;
     uint64_t seed = 42;
     bool has_seed = false;

@@ -456,3 +456,60 @@ def test_ah_allow_bitmap_filter():
     # a bitmap shorter than the dataset: indices >= its capacity are not allowed (allowlist.rs:97-100)
     idx, dist, cnt = index.search_batched(q, 10, opts=o, allow=bits[:32])
     assert np.all(cnt == 10) and np.all(idx < 2048) and np.all(idx % 7 == 0)
+
+
+# ---- 8-bit codes: 16 < num_codes <= 256 (the reference's default 256 x 8 codebooks) --------------
+@pytest.mark.parametrize("dim,S,K", [(64, 8, 256), (32, 4, 64), (128, 16, 256), (64, 8, 100)])
+def test_adc_distances_bit_exact_byte_codes(dim, S, K):
+    rows, data, stride, ix, kw = H.make_ah_case(3000, dim, S, seed=12, K=K, pq_iters=2)
+    index = hip.txh_create(**kw)
+    q = synth.uniform_f32(5, dim, 78)
+    luts = np.stack([orc.lut_from_query(ix["codebook"], qq) for qq in q])
+    assert np.array_equal(bits(hip.lut_from_query(index, q, S, K)), bits(luts))
+    got = hip.adc_distances(index, luts)
+    for i in range(q.shape[0]):
+        want = np.array([orc.lut_distance(luts[i], c) for c in ix["codes"]], np.float32)
+        assert np.array_equal(bits(got[i]), bits(want))
+
+
+@pytest.mark.parametrize("dim,S,K,P", [(64, 8, 256, 4), (128, 16, 256, 3), (32, 4, 64, 16), (64, 8, 17, 5)])
+def test_txh_search_stages_byte_codes(dim, S, K, P):
+    """TreeXHybridConfig::default() hashes with 256 codes x 8 subspaces (tree_x_hybrid/mod.rs:37-48,
+    hashes/hasher.rs:36-46): same stage-by-stage parity as the LUT16 configuration."""
+    n, L, k, nq, mult = 5000, 16, 10, 37, 4.0
+    rows, data, stride, ix, oix, kw = H.make_txh_case(n, dim, L, S, seed=21, K=K, P=P, mult=mult,
+                                                      kmeans_iters=3, pq_iters=2)
+    index = hip.txh_create(**kw)
+    q = synth.uniform_f32(nq, dim, 321)
+    o = hip.default_opts()
+    o.partitions_to_search = P
+    o.pre_reorder_k = orc.pre_reorder_k(k, mult)
+    idx, dist, cnt, (tok, tokd, ci, cd, cc) = index.search_batched(q, k, o, stages=True)
+    for i in range(nq):
+        H.check_txh_query(oix, q[i], k, idx[i, :cnt[i]], dist[i, :cnt[i]], tok[i], tokd[i],
+                          ci[i, :cc[i]], cd[i, :cc[i]], what="q%d" % i)
+
+
+def test_ah_search_byte_codes_default_config():
+    """AsymmetricHasherConfig::default(): 256 codes x 8 subspaces (hashes/hasher.rs:36-46)."""
+    n, dim, S, K, k = 20000, 64, 8, 256, 10
+    rows, data, stride, ix, kw = H.make_ah_case(n, dim, S, seed=33, K=K, pq_iters=2)
+    index = hip.txh_create(**kw)
+    q = synth.uniform_f32(21, dim, 34)
+    o = hip.default_opts()
+    o.exact_reorder = 0
+    idx, dist, cnt = index.search_batched(q, k, o)
+    o.exact_reorder, o.pre_reorder_k = 1, 200
+    idx2, dist2, cnt2 = index.search_batched(q, k, o)
+    for i in range(q.shape[0]):
+        oi, od = orc.ah_search(ix["codebook"], ix["codes"], q[i], k)
+        H.assert_topk_equal_up_to_ties(idx[i, :cnt[i]], dist[i, :cnt[i]], oi, od, what="ah q%d" % i)
+        oi, od = orc.ah_search_with_reordering(ix["codebook"], ix["codes"], data, stride, q[i], k, 200)
+        H.assert_topk_equal_up_to_ties(idx2[i, :cnt2[i]], dist2[i, :cnt2[i]], oi, od, what="ahr q%d" % i)
+
+
+def test_byte_code_limits():
+    rows, data, stride, ix, kw = H.make_ah_case(600, 96, 32, seed=35, K=17, pq_iters=1)
+    with pytest.raises(hip.ScannError) as e:   # 32 subspaces x 256 slots does not fit the LDS tables
+        hip.txh_create(**kw)
+    assert e.value.code == hip.UNIMPLEMENTED
