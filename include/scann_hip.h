@@ -257,6 +257,14 @@ int scann_hip_encode(scann_hip_ctx *ctx, const float *codebook, uint32_t num_sub
 int scann_hip_bf_distances(scann_hip_index *index, const float *queries, uint32_t nq,
                            uint32_t q_stride, float *out);
 
+/* BruteForceSearcher::search_radius (src/brute_force/searcher.rs:142-167) for one query: every
+ * datapoint with distance <= radius, stable-sorted by distance.  Writes at most `capacity` rows;
+ * *out_count receives the number found (call again with a larger capacity if it exceeds it).
+ * Empty dataset -> OK with 0 rows; wrong q_dim -> InvalidArgument. */
+int scann_hip_bf_search_radius(scann_hip_index *index, const float *query, uint32_t q_dim, float radius,
+                               uint32_t *out_idx, float *out_dist, uint64_t capacity,
+                               uint64_t *out_count);
+
 /* Index build helper: for every row of a brute-force index, the nearest of
  * `num_centers` centres [num_centers][dim] under the partitioner's arithmetic --
  * TreePartitioner::partition(x, 1) as used by TreeXHybridSearcher::compute_residuals

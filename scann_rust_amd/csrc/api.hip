@@ -902,6 +902,22 @@ int scann_hip_bf_distances(scann_hip_index *ix, const float *queries, uint32_t n
     return bf_distances_host(ix->bf, ix->bfw, queries, nq, q_stride, out, ix->stream);
 }
 
+int scann_hip_bf_search_radius(scann_hip_index *ix, const float *query, uint32_t q_dim, float radius,
+                               uint32_t *out_idx, float *out_dist, uint64_t capacity,
+                               uint64_t *out_count) {
+    if (!ix || ix->kind != KIND_BF) return fail(SCANN_HIP_INVALID_ARGUMENT, "not a brute-force index");
+    if (!out_count) return fail(SCANN_HIP_INVALID_ARGUMENT, "null out_count");
+    *out_count = 0;
+    if (ix->bf.n == 0) return SCANN_HIP_OK;   // searcher.rs:143-145
+    if (!query || q_dim != ix->bf.dim)        // searcher.rs:148-152
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "Query dimensionality does not match dataset");
+    if (capacity && (!out_idx || !out_dist)) return fail(SCANN_HIP_INVALID_ARGUMENT, "null outputs");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    SCANN_TRY(set_device(ix->ctx));
+    return bf_search_radius_host(ix->bf, ix->bfw, query, q_dim, radius, out_idx, out_dist, capacity,
+                                 out_count, ix->stream);
+}
+
 int scann_hip_bf_assign_nearest(scann_hip_index *ix, const float *centers, uint32_t num_centers,
                                 uint32_t *out_assign, float *out_dist) {
     if (!ix || ix->kind != KIND_BF) return fail(SCANN_HIP_INVALID_ARGUMENT, "not a brute-force index");

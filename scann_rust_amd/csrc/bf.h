@@ -33,6 +33,12 @@ int bf_search_device(const BfIndexDev &ix, BfWorkspace &w, const float *d_querie
 int bf_distances_host(const BfIndexDev &ix, BfWorkspace &w, const float *queries, uint32_t nq,
                       uint32_t q_stride, float *out, hipStream_t stream);
 
+// BruteForceSearcher::search_radius for one query: all rows with distance <= radius, sorted by
+// (distance, index).  At most `capacity` rows are written; *out_count = number found.
+int bf_search_radius_host(const BfIndexDev &ix, BfWorkspace &w, const float *query, uint32_t q_stride,
+                          float radius, uint32_t *out_idx, float *out_dist, uint64_t capacity,
+                          uint64_t *out_count, hipStream_t stream);
+
 // Nearest of k centres for every row of the index (sequential-scalar SquaredL2, lowest index on
 // ties): TreePartitioner::partition(x, 1) / KMeans::assign_clusters.
 int bf_assign_nearest_host(const BfIndexDev &ix, const float *centers, uint32_t k, uint32_t *out_idx,

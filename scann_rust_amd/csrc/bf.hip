@@ -16,6 +16,8 @@
 //    pass keeps only (distance, index) keys <= bound; a per-query LDS sort finishes.
 #include "bf.h"
 
+#include <hipcub/hipcub.hpp>
+
 namespace scann {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -722,6 +724,72 @@ int bf_distances_host(const BfIndexDev &ix, BfWorkspace &w, const float *queries
     a.ld = (uint32_t)ix.n;
     SCANN_TRY(launch_pass(ix, a, st));
     SCANN_HIP_CHECK(hipMemcpyAsync(out, dout.p, (size_t)nq * ix.n * 4, hipMemcpyDeviceToHost, st));
+    SCANN_HIP_CHECK(hipStreamSynchronize(st));
+    return SCANN_HIP_OK;
+}
+
+// BruteForceSearcher::search_radius (brute_force/searcher.rs:142-167): every datapoint with
+// distance <= radius, stable-sorted by distance (key order = (distance, index)).  The filter
+// pass of the search keeps keys <= (radius, max index); a device radix sort orders them.
+__global__ void bf_decode_keys_kernel(const uint64_t *__restrict__ keys, uint32_t n,
+                                      uint32_t *__restrict__ out_idx, float *__restrict__ out_dist) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = keys[i];
+    out_idx[i] = (uint32_t)key;
+    out_dist[i] = ordered_to_f32((uint32_t)(key >> 32));
+}
+
+int bf_search_radius_host(const BfIndexDev &ix, BfWorkspace &w, const float *query, uint32_t q_stride,
+                          float radius, uint32_t *out_idx, float *out_dist, uint64_t capacity,
+                          uint64_t *out_count, hipStream_t st) {
+    (void)w;
+    const uint32_t n = (uint32_t)ix.n;
+    DevBuf dq, dthr, dcnt, dcand, dsorted, dtmp, didx, ddist;
+    SCANN_TRY(upload(dq, query, (size_t)q_stride * 4));
+    // NaN radius: nothing compares <= NaN (searcher.rs:161)
+    const uint64_t T = (radius != radius) ? 0ull : (((uint64_t)f32_to_ordered(radius) << 32) | 0xFFFFFFFFull);
+    if (radius != radius) {
+        *out_count = 0;
+        return SCANN_HIP_OK;
+    }
+    SCANN_TRY(upload(dthr, &T, 8));
+    SCANN_TRY(dcnt.ensure(4));
+    SCANN_TRY(dcand.ensure((size_t)n * 8));
+    SCANN_HIP_CHECK(hipMemsetAsync(dcnt.p, 0, 4, st));
+    BfPass b{};
+    b.queries = dq.as<float>();
+    b.nq = 1;
+    b.q_stride = q_stride;
+    b.nrows = n;
+    b.row_mult = 1;
+    b.filter = 1;
+    b.thr = dthr.as<uint64_t>();
+    b.cand_cnt = dcnt.as<uint32_t>();
+    b.cand = dcand.as<uint64_t>();
+    b.cap = n;
+    SCANN_TRY(launch_pass(ix, b, st));
+    uint32_t cnt = 0;
+    SCANN_HIP_CHECK(hipMemcpyAsync(&cnt, dcnt.p, 4, hipMemcpyDeviceToHost, st));
+    SCANN_HIP_CHECK(hipStreamSynchronize(st));
+    *out_count = cnt;
+    if (cnt == 0) return SCANN_HIP_OK;
+    SCANN_TRY(dsorted.ensure((size_t)cnt * 8));
+    size_t tmp_bytes = 0;
+    SCANN_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, dcand.as<uint64_t>(),
+                                                      dsorted.as<uint64_t>(), (int)cnt, 0, 64, st));
+    SCANN_TRY(dtmp.ensure(tmp_bytes));
+    SCANN_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(dtmp.p, tmp_bytes, dcand.as<uint64_t>(),
+                                                      dsorted.as<uint64_t>(), (int)cnt, 0, 64, st));
+    const uint32_t nout = (uint32_t)std::min<uint64_t>(cnt, capacity);
+    if (nout == 0) return SCANN_HIP_OK;
+    SCANN_TRY(didx.ensure((size_t)nout * 4));
+    SCANN_TRY(ddist.ensure((size_t)nout * 4));
+    hipLaunchKernelGGL(bf_decode_keys_kernel, dim3(ceil_div_u32(nout, 256)), dim3(256), 0, st,
+                       dsorted.as<uint64_t>(), nout, didx.as<uint32_t>(), ddist.as<float>());
+    LAUNCH_CHECK();
+    SCANN_HIP_CHECK(hipMemcpyAsync(out_idx, didx.p, (size_t)nout * 4, hipMemcpyDeviceToHost, st));
+    SCANN_HIP_CHECK(hipMemcpyAsync(out_dist, ddist.p, (size_t)nout * 4, hipMemcpyDeviceToHost, st));
     SCANN_HIP_CHECK(hipStreamSynchronize(st));
     return SCANN_HIP_OK;
 }

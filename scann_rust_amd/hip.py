@@ -31,7 +31,7 @@ EXPORTS = [
     "scann_hip_txh_search_local_device", "scann_hip_txh_merge_device",
     "scann_hip_assign_leaves", "scann_hip_txh_partition", "scann_hip_lut_from_query",
     "scann_hip_adc_distances", "scann_hip_lut16_distances_batch", "scann_hip_encode",
-    "scann_hip_bf_distances", "scann_hip_bf_assign_nearest", "scann_hip_index_size", "scann_hip_index_dimensionality",
+    "scann_hip_bf_distances", "scann_hip_bf_search_radius", "scann_hip_bf_assign_nearest", "scann_hip_index_size", "scann_hip_index_dimensionality",
     "scann_hip_index_destroy", "scann_hip_index_enable_timing",
     "scann_hip_index_last_kernel_ms",
 ]
@@ -122,6 +122,8 @@ def load():
                                    C.c_uint64, C.c_uint32, f32p, u32p, u8p]
     L.scann_hip_bf_distances.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, f32p]
     L.scann_hip_bf_assign_nearest.argtypes = [vp, f32p, C.c_uint32, u32p, f32p]
+    L.scann_hip_bf_search_radius.argtypes = [vp, f32p, C.c_uint32, C.c_float, u32p, f32p, C.c_uint64,
+                                             C.POINTER(C.c_uint64)]
     L.scann_hip_index_size.restype = C.c_uint64
     L.scann_hip_index_size.argtypes = [vp]
     L.scann_hip_index_dimensionality.restype = C.c_uint32
@@ -355,6 +357,20 @@ def bf_distances(index, queries):
     out = np.zeros((nq, index.size()), np.float32)
     check(load().scann_hip_bf_distances(index.h, ptr(q, f32p), nq, qs, ptr(out, f32p)))
     return out
+
+
+def bf_search_radius(index, query, radius, capacity=None):
+    """BruteForceSearcher::search_radius: (idx, dist) of every row with distance <= radius."""
+    q = f32(query).reshape(-1)
+    cap = index.size() if capacity is None else int(capacity)
+    idx = np.zeros(max(cap, 1), np.uint32)
+    dist = np.zeros(max(cap, 1), np.float32)
+    cnt = C.c_uint64(0)
+    check(load().scann_hip_bf_search_radius(index.h, ptr(q, f32p), q.size, C.c_float(radius),
+                                            ptr(idx, u32p), ptr(dist, f32p), C.c_uint64(cap),
+                                            C.byref(cnt)))
+    n = min(int(cnt.value), cap)
+    return idx[:n], dist[:n], int(cnt.value)
 
 
 def bf_assign_nearest(index, centers, want_dist=True):

@@ -33,6 +33,9 @@ static void brute_force_tests() {
     sorted(r);
     auto b = s.search_batched({{0, 0, 0}, {1, 1, 1}}, 2); // test_brute_force_batched
     EXPECT(b.size() == 2 && b[0].size() == 2 && b[1].size() == 2);
+    auto rr = s.search_radius({0, 0, 0}, 1.5f);           // test_brute_force_radius: origin + 3 unit points
+    EXPECT(rr.size() == 4 && rr[0].first == 0);
+    sorted(rr);
     bool threw = false;                                   // test_brute_force_dimension_mismatch
     try { s.search({1, 2}, 5); } catch (const ScannError &e) { threw = e.code == ErrorCode::InvalidArgument; }
     EXPECT(threw);

@@ -322,6 +322,22 @@ public:
         auto flat = detail::flatten(queries, &d);
         return detail::run_search(ix_.h, flat.data(), (uint32_t)queries.size(), d, d, (uint32_t)k, nullptr);
     }
+    NNResultsVector search_radius(const std::vector<float> &query, float radius) const {   // :142-167
+        if (dataset_->size() == 0) return {};
+        std::vector<uint32_t> idx(256);
+        std::vector<float> dist(256);
+        uint64_t found = 0;
+        for (;;) {
+            check(scann_hip_bf_search_radius(ix_.h, query.data(), (uint32_t)query.size(), radius, idx.data(),
+                                             dist.data(), idx.size(), &found));
+            if (found <= idx.size()) break;
+            idx.resize(found);
+            dist.resize(found);
+        }
+        NNResultsVector r(found);
+        for (size_t i = 0; i < found; ++i) r[i] = {idx[i], dist[i]};
+        return r;
+    }
     size_t dataset_size() const { return dataset_->size(); }
     uint64_t dimensionality() const { return dataset_->dimensionality(); }
     DistanceMeasure distance_measure() const { return measure_; }

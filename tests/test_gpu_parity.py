@@ -513,3 +513,27 @@ def test_byte_code_limits():
     with pytest.raises(hip.ScannError) as e:   # 32 subspaces x 256 slots does not fit the LDS tables
         hip.txh_create(**kw)
     assert e.value.code == hip.UNIMPLEMENTED
+
+
+@pytest.mark.parametrize("measure", [hip.SQUARED_L2, hip.DOT_PRODUCT, hip.L2])
+@pytest.mark.parametrize("n,dim", [(20000, 128), (3000, 50)])
+def test_bf_search_radius(measure, n, dim):
+    """BruteForceSearcher::search_radius (brute_force/searcher.rs:142-167)."""
+    rows = synth.uniform_f32(n, dim, 61)
+    data, stride = orc.to_strided(rows)
+    index = hip.bf_create(data, n, dim, stride, measure)
+    q = synth.uniform_f32(3, dim, 62)
+    for i in range(3):
+        d = orc.one_to_many(q[i], data, stride, n, measure)
+        for frac in (0.0, 0.001, 0.6):     # empty, a few, most of the dataset (> LDS sort sizes)
+            radius = float(np.sort(d)[int(frac * (n - 1))]) if frac else float(d.min()) - 1.0
+            oi, od = orc.bf_search_radius(data, n, dim, stride, measure, q[i], radius)
+            gi, gd, cnt = hip.bf_search_radius(index, q[i], radius)
+            assert cnt == oi.size
+            assert np.array_equal(bits(gd), bits(od))
+            H.assert_topk_equal_up_to_ties(gi, gd, oi, od)
+    d0 = np.sort(orc.one_to_many(q[0], data, stride, n, measure))
+    gi, gd, cnt = hip.bf_search_radius(index, q[0], float(d0[100]), capacity=10)
+    assert cnt == int(np.searchsorted(d0, d0[100], side="right")) and gi.size == 10
+    with pytest.raises(hip.ScannError):
+        hip.bf_search_radius(index, q[0][:dim - 1], 1.0)
