@@ -257,6 +257,25 @@ int scann_hip_encode(scann_hip_ctx *ctx, const float *codebook, uint32_t num_sub
 int scann_hip_bf_distances(scann_hip_index *index, const float *queries, uint32_t nq,
                            uint32_t q_stride, float *out);
 
+/* ---- index build on the GPU ------------------------------------------
+ * K-means over the rows of a brute-force index, or over the column window [col_offset,
+ * col_offset + sub_dim) of them (per-subspace codebook training, src/hashes/codebook.rs:177-199).
+ *
+ * scann_hip_kmeans_init_pp: KMeans::kmeans_plusplus_init (src/trees/kmeans.rs:295-349) with a
+ *   documented splitmix64 stream (the reference's rand::StdRng is not reproducible);
+ *   centers_out [k][sub_dim].
+ * scann_hip_kmeans_lloyd: the Lloyd loop of KMeans::fit_single (:210-263) from the caller's initial
+ *   centres (updated in place): assign_clusters (strict '<', lowest index on ties; sequential-scalar
+ *   SquaredL2), inertia = f64 sum of the minimum distances, stop when |prev - inertia| / (prev + 1e-10)
+ *   < convergence_threshold, update_centers (f64 sums in ascending datapoint order, mean cast to f32,
+ *   empty cluster c takes row c % n), then the final assignment.  Outputs may be NULL. */
+int scann_hip_kmeans_init_pp(scann_hip_index *bf_index, uint32_t col_offset, uint32_t sub_dim, uint32_t k,
+                             uint64_t seed, float *centers_out);
+int scann_hip_kmeans_lloyd(scann_hip_index *bf_index, uint32_t col_offset, uint32_t sub_dim, float *centers,
+                           uint32_t k, uint32_t max_iterations, double convergence_threshold,
+                           uint32_t *out_assign, uint32_t *out_sizes, double *out_inertia,
+                           uint32_t *out_iterations, int *out_converged);
+
 /* BruteForceSearcher::search_radius (src/brute_force/searcher.rs:142-167) for one query: every
  * datapoint with distance <= radius, stable-sorted by distance.  Writes at most `capacity` rows;
  * *out_count receives the number found (call again with a larger capacity if it exceeds it).

@@ -108,6 +108,9 @@ def lib():
         L.or_ah_search_batched.restype = C.c_int
         L.or_ah_search_batched.argtypes = [f32p, sz, sz, sz, u8p, sz, f32p, sz, f32p, sz, sz, sz,
                                            sz, C.c_int, u32p, f32p, u32p, C.c_int]
+        L.or_kmeans_lloyd.restype = C.c_int
+        L.or_kmeans_lloyd.argtypes = [f32p, sz, sz, sz, sz, f32p, sz, sz, C.c_double, sz, u32p, u32p,
+                                      C.POINTER(C.c_double), u32p, C.POINTER(C.c_int)]
         L.or_txh_search.restype = C.c_int
         L.or_txh_search.argtypes = [C.POINTER(TxhIndexC), f32p, sz, sz, u32p, f32p,
                                     u32p, f32p, C.POINTER(sz), u32p, f32p, C.POINTER(sz)]
@@ -488,3 +491,21 @@ def exact_ground_truth(train, n, dim, stride, queries, k, nthreads=0):
     lib().or_exact_ground_truth(pt, n, dim, stride, pq, nq, queries.shape[1], k,
                                 gt.ctypes.data_as(u32p), nthreads)
     return gt
+
+
+def kmeans_lloyd(data, n, stride, dim, centers, max_iterations=100, convergence_threshold=1e-5,
+                 col_offset=0, simd_threshold=128):
+    """KMeans::fit_single's Lloyd loop from given centres (trees/kmeans.rs:210-263).
+    Returns (centers, assign, sizes, inertia, iterations, converged)."""
+    data, pd = _f(data)
+    c = np.array(centers, np.float32, copy=True, order="C")
+    k = c.shape[0]
+    assign = np.zeros(n, np.uint32); sizes = np.zeros(k, np.uint32)
+    inertia = C.c_double(0); iters = C.c_uint32(0); conv = C.c_int(0)
+    r = lib().or_kmeans_lloyd(pd, n, stride, col_offset, dim, c.ctypes.data_as(f32p), k, max_iterations,
+                              convergence_threshold, simd_threshold, assign.ctypes.data_as(u32p),
+                              sizes.ctypes.data_as(u32p), C.byref(inertia),
+                              C.cast(C.byref(iters), u32p), C.byref(conv))
+    if r < 0:
+        raise ValueError("InvalidArgument")
+    return c, assign, sizes, inertia.value, iters.value, bool(conv.value)

@@ -920,3 +920,81 @@ void or_exact_ground_truth(const float *train, size_t n, size_t dim, size_t stri
         free(d);
     }
 }
+
+/* ------------------------------------------------------------------------ */
+/* K-means Lloyd loop: trees/kmeans.rs:210-263 (fit_single from given        */
+/* centres), :352-379 assign_clusters, :382-414 update_centers, :419-429     */
+/* squared_distance_with_threshold (AVX2 order when dim >= simd_threshold).  */
+/* Rows are the window [col_offset, col_offset + dim) of data[n][stride].    */
+/* ------------------------------------------------------------------------ */
+static double km_assign(const float *data, size_t n, size_t stride, size_t col_offset, size_t dim,
+                        const float *centers, size_t k, size_t simd_threshold, uint32_t *assign) {
+    double inertia = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = data + i * stride + col_offset;
+        float min_dist = INFINITY;
+        uint32_t min_idx = 0;
+        for (size_t c = 0; c < k; ++c) {
+            const float *cc = centers + c * dim;
+            float d = (dim >= simd_threshold) ? or_squared_l2_avx2(p, cc, dim)
+                                              : or_squared_l2_sequential(p, cc, dim);
+            if (d < min_dist) { /* strict: lowest index on ties */
+                min_dist = d;
+                min_idx = (uint32_t)c;
+            }
+        }
+        assign[i] = min_idx;
+        inertia += (double)min_dist; /* :376 sum in datapoint order */
+    }
+    return inertia;
+}
+
+int or_kmeans_lloyd(const float *data, size_t n, size_t stride, size_t col_offset, size_t dim,
+                    float *centers, size_t k, size_t max_iterations, double convergence_threshold,
+                    size_t simd_threshold, uint32_t *assign, uint32_t *sizes, double *inertia_out,
+                    uint32_t *iterations_out, int *converged_out) {
+    if (n == 0) return OR_ERR_INVALID_ARGUMENT; /* :167-169 */
+    double *sums = (double *)malloc(k * dim * sizeof(double));
+    size_t *counts = (size_t *)malloc(k * sizeof(size_t));
+    double prev = INFINITY;
+    uint32_t iters = 0;
+    int converged = 0;
+    for (size_t it = 0; it < max_iterations; ++it) { /* :226-246 */
+        iters = (uint32_t)(it + 1);
+        double inertia = km_assign(data, n, stride, col_offset, dim, centers, k, simd_threshold, assign);
+        double rel = fabs(prev - inertia) / (prev + 1e-10);
+        if (rel < convergence_threshold) {
+            converged = 1;
+            break;
+        }
+        prev = inertia;
+        for (size_t e = 0; e < k * dim; ++e) sums[e] = 0.0; /* update_centers :382-414 */
+        for (size_t c = 0; c < k; ++c) counts[c] = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const float *p = data + i * stride + col_offset;
+            size_t c = assign[i];
+            counts[c] += 1;
+            for (size_t j = 0; j < dim; ++j) sums[c * dim + j] += (double)p[j];
+        }
+        for (size_t c = 0; c < k; ++c) {
+            if (counts[c] > 0) {
+                for (size_t j = 0; j < dim; ++j)
+                    centers[c * dim + j] = (float)(sums[c * dim + j] / (double)counts[c]);
+            } else { /* empty cluster: data[c % n] :405-408 */
+                const float *p = data + (c % n) * stride + col_offset;
+                for (size_t j = 0; j < dim; ++j) centers[c * dim + j] = p[j];
+            }
+        }
+    }
+    double fin = km_assign(data, n, stride, col_offset, dim, centers, k, simd_threshold, assign); /* :248-249 */
+    if (sizes) {
+        for (size_t c = 0; c < k; ++c) sizes[c] = 0;
+        for (size_t i = 0; i < n; ++i) sizes[assign[i]] += 1;
+    }
+    if (inertia_out) *inertia_out = fin;
+    if (iterations_out) *iterations_out = iters;
+    if (converged_out) *converged_out = converged;
+    free(sums);
+    free(counts);
+    return 0;
+}

@@ -184,6 +184,15 @@ void or_exact_ground_truth(const float *train, size_t n, size_t dim, size_t stri
 
 int or_max_threads(void);
 
+/* trees/kmeans.rs:210-263: the Lloyd loop of KMeans::fit_single from given centres (in/out
+ * [k][dim]) over the column window [col_offset, col_offset + dim) of data[n][stride].
+ * simd_threshold: dimensions from which the reference uses its AVX2 squared_l2 (default 128;
+ * pass SIZE_MAX for always-scalar). */
+int or_kmeans_lloyd(const float *data, size_t n, size_t stride, size_t col_offset, size_t dim,
+                    float *centers, size_t k, size_t max_iterations, double convergence_threshold,
+                    size_t simd_threshold, uint32_t *assign, uint32_t *sizes, double *inertia_out,
+                    uint32_t *iterations_out, int *converged_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -928,4 +928,33 @@ int scann_hip_bf_assign_nearest(scann_hip_index *ix, const float *centers, uint3
     return bf_assign_nearest_host(ix->bf, centers, num_centers, out_assign, out_dist, ix->stream);
 }
 
+static int kmeans_args(scann_hip_index *ix, uint32_t col_offset, uint32_t sub_dim, uint32_t k, const void *c) {
+    if (!ix || ix->kind != KIND_BF) return fail(SCANN_HIP_INVALID_ARGUMENT, "not a brute-force index");
+    if (ix->bf.n == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "Cannot cluster empty dataset");   // kmeans.rs:167-169
+    if (!c || k == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "null centres / zero clusters");
+    if (sub_dim == 0 || (uint64_t)col_offset + sub_dim > ix->bf.dim)
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "column window outside the rows");
+    return SCANN_HIP_OK;
+}
+
+int scann_hip_kmeans_init_pp(scann_hip_index *ix, uint32_t col_offset, uint32_t sub_dim, uint32_t k,
+                             uint64_t seed, float *centers_out) {
+    SCANN_TRY(kmeans_args(ix, col_offset, sub_dim, k, centers_out));
+    std::lock_guard<std::mutex> lock(ix->mu);
+    SCANN_TRY(set_device(ix->ctx));
+    return bf_kmeans_init_pp_host(ix->bf, col_offset, sub_dim, k, seed, centers_out, ix->stream);
+}
+
+int scann_hip_kmeans_lloyd(scann_hip_index *ix, uint32_t col_offset, uint32_t sub_dim, float *centers,
+                           uint32_t k, uint32_t max_iterations, double convergence_threshold,
+                           uint32_t *out_assign, uint32_t *out_sizes, double *out_inertia,
+                           uint32_t *out_iterations, int *out_converged) {
+    SCANN_TRY(kmeans_args(ix, col_offset, sub_dim, k, centers));
+    std::lock_guard<std::mutex> lock(ix->mu);
+    SCANN_TRY(set_device(ix->ctx));
+    return bf_kmeans_lloyd_host(ix->bf, col_offset, sub_dim, centers, k, max_iterations,
+                                convergence_threshold, out_assign, out_sizes, out_inertia, out_iterations,
+                                out_converged, ix->stream);
+}
+
 }  // extern "C"

@@ -18,6 +18,9 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <cmath>
+#include <vector>
+
 namespace scann {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -810,6 +813,352 @@ int bf_assign_nearest_host(const BfIndexDev &ix, const float *centers, uint32_t 
     SCANN_HIP_CHECK(hipMemcpyAsync(out_idx, di.p, (size_t)ix.n * 4, hipMemcpyDeviceToHost, st));
     if (out_dist) SCANN_HIP_CHECK(hipMemcpyAsync(out_dist, dd.p, (size_t)ix.n * 4, hipMemcpyDeviceToHost, st));
     SCANN_HIP_CHECK(hipStreamSynchronize(st));
+    return SCANN_HIP_OK;
+}
+
+// =====================================================================================
+// K-means on the GPU (index build).  KMeans::fit_single
+// (trees/kmeans.rs:210-263) over the rows of a brute-force index, optionally a column window
+// [col_offset, col_offset + sub_dim) of them (per-subspace codebook training,
+// hashes/codebook.rs:177-199):
+//   assign_clusters :352-379   nearest centre, strict '<' (lowest index on ties); sequential
+//                              scalar SquaredL2 (the reference switches to its AVX2 order at
+//                              dim >= simd_threshold = 128; not reproduced, training parity
+//                              is unpinned anyway: the reference seeds from an unpinned RNG)
+//   inertia                    f64 sum of the minimum distances (fixed reduction tree)
+//   update_centers :382-414    f64 sums in ascending datapoint order per (cluster, dim), mean
+//                              cast to f32; empty cluster c takes row c % n
+// =====================================================================================
+__global__ __launch_bounds__(256) void km_sum_f64_kernel(const float *__restrict__ v, uint64_t n,
+                                                         double *__restrict__ partials) {
+    __shared__ double s[256];
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    s[threadIdx.x] = i < n ? (double)v[i] : 0.0;
+    __syncthreads();
+    for (uint32_t o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = s[0];
+}
+
+// partials -> total (fixed order: per-thread chunks, then the 256 chunk sums in order); optional
+// k-means++ pick: first i with cumulative min_d >= u * total (kmeans.rs:318-331), or `fallback`
+// if total == 0.  One block of 256 threads.
+__global__ __launch_bounds__(256) void km_total_pick_kernel(const double *__restrict__ partials, uint32_t nb,
+                                                            const float *__restrict__ min_d, uint64_t n,
+                                                            double u, uint32_t fallback,
+                                                            double *__restrict__ total_out,
+                                                            uint32_t *__restrict__ pick_out) {
+    __shared__ double s_chunk[256];
+    __shared__ float s_vals[256];
+    __shared__ uint32_t s_blk;
+    __shared__ double s_cum;
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (nb + 255u) / 256u;
+    const uint32_t b0 = min(nb, t * per), b1 = min(nb, b0 + per);
+    double mine = 0.0;
+    for (uint32_t b = b0; b < b1; ++b) mine += partials[b];
+    s_chunk[t] = mine;
+    __syncthreads();
+    if (t == 0) {
+        double total = 0.0;
+        for (uint32_t c = 0; c < 256; ++c) total += s_chunk[c];
+        *total_out = total;
+        s_blk = 0xFFFFFFFFu;
+        if (pick_out) {
+            if (!(total > 0.0)) {
+                *pick_out = fallback;
+            } else {
+                const double thr = u * total;
+                double cum = 0.0;
+                uint32_t c = 0;
+                for (; c + 1 < 256; ++c) {   // chunk holding the threshold
+                    if (cum + s_chunk[c] >= thr) break;
+                    cum += s_chunk[c];
+                }
+                uint32_t b = min(nb, c * per);
+                const uint32_t be = min(nb, b + per);
+                for (; b + 1 < be; ++b) {    // block of 256 rows inside the chunk
+                    if (cum + partials[b] >= thr) break;
+                    cum += partials[b];
+                }
+                s_blk = min(b, nb - 1);
+                s_cum = cum;
+            }
+        }
+    }
+    __syncthreads();
+    if (s_blk == 0xFFFFFFFFu) return;
+    const uint64_t i0 = (uint64_t)s_blk * 256;
+    s_vals[t] = (i0 + t < n) ? min_d[i0 + t] : 0.0f;
+    __syncthreads();
+    if (t == 0) {
+        const double thr = u * (*total_out);
+        const uint32_t cnt = (uint32_t)min((uint64_t)256, n - i0);
+        double cum = s_cum;
+        uint32_t sel = cnt - 1;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            cum += (double)s_vals[i];
+            if (cum >= thr) {
+                sel = i;
+                break;
+            }
+        }
+        *pick_out = (uint32_t)(i0 + sel);
+    }
+}
+
+// min_d[i] = min(min_d[i], ||row_i - row_sel||^2)  (kmeans.rs:303-345); first = overwrite
+__global__ __launch_bounds__(256) void km_mind_update_kernel(BfIndexDev ix, const uint32_t *__restrict__ sel,
+                                                             int first, float *__restrict__ min_d) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ix.n) return;
+    const float *row = ix.rows + i * ix.stride, *c = ix.rows + (uint64_t)(*sel) * ix.stride;
+    float d = 0.0f;
+    uint32_t j = 0;
+    if (((ix.stride & 3u) == 0) && ((reinterpret_cast<uintptr_t>(ix.rows) & 15u) == 0)) {
+        for (; j + 4 <= ix.dim; j += 4) {   // 16-byte loads, same sequential sum
+            const float4 x = *reinterpret_cast<const float4 *>(row + j);
+            const float4 y = *reinterpret_cast<const float4 *>(c + j);
+            float t = x.x - y.x; d = d + t * t;
+            t = x.y - y.y; d = d + t * t;
+            t = x.z - y.z; d = d + t * t;
+            t = x.w - y.w; d = d + t * t;
+        }
+    }
+    for (; j < ix.dim; ++j) {
+        const float t = row[j] - c[j];
+        d = d + t * t;
+    }
+    min_d[i] = (first || d < min_d[i]) ? d : min_d[i];
+}
+
+__global__ void km_gather_rows_kernel(BfIndexDev ix, const uint32_t *__restrict__ picks, uint32_t k,
+                                      float *__restrict__ centers) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= k * ix.dim) return;
+    const uint32_t c = e / ix.dim, j = e - c * ix.dim;
+    centers[e] = ix.rows[(uint64_t)picks[c] * ix.stride + j];
+}
+
+__global__ void km_make_keys_kernel(const uint32_t *__restrict__ assign, uint64_t n,
+                                    uint64_t *__restrict__ keys) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = ((uint64_t)assign[i] << 32) | (uint32_t)i;
+}
+
+// offsets[c] = first position of cluster c in the sorted keys (lower bound), offsets[k] = n
+__global__ void km_offsets_kernel(const uint64_t *__restrict__ sorted, uint64_t n, uint32_t k,
+                                  uint32_t *__restrict__ offsets) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > k) return;
+    const uint64_t target = (uint64_t)c << 32;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (sorted[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    offsets[c] = (uint32_t)lo;
+}
+
+// sorted member order -> contiguous copy of the (windowed) rows, so that the update streams
+__global__ void km_gather_sorted_kernel(BfIndexDev ix, const uint64_t *__restrict__ sorted, uint64_t n,
+                                        float *__restrict__ out) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * ix.dim) return;
+    const uint64_t m = e / ix.dim;
+    const uint32_t j = (uint32_t)(e - m * ix.dim);
+    out[e] = ix.rows[(uint64_t)(uint32_t)sorted[m] * ix.stride + j];
+}
+
+// One block per cluster.  The f64 sum of every (cluster, dimension) runs over the cluster's
+// members in ascending datapoint order (keys are sorted by (cluster, index)) -- a sequential
+// chain by definition; the member rows were gathered into member order by the whole chip
+// (km_gather_sorted_kernel) and the block stages tiles of them in LDS with all 256 threads, so
+// the chain reads LDS instead of waiting for one random HBM access per add.
+constexpr uint32_t kKmTileFloats = 8192;   // 32 KB of staged row values
+__global__ __launch_bounds__(256) void km_update_kernel(BfIndexDev ix, const float *__restrict__ grows,
+                                                        const uint32_t *__restrict__ offsets,
+                                                        float *__restrict__ centers) {
+    __shared__ float s_x[kKmTileFloats];
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, dim = ix.dim;
+    const uint32_t b = offsets[c], e = offsets[c + 1];
+    if (e == b) {   // empty cluster: data[c % n]  (kmeans.rs:405-408)
+        for (uint32_t j = tid; j < dim; j += blockDim.x)
+            centers[(size_t)c * dim + j] = ix.rows[(uint64_t)(c % ix.n) * ix.stride + j];
+        return;
+    }
+    // dimensions are processed in slabs of <= 256 (one chain per thread)
+    for (uint32_t j0 = 0; j0 < dim; j0 += 256) {
+        const uint32_t dw = min(256u, dim - j0);          // slab width
+        const uint32_t tm = kKmTileFloats / dw;           // members per tile
+        double sum = 0.0;
+        for (uint32_t m0 = b; m0 < e; m0 += tm) {
+            const uint32_t nm = min(tm, e - m0);
+            __syncthreads();
+            for (uint32_t f = tid; f < nm * dw; f += blockDim.x) {
+                const uint32_t mm = f / dw, jj = f - mm * dw;
+                s_x[f] = grows[(uint64_t)(m0 + mm) * dim + j0 + jj];   // rows gathered in member order
+            }
+            __syncthreads();
+            if (tid < dw)
+                for (uint32_t mm = 0; mm < nm; ++mm) sum += (double)s_x[mm * dw + tid];
+        }
+        if (tid < dw) centers[(size_t)c * dim + j0 + tid] = (float)(sum / (double)(e - b));
+    }
+}
+
+static inline uint64_t km_splitmix(uint64_t &s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+static BfIndexDev km_view(const BfIndexDev &ix, uint32_t col_offset, uint32_t sub_dim) {
+    BfIndexDev v = ix;
+    v.rows = ix.rows + col_offset;
+    v.dim = sub_dim;
+    return v;
+}
+
+static int km_launch_assign(const BfIndexDev &v, const float *d_centers, uint32_t k, uint32_t *d_assign,
+                            float *d_dist, hipStream_t st) {
+    const uint32_t dimp = (v.dim + 3u) & ~3u;
+    const size_t lds = (size_t)kAsgTC * dimp * sizeof(float);
+    SCANN_TRY(set_dyn_lds(assign_nearest_kernel, lds));
+    hipLaunchKernelGGL(assign_nearest_kernel, dim3((uint32_t)ceil_div_u64(v.n, 256)), dim3(256), lds, st, v,
+                       d_centers, k, d_assign, d_dist);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+int bf_kmeans_init_pp_host(const BfIndexDev &ix, uint32_t col_offset, uint32_t sub_dim, uint32_t k,
+                           uint64_t seed, float *centers_out, hipStream_t st) {
+    const BfIndexDev v = km_view(ix, col_offset, sub_dim);
+    const uint64_t n = v.n;
+    if (n == 0 || k == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "empty dataset / no clusters");
+    const uint32_t nb = (uint32_t)ceil_div_u64(n, 256);
+    DevBuf dmin, dpart, dtotal, dpicks, dcent;
+    SCANN_TRY(dmin.ensure(n * 4));
+    SCANN_TRY(dpart.ensure((size_t)nb * 8));
+    SCANN_TRY(dtotal.ensure(8));
+    SCANN_TRY(dpicks.ensure((size_t)k * 4));
+    SCANN_TRY(dcent.ensure((size_t)k * sub_dim * 4));
+    uint64_t s = seed;
+    const uint32_t first = (uint32_t)(km_splitmix(s) % n);   // kmeans.rs:305-306
+    SCANN_HIP_CHECK(hipMemcpyAsync(dpicks.p, &first, 4, hipMemcpyHostToDevice, st));
+    for (uint32_t c = 1; c <= k; ++c) {
+        uint32_t *sel = dpicks.as<uint32_t>() + (c - 1);
+        hipLaunchKernelGGL(km_mind_update_kernel, dim3(nb), dim3(256), 0, st, v, sel, c == 1 ? 1 : 0,
+                           dmin.as<float>());
+        LAUNCH_CHECK();
+        if (c == k) break;
+        hipLaunchKernelGGL(km_sum_f64_kernel, dim3(nb), dim3(256), 0, st, dmin.as<float>(), n,
+                           dpart.as<double>());
+        LAUNCH_CHECK();
+        const double u = (double)(km_splitmix(s) >> 11) * (1.0 / 9007199254740992.0);
+        const uint32_t fallback = (uint32_t)(km_splitmix(s) % n);
+        hipLaunchKernelGGL(km_total_pick_kernel, dim3(1), dim3(256), 0, st, dpart.as<double>(), nb,
+                           dmin.as<float>(), n, u, fallback, dtotal.as<double>(), dpicks.as<uint32_t>() + c);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(km_gather_rows_kernel, dim3(ceil_div_u32(k * sub_dim, 256)), dim3(256), 0, st, v,
+                       dpicks.as<uint32_t>(), k, dcent.as<float>());
+    LAUNCH_CHECK();
+    SCANN_HIP_CHECK(hipMemcpyAsync(centers_out, dcent.p, (size_t)k * sub_dim * 4, hipMemcpyDeviceToHost, st));
+    SCANN_HIP_CHECK(hipStreamSynchronize(st));
+    return SCANN_HIP_OK;
+}
+
+int bf_kmeans_lloyd_host(const BfIndexDev &ix, uint32_t col_offset, uint32_t sub_dim, float *centers,
+                         uint32_t k, uint32_t max_iterations, double convergence_threshold,
+                         uint32_t *out_assign, uint32_t *out_sizes, double *out_inertia,
+                         uint32_t *out_iterations, int *out_converged, hipStream_t st) {
+    const BfIndexDev v = km_view(ix, col_offset, sub_dim);
+    const uint64_t n = v.n;
+    if (n == 0 || k == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "Cannot cluster empty dataset");
+    const uint32_t nb = (uint32_t)ceil_div_u64(n, 256);
+    DevBuf dcent, dassign, ddist, dpart, dtotal, dkeys, dsorted, dtmp, doff, dgrows;
+    SCANN_TRY(upload(dcent, centers, (size_t)k * sub_dim * 4));
+    SCANN_TRY(dassign.ensure(n * 4));
+    SCANN_TRY(ddist.ensure(n * 4));
+    SCANN_TRY(dpart.ensure((size_t)nb * 8));
+    SCANN_TRY(dtotal.ensure(8));
+    SCANN_TRY(dkeys.ensure(n * 8));
+    SCANN_TRY(dsorted.ensure(n * 8));
+    SCANN_TRY(doff.ensure((size_t)(k + 1) * 4));
+    SCANN_TRY(dgrows.ensure(n * sub_dim * 4));
+    size_t tmp_bytes = 0;
+    SCANN_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, dkeys.as<uint64_t>(),
+                                                      dsorted.as<uint64_t>(), (int)n, 0, 64, st));
+    SCANN_TRY(dtmp.ensure(tmp_bytes));
+    int key_bits = 33;   // 32 index bits + the bits of the cluster id
+    while (key_bits < 64 && (1ull << (key_bits - 32)) < k) ++key_bits;
+
+    auto assign_and_inertia = [&](double *inertia) -> int {
+        SCANN_TRY(km_launch_assign(v, dcent.as<float>(), k, dassign.as<uint32_t>(), ddist.as<float>(), st));
+        hipLaunchKernelGGL(km_sum_f64_kernel, dim3(nb), dim3(256), 0, st, ddist.as<float>(), n,
+                           dpart.as<double>());
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(km_total_pick_kernel, dim3(1), dim3(256), 0, st, dpart.as<double>(), nb,
+                           (const float *)nullptr, n, 0.0, 0u, dtotal.as<double>(), (uint32_t *)nullptr);
+        LAUNCH_CHECK();
+        SCANN_HIP_CHECK(hipMemcpyAsync(inertia, dtotal.p, 8, hipMemcpyDeviceToHost, st));
+        SCANN_HIP_CHECK(hipStreamSynchronize(st));
+        return SCANN_HIP_OK;
+    };
+
+    double prev = INFINITY, inertia = 0.0;
+    uint32_t iters = 0;
+    int converged = 0;
+    for (uint32_t it = 0; it < max_iterations; ++it) {   // kmeans.rs:226-246
+        iters = it + 1;
+        SCANN_TRY(assign_and_inertia(&inertia));
+        const double rel = std::fabs(prev - inertia) / (prev + 1e-10);
+        if (rel < convergence_threshold) {
+            converged = 1;
+            break;
+        }
+        prev = inertia;
+        // update_centers: members of every cluster in ascending datapoint order
+        hipLaunchKernelGGL(km_make_keys_kernel, dim3(nb), dim3(256), 0, st, dassign.as<uint32_t>(), n,
+                           dkeys.as<uint64_t>());
+        LAUNCH_CHECK();
+        SCANN_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(dtmp.p, tmp_bytes, dkeys.as<uint64_t>(),
+                                                          dsorted.as<uint64_t>(), (int)n, 0, key_bits, st));
+        hipLaunchKernelGGL(km_offsets_kernel, dim3(ceil_div_u32(k + 1, 256)), dim3(256), 0, st,
+                           dsorted.as<uint64_t>(), n, k, doff.as<uint32_t>());
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(km_gather_sorted_kernel, dim3((uint32_t)ceil_div_u64(n * sub_dim, 256)), dim3(256), 0,
+                           st, v, dsorted.as<uint64_t>(), n, dgrows.as<float>());
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(km_update_kernel, dim3(k), dim3(256), 0, st, v, dgrows.as<float>(),
+                           doff.as<uint32_t>(), dcent.as<float>());
+        LAUNCH_CHECK();
+    }
+    // final assignment for accurate sizes / inertia (kmeans.rs:248-255)
+    SCANN_TRY(assign_and_inertia(&inertia));
+    SCANN_HIP_CHECK(hipMemcpyAsync(centers, dcent.p, (size_t)k * sub_dim * 4, hipMemcpyDeviceToHost, st));
+    if (out_assign || out_sizes) {
+        std::vector<uint32_t> tmp;
+        uint32_t *dst = out_assign;
+        if (!dst) {
+            tmp.resize(n);
+            dst = tmp.data();
+        }
+        SCANN_HIP_CHECK(hipMemcpyAsync(dst, dassign.p, n * 4, hipMemcpyDeviceToHost, st));
+        SCANN_HIP_CHECK(hipStreamSynchronize(st));
+        if (out_sizes) {
+            for (uint32_t c = 0; c < k; ++c) out_sizes[c] = 0;
+            for (uint64_t i = 0; i < n; ++i) ++out_sizes[dst[i]];
+        }
+    }
+    SCANN_HIP_CHECK(hipStreamSynchronize(st));
+    if (out_inertia) *out_inertia = inertia;
+    if (out_iterations) *out_iterations = iters;
+    if (out_converged) *out_converged = converged;
     return SCANN_HIP_OK;
 }
 

@@ -31,7 +31,8 @@ EXPORTS = [
     "scann_hip_txh_search_local_device", "scann_hip_txh_merge_device",
     "scann_hip_assign_leaves", "scann_hip_txh_partition", "scann_hip_lut_from_query",
     "scann_hip_adc_distances", "scann_hip_lut16_distances_batch", "scann_hip_encode",
-    "scann_hip_bf_distances", "scann_hip_bf_search_radius", "scann_hip_bf_assign_nearest", "scann_hip_index_size", "scann_hip_index_dimensionality",
+    "scann_hip_bf_distances", "scann_hip_bf_search_radius", "scann_hip_bf_assign_nearest",
+    "scann_hip_kmeans_init_pp", "scann_hip_kmeans_lloyd", "scann_hip_index_size", "scann_hip_index_dimensionality",
     "scann_hip_index_destroy", "scann_hip_index_enable_timing",
     "scann_hip_index_last_kernel_ms",
 ]
@@ -122,6 +123,10 @@ def load():
                                    C.c_uint64, C.c_uint32, f32p, u32p, u8p]
     L.scann_hip_bf_distances.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, f32p]
     L.scann_hip_bf_assign_nearest.argtypes = [vp, f32p, C.c_uint32, u32p, f32p]
+    L.scann_hip_kmeans_init_pp.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, f32p]
+    L.scann_hip_kmeans_lloyd.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, C.c_uint32, C.c_uint32,
+                                         C.c_double, u32p, u32p, C.POINTER(C.c_double), u32p,
+                                         C.POINTER(C.c_int)]
     L.scann_hip_bf_search_radius.argtypes = [vp, f32p, C.c_uint32, C.c_float, u32p, f32p, C.c_uint64,
                                              C.POINTER(C.c_uint64)]
     L.scann_hip_index_size.restype = C.c_uint64
@@ -371,6 +376,29 @@ def bf_search_radius(index, query, radius, capacity=None):
                                             C.byref(cnt)))
     n = min(int(cnt.value), cap)
     return idx[:n], dist[:n], int(cnt.value)
+
+
+def kmeans_init_pp(index, k, seed, col_offset=0, sub_dim=None):
+    """k-means++ seeding on the GPU over the rows of a brute-force index: centres [k][sub_dim]."""
+    sd = index.dimensionality() if sub_dim is None else sub_dim
+    out = np.zeros((k, sd), np.float32)
+    check(load().scann_hip_kmeans_init_pp(index.h, col_offset, sd, k, C.c_uint64(seed), ptr(out, f32p)))
+    return out
+
+
+def kmeans_lloyd(index, centers, max_iterations=100, convergence_threshold=1e-5, col_offset=0):
+    """KMeans::fit_single's Lloyd loop on the GPU from given centres.
+    Returns (centers, assign, sizes, inertia, iterations, converged)."""
+    c = np.array(centers, np.float32, copy=True, order="C")
+    k, sd = c.shape
+    n = index.size()
+    assign = np.zeros(n, np.uint32); sizes = np.zeros(k, np.uint32)
+    inertia = C.c_double(0); iters = C.c_uint32(0); conv = C.c_int(0)
+    check(load().scann_hip_kmeans_lloyd(index.h, col_offset, sd, ptr(c, f32p), k, max_iterations,
+                                        C.c_double(convergence_threshold), ptr(assign, u32p),
+                                        ptr(sizes, u32p), C.byref(inertia),
+                                        C.cast(C.byref(iters), u32p), C.byref(conv)))
+    return c, assign, sizes, inertia.value, iters.value, bool(conv.value)
 
 
 def bf_assign_nearest(index, centers, want_dist=True):

@@ -201,88 +201,26 @@ inline uint64_t splitmix(uint64_t &s) {
     return z ^ (z >> 31);
 }
 
-// Lloyd k-means on rows [n][stride] restricted to columns [c0, c0+d).  Returns centers
-// [k][d] and assignments.  (trees/kmeans.rs:166-414 analogue; own RNG, random init.)
-inline void kmeans(const float *rows, size_t n, size_t stride, size_t c0, size_t d, size_t k,
-                   size_t iters, uint64_t seed, std::vector<float> &centers, std::vector<uint32_t> &assign) {
-    k = std::min(k, n);
+// KMeans::fit (trees/kmeans.rs:166-263) on the GPU over the rows of the brute-force index `bf`,
+// restricted to columns [c0, c0 + d): k-means++ seeding (scann_hip_kmeans_init_pp, splitmix64 stream)
+// then the Lloyd loop of fit_single (scann_hip_kmeans_lloyd: sequential-scalar assignment with the
+// lowest index on ties, f64 centre update in datapoint order, the reference's convergence test).
+inline void kmeans_gpu(scann_hip_index *bf, size_t n, size_t c0, size_t d, size_t k, size_t max_iterations,
+                       double convergence_threshold, uint64_t seed, std::vector<float> &centers,
+                       std::vector<uint32_t> &assign) {
+    k = std::min(k, n);   // kmeans.rs:171-175: at most n clusters
     centers.assign(k * d, 0.0f);
     assign.assign(n, 0);
-    uint64_t s = seed;
-    std::vector<size_t> pick;
-    while (pick.size() < k) {
-        size_t c = splitmix(s) % n;
-        if (std::find(pick.begin(), pick.end(), c) == pick.end()) pick.push_back(c);
-    }
-    for (size_t c = 0; c < k; ++c) std::memcpy(&centers[c * d], rows + pick[c] * stride + c0, d * 4);
-    std::vector<double> sums(k * d);
-    std::vector<size_t> cnt(k);
-    for (size_t it = 0; it <= iters; ++it) {
-        bool changed = false;
-        for (size_t i = 0; i < n; ++i) {
-            const float *x = rows + i * stride + c0;
-            float best = std::numeric_limits<float>::infinity();
-            uint32_t bi = 0;
-            for (size_t c = 0; c < k; ++c) {
-                float acc = 0.0f;
-                for (size_t j = 0; j < d; ++j) { float t = x[j] - centers[c * d + j]; acc += t * t; }
-                if (acc < best) { best = acc; bi = (uint32_t)c; }
-            }
-            if (assign[i] != bi) { assign[i] = bi; changed = true; }
-        }
-        if (it == iters || (!changed && it > 0)) break;
-        std::fill(sums.begin(), sums.end(), 0.0);
-        std::fill(cnt.begin(), cnt.end(), 0);
-        for (size_t i = 0; i < n; ++i) {
-            const float *x = rows + i * stride + c0;
-            for (size_t j = 0; j < d; ++j) sums[assign[i] * d + j] += x[j];
-            ++cnt[assign[i]];
-        }
-        for (size_t c = 0; c < k; ++c)
-            if (cnt[c]) for (size_t j = 0; j < d; ++j) centers[c * d + j] = (float)(sums[c * d + j] / cnt[c]);
-    }
+    check(scann_hip_kmeans_init_pp(bf, (uint32_t)c0, (uint32_t)d, (uint32_t)k, seed, centers.data()));
+    check(scann_hip_kmeans_lloyd(bf, (uint32_t)c0, (uint32_t)d, centers.data(), (uint32_t)k,
+                                 (uint32_t)max_iterations, convergence_threshold, assign.data(), nullptr,
+                                 nullptr, nullptr, nullptr));
 }
 
-// Lloyd k-means over whole rows with the ASSIGNMENT step on the GPU
-// (scann_hip_bf_assign_nearest: the partitioner's sequential-scalar arithmetic, lowest index
-// on ties) and the centre update on the host in f64, as trees/kmeans.rs:382-414 does.
-// `bf` is a brute-force index holding the same rows.
-inline void kmeans_gpu(scann_hip_index *bf, const float *rows, size_t n, size_t stride, size_t d, size_t k,
-                       size_t iters, uint64_t seed, std::vector<float> &centers, std::vector<uint32_t> &assign) {
-    k = std::min(k, n);
-    centers.assign(k * d, 0.0f);
-    assign.assign(n, 0);
-    uint64_t s = seed;
-    std::vector<size_t> pick;
-    while (pick.size() < k) {
-        size_t c = splitmix(s) % n;
-        if (std::find(pick.begin(), pick.end(), c) == pick.end()) pick.push_back(c);
-    }
-    for (size_t c = 0; c < k; ++c) std::memcpy(&centers[c * d], rows + pick[c] * stride, d * 4);
-    std::vector<uint32_t> next(n);
-    std::vector<double> sums(k * d);
-    std::vector<size_t> cnt(k);
-    for (size_t it = 0; it <= iters; ++it) {
-        check(scann_hip_bf_assign_nearest(bf, centers.data(), (uint32_t)k, next.data(), nullptr));
-        const bool changed = next != assign;
-        assign.swap(next);
-        if (it == iters || (!changed && it > 0)) break;
-        std::fill(sums.begin(), sums.end(), 0.0);
-        std::fill(cnt.begin(), cnt.end(), 0);
-        for (size_t i = 0; i < n; ++i) {
-            const float *x = rows + i * stride;
-            double *sp = &sums[(size_t)assign[i] * d];
-            for (size_t j = 0; j < d; ++j) sp[j] += x[j];
-            ++cnt[assign[i]];
-        }
-        for (size_t c = 0; c < k; ++c)
-            if (cnt[c]) for (size_t j = 0; j < d; ++j) centers[c * d + j] = (float)(sums[c * d + j] / cnt[c]);
-    }
-}
-
-// Codebook::train (hashes/codebook.rs:146-202): per-subspace k-means, seed + s.
-inline std::vector<float> train_codebook(const float *rows, size_t n, size_t stride, uint32_t dim,
-                                         uint32_t S, uint32_t K, uint64_t seed, size_t iters) {
+// Codebook::train (hashes/codebook.rs:146-202): per-subspace k-means with seed + s, on the GPU over
+// the column windows of `bf` (an index holding the training rows).
+inline std::vector<float> train_codebook(scann_hip_index *bf, size_t n, uint32_t dim, uint32_t S, uint32_t K,
+                                         uint64_t seed, size_t max_iterations, double convergence_threshold) {
     if (n == 0) throw ScannError::invalid_argument("Cannot train on empty dataset");
     if (dim % S != 0)   // codebook.rs:154-159
         throw ScannError::invalid_argument("Dimensionality " + std::to_string(dim) +
@@ -291,7 +229,8 @@ inline std::vector<float> train_codebook(const float *rows, size_t n, size_t str
     std::vector<float> cb((size_t)S * K * dsub, 0.0f), centers;
     std::vector<uint32_t> assign;
     for (uint32_t s = 0; s < S; ++s) {
-        kmeans(rows, n, stride, (size_t)s * dsub, dsub, K, iters, seed + s, centers, assign);
+        kmeans_gpu(bf, n, (size_t)s * dsub, dsub, K, max_iterations, convergence_threshold, seed + s, centers,
+                   assign);
         const size_t got = centers.size() / dsub;
         for (uint32_t c = 0; c < K; ++c)
             std::memcpy(&cb[((size_t)s * K + c) * dsub], &centers[std::min<size_t>(c, got - 1) * dsub], dsub * 4);
@@ -354,7 +293,8 @@ struct AsymmetricHasherConfig {      // hasher.rs:19-69 (default 256 x 8: byte c
     size_t num_codes = 256, num_subspaces = 8;
     uint64_t seed = 42;
     bool has_seed = false;
-    size_t training_iterations = 25;
+    size_t training_iterations = 25;       // CodebookConfig.max_iterations
+    double convergence_threshold = 1e-5;   // CodebookConfig.convergence_threshold
     AsymmetricHasherConfig() = default;
     AsymmetricHasherConfig(size_t codes, size_t subspaces) : num_codes(codes), num_subspaces(subspaces) {}
     AsymmetricHasherConfig with_seed(uint64_t s) const { auto c = *this; c.seed = s; c.has_seed = true; return c; }
@@ -406,8 +346,13 @@ private:
         dim_ = ds.dimensionality();
         n_ = ds.size();
         const uint32_t S = (uint32_t)config_.num_subspaces, K = (uint32_t)config_.num_codes;
-        codebook_ = detail::train_codebook(ds.raw_data(), n_, ds.stride(), (uint32_t)dim_, S, K,
-                                           config_.seed, config_.training_iterations);
+        {
+            detail::IndexHandle tmp;   // training rows resident on the GPU for the k-means passes
+            check(scann_hip_bf_create(context(device_), ds.raw_data(), n_, (uint32_t)dim_, ds.stride(),
+                                      SCANN_HIP_SQUARED_L2, &tmp.h));
+            codebook_ = detail::train_codebook(tmp.h, n_, (uint32_t)dim_, S, K, config_.seed,
+                                               config_.training_iterations, config_.convergence_threshold);
+        }
         codes_.assign(n_ * S, 0);
         check(scann_hip_encode(context(device_), codebook_.data(), S, K, (uint32_t)dim_ / S, ds.raw_data(), n_,
                                ds.stride(), nullptr, nullptr, codes_.data()));
@@ -445,7 +390,7 @@ struct TreeXHybridConfig {           // mod.rs:23-78
     bool use_residuals = true;
     float pre_reorder_multiplier = 3.0f;
     bool parallel_partition_search = true;   // no effect: every leaf scan is parallel on the GPU
-    size_t kmeans_iterations = 25;
+    size_t kmeans_iterations = 100;   // tree_partitioner.rs:72 with_max_iterations(100)
     TreeXHybridConfig() = default;
     TreeXHybridConfig(size_t parts, size_t to_search) : num_partitions(parts), partitions_to_search(to_search) {}
     TreeXHybridConfig with_hash(AsymmetricHasherConfig c) const { auto t = *this; t.hash_config = c; return t; }
@@ -466,15 +411,14 @@ public:
         if (dim % S != 0)
             throw ScannError::invalid_argument("Dimensionality " + std::to_string(dim) +
                                                " must be divisible by num_subspaces " + std::to_string(S));
-        // TreePartitioner::build: flat k-means, seed 42 (tree_partitioner.rs:48-98); the
-        // assignment step (N x L x d) runs on the GPU, the f64 centre update on the host.
+        // TreePartitioner::build: flat k-means, seed 42 (tree_partitioner.rs:48-98), on the GPU.
         std::vector<uint32_t> assign;
         {
             detail::IndexHandle tmp;
             check(scann_hip_bf_create(context(device_), ds.raw_data(), n, (uint32_t)dim, (uint32_t)st,
                                       SCANN_HIP_SQUARED_L2, &tmp.h));
-            detail::kmeans_gpu(tmp.h, ds.raw_data(), n, st, dim, config_.num_partitions,
-                               config_.kmeans_iterations, 42, centers_, assign);
+            detail::kmeans_gpu(tmp.h, n, 0, dim, config_.num_partitions, config_.kmeans_iterations, 1e-5, 42,
+                               centers_, assign);
         }
         const uint32_t L = (uint32_t)(centers_.size() / dim);
         leaf_off_.assign(L + 1, 0);
@@ -495,8 +439,14 @@ public:
                 for (size_t j = 0; j < dim; ++j)
                     rows[r * dim + j] = config_.use_residuals ? x[j] - centers_[l * dim + j] : x[j];
             }
-        codebook_ = detail::train_codebook(rows.data(), n, dim, (uint32_t)dim, S, K, config_.hash_config.seed,
-                                           config_.hash_config.training_iterations);
+        {
+            detail::IndexHandle tmp;   // residual rows resident on the GPU for the codebook k-means
+            check(scann_hip_bf_create(context(device_), rows.data(), n, (uint32_t)dim, (uint32_t)dim,
+                                      SCANN_HIP_SQUARED_L2, &tmp.h));
+            codebook_ = detail::train_codebook(tmp.h, n, (uint32_t)dim, S, K, config_.hash_config.seed,
+                                               config_.hash_config.training_iterations,
+                                               config_.hash_config.convergence_threshold);
+        }
         codes_.assign(n * S, 0);
         check(scann_hip_encode(context(device_), codebook_.data(), S, K, (uint32_t)dim / S, rows.data(), n,
                                (uint32_t)dim, nullptr, nullptr, codes_.data()));

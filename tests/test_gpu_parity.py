@@ -537,3 +537,51 @@ def test_bf_search_radius(measure, n, dim):
     assert cnt == int(np.searchsorted(d0, d0[100], side="right")) and gi.size == 10
     with pytest.raises(hip.ScannError):
         hip.bf_search_radius(index, q[0][:dim - 1], 1.0)
+
+
+# ---- index build: K-means on the GPU (trees/kmeans.rs:210-414) -------------------------------------
+@pytest.mark.parametrize("n,dim,k,col,sub", [(5000, 32, 16, 0, 32), (20000, 96, 50, 0, 96),
+                                             (3000, 64, 16, 8, 4), (4000, 64, 256, 61, 3), (300, 7, 3, 0, 7)])
+def test_kmeans_lloyd_matches_oracle(n, dim, k, col, sub):
+    """Same initial centres -> bit-identical centres, assignments and iteration count as the CPU
+    restatement of KMeans::fit_single (dims < 128: both sides use the sequential scalar distance)."""
+    rows, _ = synth.clustered_f32(n, dim, 71, n_clusters=max(4, k // 2))
+    data, stride = orc.to_strided(rows)
+    index = hip.bf_create(data, n, dim, stride, hip.SQUARED_L2)
+    pick = (synth.splitmix64(5, 0, k) % np.uint64(n)).astype(np.int64)
+    init = np.ascontiguousarray(rows[pick][:, col:col + sub])
+    gc, ga, gs, gi, git, gconv = hip.kmeans_lloyd(index, init, max_iterations=12, col_offset=col)
+    oc, oa, os_, oi, oit, oconv = orc.kmeans_lloyd(data, n, stride, sub, init, max_iterations=12,
+                                                   col_offset=col)
+    assert git == oit and gconv == oconv
+    assert np.array_equal(bits(gc), bits(oc))
+    assert np.array_equal(ga, oa) and np.array_equal(gs, os_)
+    assert abs(gi - oi) <= 1e-9 * max(1.0, abs(oi))      # f64 inertia: reduction order differs
+
+
+def test_kmeans_reference_unit_tests_on_gpu():
+    """trees/kmeans.rs:461-510: three clear clusters; empty clusters."""
+    x = np.array([[bx + np.float32(i) * np.float32(0.1), by + np.float32(i) * np.float32(0.05)]
+                  for bx, by in ((0.0, 0.0), (10.0, 10.0), (0.0, 10.0)) for i in range(10)], np.float32)
+    data, stride = orc.to_strided(x)
+    index = hip.bf_create(data, 30, 2, stride, hip.SQUARED_L2)
+    init = hip.kmeans_init_pp(index, 3, seed=42)
+    assert init.shape == (3, 2) and all(any(np.array_equal(r, p) for p in x) for r in init)
+    c, a, sizes, inertia, iters, conv = hip.kmeans_lloyd(index, init)
+    assert c.shape == (3, 2) and a.size == 30 and sizes.sum() == 30 and (conv or iters > 0)
+    far = np.array([[0, 0], [10, 10], [1000, 1000]], np.float32)
+    c, a, sizes, *_ = hip.kmeans_lloyd(index, far, max_iterations=1)
+    assert np.array_equal(c[2], x[2])                   # empty cluster c takes row c % n
+    oc, *_ = orc.kmeans_lloyd(data, 30, stride, 2, far, max_iterations=1)
+    assert np.array_equal(bits(c), bits(oc))
+
+
+def test_kmeans_init_pp_spreads_seeds():
+    rows, labels = synth.clustered_f32(20000, 32, 72, n_clusters=20)
+    data, stride = orc.to_strided(rows)
+    index = hip.bf_create(data, 20000, 32, stride, hip.SQUARED_L2)
+    a = hip.kmeans_init_pp(index, 20, seed=7)
+    assert np.array_equal(a, hip.kmeans_init_pp(index, 20, seed=7))   # deterministic in the seed
+    # D^2 sampling lands in (almost) every well-separated cluster
+    owner = [int(labels[np.flatnonzero((rows == r).all(1))[0]]) for r in a]
+    assert len(set(owner)) >= 16

@@ -342,3 +342,32 @@ def test_txh_filter_equals_search_over_allowed_rows():
         b = orc.txh_search(sub, q[i], 5, stages=True)
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
+
+
+def _clustered_30():   # trees/kmeans.rs:438-459
+    pts = []
+    for bx, by in ((0.0, 0.0), (10.0, 10.0), (0.0, 10.0)):
+        for i in range(10):
+            pts.append([bx + np.float32(i) * np.float32(0.1), by + np.float32(i) * np.float32(0.05)])
+    return np.array(pts, np.float32)
+
+
+def test_kmeans_lloyd_reference_unit_tests():  # trees/kmeans.rs:461-498 (structural asserts)
+    x = _clustered_30()
+    c, a, sizes, inertia, iters, conv = orc.kmeans_lloyd(x, 30, 2, 2, x[[0, 10, 20]])
+    assert c.shape == (3, 2) and a.size == 30 and sizes.sum() == 30 and (conv or iters > 0)
+    assert sorted(sizes.tolist()) == [10, 10, 10]
+    # centres = means of the three groups (f64 sum, cast to f32: update_centers :382-414)
+    for g in range(3):
+        want = (x[10 * g:10 * g + 10].astype(np.float64).sum(0) / 10).astype(np.float32)
+        assert np.array_equal(c[a[10 * g]], want)
+    y = np.array([[1.0, 2.0], [1.1, 2.1], [0.9, 1.9]], np.float32)   # test_kmeans_single_cluster
+    c, a, sizes, *_ = orc.kmeans_lloyd(y, 3, 2, 2, y[:1])
+    assert c.shape == (1, 2) and np.all(a == 0)
+
+
+def test_kmeans_lloyd_empty_cluster_reseeds_from_row():  # trees/kmeans.rs:405-408
+    x = _clustered_30()
+    init = np.array([[0, 0], [10, 10], [1000, 1000]], np.float32)   # third centre attracts nothing
+    c, a, sizes, inertia, iters, conv = orc.kmeans_lloyd(x, 30, 2, 2, init, max_iterations=1)
+    assert np.array_equal(c[2], x[2 % 30])
