@@ -73,8 +73,9 @@ def dev_ptr(t):
 
 def build_txh(args, torch, dist, hip, synth, trainer, device, local_rank, rank, world, stride):
     """Tree-X-Hybrid index on a clustered synthetic set (mixture of 1000 Gaussians, SURVEY.md
-    8d).  Harness plumbing: data and k-means run in torch on the GPU; rank 0 trains and
-    broadcasts so every rank holds the identical index, then keeps only its leaves."""
+    8d).  The data is generated with torch on the GPU (harness plumbing); rank 0 builds the index
+    with the library's GPU k-means and broadcasts it so every rank holds the identical index, then
+    keeps only its leaves."""
     from scann_rust_amd import sharding
     n, dim, S, L, Q, k = args.n, args.dim, args.subspaces, args.leaves, args.batch, args.k
     g = torch.Generator(device=device)
@@ -90,24 +91,30 @@ def build_txh(args, torch, dist, hip, synth, trainer, device, local_rank, rank, 
     assign = torch.empty((n,), dtype=torch.int64, device=device)
     cb_t = torch.empty((S, 16, dim // S), device=device)
     if rank == 0:
-        Cn = X[torch.randperm(n, generator=g, device=device)[:L]].clone()
-        for it in range(9):
-            cn = (Cn * Cn).sum(1)
-            a = torch.cat([(cn[None, :] - 2.0 * (X[r0:r0 + 262144] @ Cn.T)).argmin(1)
-                           for r0 in range(0, n, 262144)])
-            if it == 8:
-                break
-            sums = torch.zeros_like(Cn).index_add_(0, a, X)
-            cnt = torch.bincount(a, minlength=L)
-            newC = sums / cnt.clamp(min=1).to(X.dtype)[:, None]
-            newC[cnt == 0] = Cn[cnt == 0]
-            Cn = newC
-        C.copy_(Cn)
-        assign.copy_(a)
+        # index build with the library's own GPU k-means (KMeans::fit of trees/kmeans.rs: k-means++
+        # seeding + Lloyd, scann_hip_kmeans_*): partitioner on all rows, codebook on a residual sample
+        xs = np.zeros((n, stride), np.float32)
+        xs[:, :dim] = X.cpu().numpy()
+        bf = hip.bf_create(xs, n, dim, stride, hip.SQUARED_L2, device=local_rank)
+        c_np, a_np, _, _, it_done, _ = hip.kmeans_lloyd(bf, hip.kmeans_init_pp(bf, L, seed=42),
+                                                        max_iterations=25)
+        bf.close()
+        del xs
+        C.copy_(torch.from_numpy(c_np).to(device))
+        assign.copy_(torch.from_numpy(a_np.astype(np.int64)).to(device))
         res = X - C[assign]
-        sample = res[torch.randperm(n, generator=g, device=device)[:65536]].cpu().numpy()
-        cb_t.copy_(torch.from_numpy(trainer.train_codebook(sample, S, 16, iters=15, seed=42,
-                                                           sample=1 << 30)).to(device))
+        ns = min(n, 262144)
+        rs = np.zeros((ns, stride), np.float32)
+        rs[:, :dim] = res[torch.randperm(n, generator=g, device=device)[:ns]].cpu().numpy()
+        rbf = hip.bf_create(rs, ns, dim, stride, hip.SQUARED_L2, device=local_rank)
+        dsub = dim // S
+        cb_np = np.zeros((S, 16, dsub), np.float32)
+        for sidx in range(S):
+            c0 = hip.kmeans_init_pp(rbf, 16, seed=42 + sidx, col_offset=sidx * dsub, sub_dim=dsub)
+            cb_np[sidx] = hip.kmeans_lloyd(rbf, c0, max_iterations=25, col_offset=sidx * dsub)[0]
+        rbf.close()
+        cb_t.copy_(torch.from_numpy(cb_np).to(device))
+        log("partitioner k-means: %d Lloyd iterations" % it_done)
     if world > 1:
         if args.backend == "nccl":
             for t in (C, assign, cb_t):
