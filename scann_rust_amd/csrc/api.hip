@@ -473,14 +473,15 @@ static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallP
     w->scap = p.scap;
     {   // sample tiles: enough of them to fill the chip (the sample pass is 1/st of the scan)
         const uint64_t quads = ((uint64_t)nq * P + 3) / 4;
-        const uint64_t chunks = std::max<uint64_t>(1, ((uint64_t)p.scap + kScanTP - 1) / kScanTP);
+        const uint32_t tp = scan_tile_points(t);
+        const uint64_t chunks = std::max<uint64_t>(1, ((uint64_t)p.scap + tp - 1) / tp);
         uint32_t qpt = kScanQuadsPerTile;
         while (qpt > 2 && chunks * ((quads + qpt - 1) / qpt) < 4096) qpt >>= 1;
         if (const char *e = std::getenv("SCANN_HIP_SQPT")) qpt = (uint32_t)std::max(1, std::atoi(e));
         w->sqpt = qpt;
         // scan tiles: the largest quad group that still yields ~4 tiles per resident workgroup
         // (small shards and small batches would otherwise leave most of the chip idle)
-        const uint64_t all_chunks = t.n_local / kScanTP + L;
+        const uint64_t all_chunks = t.n_local / tp + L;
         const uint64_t quads_per_leaf = std::max<uint64_t>(1, quads / std::max(1u, L));
         uint32_t sq = kScanQuadsPerTile;
         while (sq > 8 && all_chunks * ((quads_per_leaf + sq - 1) / sq) < 6144) sq >>= 1;

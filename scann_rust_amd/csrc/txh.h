@@ -90,6 +90,11 @@ struct TxhIndexDev {
     int ah_mode;                  // single implicit leaf, no centroid stage
 };
 
+// points of one scan tile chunk for this index's code layout (Codec<S, bits>::TP in txh.hip)
+static inline uint32_t scan_tile_points(const TxhIndexDev &ix) {
+    return kScanThreads * (ix.code_bits == 4 ? kScanPPT : 8u);
+}
+
 // counters[] slots
 enum {
     CNT_TOTAL_QUADS = 0, CNT_TOTAL_TILES = 1, CNT_QUEUE_HEAD = 2, CNT_STATUS = 3,

@@ -426,6 +426,10 @@ struct Codec {
     static constexpr int KP = BITS == 4 ? 16 : 256;               // table entries per subspace
     static constexpr int SUB_BYTES = KP * 16;
     static constexpr int LUT4 = S * KP;                           // float4 per quad
+    // points per thread per tile chunk: byte-code tables are 16x larger per subspace and there
+    // are 4x fewer subspaces, so a tile takes 4x more points per staged table
+    static constexpr int PPT = BITS == 4 ? (int)kScanPPT : 8;
+    static constexpr int TP = (int)kScanThreads * PPT;            // points per tile chunk
     static_assert((S - 1) * SUB_BYTES < 65536, "ds_read immediate offset");
     // workgroups per CU the kernel is built for (LDS: two LUT buffers + survivor stage)
     static constexpr int WGS = BITS == 4 ? (S <= 32 ? (int)kScanWaves : 3)
@@ -467,10 +471,11 @@ struct Codec {
     }
 };
 
-template <typename C, int NP, int BUF>
+// Points G .. G+NP-1 of the lane against the quad's tables.
+template <typename C, int NP, int BUF, int G>
 __device__ __forceinline__ void scan_quad_compute(const float4 *lut_base,
-                                                  uint32_t (&regs)[kScanPPT][C::REGS],
-                                                  float (&acc)[4][kScanPPT]) {
+                                                  uint32_t (&regs)[C::PPT][C::REGS],
+                                                  float (&acc)[4][C::PPT]) {
     constexpr int S = C::S;
     const char *lb = reinterpret_cast<const char *>(lut_base + BUF * C::LUT4);
     // The byte extractions below are invariant across the quad loop; without this
@@ -478,7 +483,7 @@ __device__ __forceinline__ void scan_quad_compute(const float4 *lut_base,
 #pragma unroll
     for (int i = 0; i < NP; ++i)
 #pragma unroll
-        for (int ri = 0; ri < C::REGS; ++ri) asm volatile("" : "+v"(regs[i][ri]));
+        for (int ri = 0; ri < C::REGS; ++ri) asm volatile("" : "+v"(regs[G + i][ri]));
     // Software pipeline, kScanDepth subspaces deep: the NP ds_read_b128 of subspaces
     // s+1 .. s+D are in flight while subspace s is accumulated.  sched_barrier(0) pins the
     // stage order so the scheduler cannot hoist every gather to the top (256 VGPRs,
@@ -488,7 +493,7 @@ __device__ __forceinline__ void scan_quad_compute(const float4 *lut_base,
     auto issue = [&](int s, int slot) {
 #pragma unroll
         for (int i = 0; i < NP; ++i)
-            v[slot][i] = *reinterpret_cast<const float4 *>(lb + s * C::SUB_BYTES + C::offset(regs[i], s));
+            v[slot][i] = *reinterpret_cast<const float4 *>(lb + s * C::SUB_BYTES + C::offset(regs[G + i], s));
     };
 #pragma unroll
     for (int d = 0; d < D; ++d)
@@ -500,12 +505,12 @@ __device__ __forceinline__ void scan_quad_compute(const float4 *lut_base,
         for (int i = 0; i < NP; ++i) {
             const float4 t = v[s % (D + 1)][i];
             if (s == 0) {
-                acc[0][i] = t.x; acc[1][i] = t.y; acc[2][i] = t.z; acc[3][i] = t.w;
+                acc[0][G + i] = t.x; acc[1][G + i] = t.y; acc[2][G + i] = t.z; acc[3][G + i] = t.w;
             } else {
-                acc[0][i] = acc[0][i] + t.x;
-                acc[1][i] = acc[1][i] + t.y;
-                acc[2][i] = acc[2][i] + t.z;
-                acc[3][i] = acc[3][i] + t.w;
+                acc[0][G + i] = acc[0][G + i] + t.x;
+                acc[1][G + i] = acc[1][G + i] + t.y;
+                acc[2][G + i] = acc[2][G + i] + t.z;
+                acc[3][G + i] = acc[3][G + i] + t.w;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -514,11 +519,19 @@ __device__ __forceinline__ void scan_quad_compute(const float4 *lut_base,
 
 template <typename C, int BUF>
 __device__ __forceinline__ void scan_quad_dispatch(const float4 *lut_s, uint32_t nsub,
-                                                   uint32_t (&regs)[kScanPPT][C::REGS],
-                                                   float (&acc)[4][kScanPPT]) {
-    switch (nsub) {
-        case 1: scan_quad_compute<C, 1, BUF>(lut_s, regs, acc); break;
-        default: scan_quad_compute<C, (kScanPPT < 2 ? 1 : 2), BUF>(lut_s, regs, acc); break;
+                                                   uint32_t (&regs)[C::PPT][C::REGS],
+                                                   float (&acc)[4][C::PPT]) {
+    if constexpr (C::PPT <= 2) {
+        switch (nsub) {
+            case 1: scan_quad_compute<C, 1, BUF, 0>(lut_s, regs, acc); break;
+            default: scan_quad_compute<C, (C::PPT < 2 ? 1 : 2), BUF, 0>(lut_s, regs, acc); break;
+        }
+    } else {   // pairs of points; a pair past nsub is skipped (wave-uniform)
+        static_assert(C::PPT == 8, "point-pair groups are spelled out for 8 points per thread");
+        scan_quad_compute<C, 2, BUF, 0>(lut_s, regs, acc);
+        if (nsub > 2) scan_quad_compute<C, 2, BUF, 2>(lut_s, regs, acc);
+        if (nsub > 4) scan_quad_compute<C, 2, BUF, 4>(lut_s, regs, acc);
+        if (nsub > 6) scan_quad_compute<C, 2, BUF, 6>(lut_s, regs, acc);
     }
 }
 
@@ -545,7 +558,6 @@ __device__ __forceinline__ uint32_t grab_tile(uint32_t *queues, uint32_t total_t
     return kInvalid;
 }
 
-static_assert(kScanPPT <= 4, "adc_scan_kernel's nsub switch handles up to 4 points per thread");
 constexpr uint32_t kScanStage = 128;   // LDS-staged survivors per (quad, query); <= kScanThreads
 static_assert(kScanStage <= kScanThreads, "the flush copies one survivor per thread");
 
@@ -601,21 +613,21 @@ __global__ __launch_bounds__(kScanThreads, C::WGS) void adc_scan_kernel(TxhIndex
         const uint32_t leaf = lo;
         const uint32_t lb = uniform_load(ix.leaf_off + leaf);
         const uint32_t size = uniform_load(ix.leaf_off + leaf + 1) - lb;
-        const uint32_t nchunks = (size + kScanTP - 1) / kScanTP;
+        const uint32_t nchunks = (size + (uint32_t)C::TP - 1) / (uint32_t)C::TP;
         const uint32_t local = tile - uniform_load(a.tile_off + leaf);
         const uint32_t chunk = local % nchunks, qg = local / nchunks;
         const uint32_t slot0 = uniform_load(a.pair_off + leaf);
         const uint32_t nquads = (uniform_load(a.pair_off + leaf + 1) - slot0) >> 2;
         const uint32_t q0 = qg * a.qpt;
         const uint32_t q1 = min(q0 + a.qpt, nquads);
-        const uint32_t c0 = chunk * kScanTP;
-        const uint32_t npts = min(kScanTP, size - c0);
+        const uint32_t c0 = chunk * (uint32_t)C::TP;
+        const uint32_t npts = min((uint32_t)C::TP, size - c0);
         const uint32_t nsub = (npts + kScanThreads - 1) / kScanThreads;
 
         // packed codes of this lane's points in the codec's register form
-        uint32_t regs[kScanPPT][C::REGS];
+        uint32_t regs[C::PPT][C::REGS];
 #pragma unroll
-        for (int i = 0; i < (int)kScanPPT; ++i) {
+        for (int i = 0; i < C::PPT; ++i) {
             const uint32_t j = c0 + tid + kScanThreads * i;
             uint32_t w[C::NWORDS];
             C::load_words(ix.codes + (size_t)(lb + (j < size ? j : 0)) * C::NWORDS, w);
@@ -683,7 +695,7 @@ __global__ __launch_bounds__(kScanThreads, C::WGS) void adc_scan_kernel(TxhIndex
 
             if (live) {
                 // B. gather + accumulate
-                float acc[4][kScanPPT];
+                float acc[4][C::PPT];
                 if (buf == 0) scan_quad_dispatch<C, 0>(lut_s, nsub, regs, acc);
                 else scan_quad_dispatch<C, 1>(lut_s, nsub, regs, acc);
                 // threshold filter: survivors go to the LDS stage of this quad
@@ -696,7 +708,7 @@ __global__ __launch_bounds__(kScanThreads, C::WGS) void adc_scan_kernel(TxhIndex
                     const float Tf = (Thi == 0xFFFFFFFFu) ? __builtin_inff() : ordered_to_f32(Thi);
                     const uint32_t vb = f_vb[p];
 #pragma unroll
-                    for (int i = 0; i < (int)kScanPPT; ++i) {
+                    for (int i = 0; i < C::PPT; ++i) {
                         if (i < (int)nsub && acc[p][i] <= Tf) {
                             const uint32_t j = c0 + tid + kScanThreads * i;
                             if (j < size) {
@@ -747,7 +759,7 @@ __global__ __launch_bounds__(kScanThreads, C::WGS) void adc_scan_kernel(TxhIndex
 // K5: threshold from a strided sample (plan: sample_stride / sample_plan / sample_rank).
 //
 // K5a adc_sample_kernel: the scan's tiled LUT16 gather over every st-th point of each
-// selected leaf.  Tiles = (leaf, chunk of kScanTP SAMPLED points, group of a.qpt query
+// selected leaf.  Tiles = (leaf, chunk of (uint32_t)C::TP SAMPLED points, group of a.qpt query
 // quads); the ordered approximate distance of sample i of (query, leaf) goes to
 // samp[query][sbase(query, leaf) + i].  Points the allow-bitmap rejects are written as
 // 0xFFFFFFFF (absent).
@@ -789,21 +801,21 @@ __global__ __launch_bounds__(kScanThreads, C::WGS) void adc_sample_kernel(TxhInd
         const uint32_t lb = ix.leaf_off[leaf];
         const uint32_t size = ix.leaf_off[leaf + 1] - lb;
         const uint32_t ssize = (size + st - 1) / st;            // sampled points of the leaf
-        const uint32_t nchunks = (ssize + kScanTP - 1) / kScanTP;
+        const uint32_t nchunks = (ssize + (uint32_t)C::TP - 1) / (uint32_t)C::TP;
         const uint32_t local = tile - a.stile_off[leaf];
         const uint32_t chunk = local % nchunks, qg = local / nchunks;
         const uint32_t slot0 = a.pair_off[leaf];
         const uint32_t nquads = (a.pair_off[leaf + 1] - slot0) >> 2;
         const uint32_t q0 = qg * a.qpt;
         const uint32_t q1 = min(q0 + a.qpt, nquads);
-        const uint32_t c0 = chunk * kScanTP;
-        const uint32_t npts = min(kScanTP, ssize - c0);
+        const uint32_t c0 = chunk * (uint32_t)C::TP;
+        const uint32_t npts = min((uint32_t)C::TP, ssize - c0);
         const uint32_t nsub = (npts + kScanThreads - 1) / kScanThreads;
 
-        uint32_t regs[kScanPPT][C::REGS];
-        bool ok[kScanPPT];
+        uint32_t regs[C::PPT][C::REGS];
+        bool ok[C::PPT];
 #pragma unroll
-        for (int i = 0; i < (int)kScanPPT; ++i) {
+        for (int i = 0; i < C::PPT; ++i) {
             const uint32_t j = c0 + tid + kScanThreads * i;
             const uint32_t row = lb + (j < ssize ? j * st : 0u);
             ok[i] = j < ssize && row_allowed(ix, a.allow, a.allow_bits, row);
@@ -850,7 +862,7 @@ __global__ __launch_bounds__(kScanThreads, C::WGS) void adc_sample_kernel(TxhInd
                 f_pq[p] = __builtin_amdgcn_readfirstlane(a.pair_q[slot + p]);
                 f_sb[p] = __builtin_amdgcn_readfirstlane(a.pair_sbase[slot + p]);
             }
-            float acc[4][kScanPPT];
+            float acc[4][C::PPT];
             if (buf == 0) scan_quad_dispatch<C, 0>(lut_s, nsub, regs, acc);
             else scan_quad_dispatch<C, 1>(lut_s, nsub, regs, acc);
 #pragma unroll
@@ -858,7 +870,7 @@ __global__ __launch_bounds__(kScanThreads, C::WGS) void adc_sample_kernel(TxhInd
                 if (f_pq[p] == kInvalid) continue;   // wave-uniform
                 uint32_t *dst = a.samp + (size_t)f_pq[p] * a.scap + f_sb[p];
 #pragma unroll
-                for (int i = 0; i < (int)kScanPPT; ++i) {
+                for (int i = 0; i < C::PPT; ++i) {
                     const uint32_t j = c0 + tid + kScanThreads * i;
                     if (i < (int)nsub && j < ssize) dst[j] = ok[i] ? f32_to_ordered(acc[p][i]) : 0xFFFFFFFFu;
                 }
@@ -1693,7 +1705,7 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
                        npairs, ix.ah_mode, w.tokens, ix.leaf_off, w.leaf_cnt);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(worklist_scan_kernel, dim3(1), dim3(1024), 0, st, ix.L, w.leaf_cnt,
-                       ix.leaf_off, kScanTP, w.qpt, w.st, w.sqpt, w.pair_off, w.tile_off,
+                       ix.leaf_off, scan_tile_points(ix), w.qpt, w.st, w.sqpt, w.pair_off, w.tile_off,
                        w.stile_off, w.counters);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(worklist_fill_kernel, dim3(ceil_div_u32(npairs, 256)), dim3(256), 0, st, w.nq,
