@@ -84,37 +84,52 @@ __global__ __launch_bounds__(256) void bf_generic_kernel(BfIndexDev ix, BfPass p
     if (vrow >= p.nrows) return;
     const float *row = ix.rows + (size_t)vrow * p.row_mult * ix.stride;
     const uint32_t chunks = dim >> 3;
-    float acc[kBfGenQT][8];
+    // The 8 AVX2 lane chains of a (query, row) pair are independent accumulators: pairs of
+    // them go through the packed-f32 pipe (v_pk_add_f32 / v_pk_fma_f32: two IEEE operations per
+    // instruction, same results as the scalar ones).
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 accv[kBfGenQT][4];
 #pragma unroll
     for (int qi = 0; qi < kBfGenQT; ++qi)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[qi][j] = 0.0f;
+        for (int j = 0; j < 4; ++j) accv[qi][j] = f32x2{0.0f, 0.0f};
     const bool vec = ((ix.stride & 3u) == 0) && ((reinterpret_cast<uintptr_t>(ix.rows) & 15u) == 0);
     for (uint32_t c = 0; c < chunks; ++c) {
-        float x[8];
+        f32x2 x[4];
         if (vec) {
             const float4 a = *reinterpret_cast<const float4 *>(row + 8 * c);
             const float4 b = *reinterpret_cast<const float4 *>(row + 8 * c + 4);
-            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
-            x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+            x[0] = f32x2{a.x, a.y}; x[1] = f32x2{a.z, a.w};
+            x[2] = f32x2{b.x, b.y}; x[3] = f32x2{b.z, b.w};
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = row[8 * c + j];
+            for (int j = 0; j < 4; ++j) x[j] = f32x2{row[8 * c + 2 * j], row[8 * c + 2 * j + 1]};
         }
 #pragma unroll
         for (int qi = 0; qi < kBfGenQT; ++qi) {
-            const float *qv = qs + qi * dimp + 8 * c;
+            const float4 qa = *reinterpret_cast<const float4 *>(qs + qi * dimp + 8 * c);
+            const float4 qb = *reinterpret_cast<const float4 *>(qs + qi * dimp + 8 * c + 4);
+            const f32x2 qv[4] = {f32x2{qa.x, qa.y}, f32x2{qa.z, qa.w}, f32x2{qb.x, qb.y},
+                                 f32x2{qb.z, qb.w}};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 if (MEASURE == SCANN_HIP_DOT_PRODUCT) {
-                    acc[qi][j] = fmaf(qv[j], x[j], acc[qi][j]);
+                    accv[qi][j] = __builtin_elementwise_fma(qv[j], x[j], accv[qi][j]);
                 } else {
-                    const float d = qv[j] - x[j];
-                    acc[qi][j] = fmaf(d, d, acc[qi][j]);
+                    const f32x2 d = qv[j] - x[j];
+                    accv[qi][j] = __builtin_elementwise_fma(d, d, accv[qi][j]);
                 }
             }
         }
     }
+    float acc[kBfGenQT][8];
+#pragma unroll
+    for (int qi = 0; qi < kBfGenQT; ++qi)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[qi][2 * j] = accv[qi][j].x;
+            acc[qi][2 * j + 1] = accv[qi][j].y;
+        }
 #pragma unroll
     for (int qi = 0; qi < kBfGenQT; ++qi) {
         if (q0 + qi >= p.nq) continue;
