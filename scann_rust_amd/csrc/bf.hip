@@ -159,6 +159,110 @@ __global__ __launch_bounds__(256) void bf_generic_kernel(BfIndexDev ix, BfPass p
 }
 
 // =====================================================================================
+// SquaredL2 / L2 kernel with one QUERY per lane (dim = 8 * DC <= 128).  (q - x)^2 cannot go
+// through MFMA bit-exactly, so this is the VALU roofline: a lane keeps its whole query in
+// registers (DC * 4 packed pairs), a block of 4 waves (256 queries) shares 32-row tiles of
+// the database staged in LDS, and every row value is a wave-uniform LDS broadcast read.  Per
+// (row, 8 dims, 64 queries): 2 ds_read_b128 + 4 v_pk_add_f32 + 4 v_pk_fma_f32 -- the 8 AVX2
+// lane chains of simd/x86.rs:139-165 as 4 packed accumulators, combined by the same hsum tree.
+// (Feeding the rows through the scalar cache as SGPR operands instead was slower: a row needs
+// 128 SGPRs, so nothing can be prefetched while the previous row computes.)
+// =====================================================================================
+constexpr int kVqRows = 32;   // rows per LDS tile
+
+template <int MEASURE, int DC>
+__global__ __launch_bounds__(256, 2) void bf_vq_kernel(BfIndexDev ix, BfPass p, uint32_t nx) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int DIM = DC * 8;
+    constexpr int LD4 = kVqRows * DIM / 4 / 256;                  // float4 staged per thread
+    __shared__ __attribute__((aligned(16))) float tile[2][kVqRows * DIM];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t bx = blockIdx.x % nx, by = blockIdx.x / nx;
+    const uint32_t q = by * 256 + tid;
+    const bool qok = q < p.nq;
+    f32x2 qv[DC * 4];
+    {
+        const float *qrow = p.queries + (size_t)(qok ? q : 0) * p.q_stride;
+#pragma unroll
+        for (int i = 0; i < DC * 4; ++i) qv[i] = qok ? f32x2{qrow[2 * i], qrow[2 * i + 1]} : f32x2{0.0f, 0.0f};
+    }
+    uint64_t T = 0;
+    float Tf = 0.0f, Tpre = __builtin_inff();
+    if (p.filter && qok) {
+        T = p.thr[q];
+        Tf = bf_thr_float(T);
+        // L2: sqrt only for distances that can pass the bound (sqrt is monotone; the margin
+        // covers its rounding, the exact test on the rooted value follows in bf_emit)
+        Tpre = MEASURE == SCANN_HIP_L2 ? Tf * Tf * 1.000001f + 1e-30f : Tf;
+    }
+    const uint32_t ntiles = (p.nrows + kVqRows - 1) / kVqRows;
+    float4 stage[LD4];
+    auto fetch = [&](uint32_t t) {
+#pragma unroll
+        for (int i = 0; i < LD4; ++i) {
+            const uint32_t e = (tid + i * 256) * 4;              // float index inside the tile
+            const uint32_t r = e / DIM, j = e - r * DIM;
+            const uint32_t vrow = t * kVqRows + r;
+            stage[i] = vrow < p.nrows
+                           ? *reinterpret_cast<const float4 *>(ix.rows + (size_t)vrow * p.row_mult * ix.stride + j)
+                           : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    };
+    auto commit = [&](uint32_t buf) {
+#pragma unroll
+        for (int i = 0; i < LD4; ++i) *reinterpret_cast<float4 *>(&tile[buf][(tid + i * 256) * 4]) = stage[i];
+    };
+    uint32_t t = bx;
+    if (t < ntiles) {
+        fetch(t);
+        commit(0);
+    }
+    __syncthreads();
+    for (uint32_t it = 0; t < ntiles; t += nx, ++it) {
+        const uint32_t buf = it & 1u;
+        const bool more = t + nx < ntiles;
+        if (more) fetch(t + nx);                                  // in flight during the compute
+        const float *tl = tile[buf];
+        // one row at a time (a real loop: 4 packed accumulators live), its chunks software-
+        // pipelined one deep; sched_barrier pins the order so the scheduler cannot hoist all of a
+        // row's broadcast reads on top of the 128-VGPR resident query
+#pragma unroll 1
+        for (int r = 0; r < kVqRows; ++r) {
+            const float *xr = tl + r * DIM;                      // wave-uniform: LDS broadcast reads
+            f32x2 acc[4] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
+            float4 xa[2], xb[2];
+            xa[0] = *reinterpret_cast<const float4 *>(xr);
+            xb[0] = *reinterpret_cast<const float4 *>(xr + 4);
+#pragma unroll
+            for (int c = 0; c < DC; ++c) {
+                if (c + 1 < DC) {
+                    xa[(c + 1) & 1] = *reinterpret_cast<const float4 *>(xr + 8 * (c + 1));
+                    xb[(c + 1) & 1] = *reinterpret_cast<const float4 *>(xr + 8 * (c + 1) + 4);
+                }
+                const float4 ca = xa[c & 1], cb = xb[c & 1];
+                const f32x2 x[4] = {f32x2{ca.x, ca.y}, f32x2{ca.z, ca.w}, f32x2{cb.x, cb.y}, f32x2{cb.z, cb.w}};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 d = qv[4 * c + j] - x[j];
+                    acc[j] = __builtin_elementwise_fma(d, d, acc[j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // hsum tree (x86.rs:31-44): (a0+a4, a1+a5), (a2+a6, a3+a7) -> (s0+s1) + (s2+s3)
+            const f32x2 s01 = acc[0] + acc[2], s23 = acc[1] + acc[3];
+            const float v = (s01.x + s01.y) + (s23.x + s23.y);
+            const uint32_t vrow = t * kVqRows + r;
+            if (qok && vrow < p.nrows && (!p.filter || v <= Tpre)) {
+                const float dist = MEASURE == SCANN_HIP_L2 ? sqrtf(v) : v;
+                bf_emit(p, q, vrow, dist, Tf, T);
+            }
+        }
+        if (more) commit(buf ^ 1u);
+        __syncthreads();
+    }
+}
+
+// =====================================================================================
 // MFMA kernel: DotProduct, dim = 16 * TS (dim % 32 == 0).  Block = 4 waves; wave w owns
 // 32 queries (Q fragments resident in VGPRs); all waves share a 32-row X tile that is
 // DMA'd global -> LDS (global_load_lds_dwordx4, no VGPR staging), double-buffered.  The
@@ -550,6 +654,14 @@ static bool mfma_eligible(const BfIndexDev &ix) {
     }
 }
 
+// one-query-per-lane kernel: SquaredL2 / L2, dim in {32, 64, 96, 128}, enough queries to fill waves
+static bool vq_eligible(const BfIndexDev &ix, const BfPass &p) {
+    if (ix.measure != SCANN_HIP_SQUARED_L2 && ix.measure != SCANN_HIP_L2) return false;
+    if ((ix.stride & 3u) || (reinterpret_cast<uintptr_t>(ix.rows) & 15u)) return false;
+    if (ix.dim != 32 && ix.dim != 64 && ix.dim != 96 && ix.dim != 128) return false;
+    return p.nq >= 128;
+}
+
 static int launch_pass(const BfIndexDev &ix, const BfPass &p, hipStream_t st) {
     if (p.nq == 0 || p.nrows == 0) return SCANN_HIP_OK;
     if (mfma_eligible(ix)) {
@@ -561,6 +673,23 @@ static int launch_pass(const BfIndexDev &ix, const BfPass &p, hipStream_t st) {
             case 12: return launch_mfma<12>(ix, p, st);
             case 16: return launch_mfma<16>(ix, p, st);
         }
+    }
+    if (vq_eligible(ix, p)) {
+        const uint32_t ny = ceil_div_u32(p.nq, 256);
+        const uint32_t ntiles = ceil_div_u32(p.nrows, kVqRows);
+        const uint32_t nx = std::max(1u, std::min(ntiles, (2u * (uint32_t)num_cus() + ny - 1) / ny));
+#define SCANN_VQ(M, DCV)                                                                          \
+    hipLaunchKernelGGL((bf_vq_kernel<M, DCV>), dim3(nx * ny), dim3(256), 0, st, ix, p, nx)
+        const bool l2 = ix.measure == SCANN_HIP_L2;
+        switch (ix.dim / 8) {
+            case 4: if (l2) SCANN_VQ(SCANN_HIP_L2, 4); else SCANN_VQ(SCANN_HIP_SQUARED_L2, 4); break;
+            case 8: if (l2) SCANN_VQ(SCANN_HIP_L2, 8); else SCANN_VQ(SCANN_HIP_SQUARED_L2, 8); break;
+            case 12: if (l2) SCANN_VQ(SCANN_HIP_L2, 12); else SCANN_VQ(SCANN_HIP_SQUARED_L2, 12); break;
+            default: if (l2) SCANN_VQ(SCANN_HIP_L2, 16); else SCANN_VQ(SCANN_HIP_SQUARED_L2, 16); break;
+        }
+#undef SCANN_VQ
+        LAUNCH_CHECK();
+        return SCANN_HIP_OK;
     }
     const uint32_t dimp = (ix.dim + 3u) & ~3u;
     const size_t lds = (size_t)kBfGenQT * dimp * sizeof(float);

@@ -118,6 +118,14 @@ __device__ static inline uint32_t wave_prefix_count(bool pred, uint32_t *total) 
     return (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
+// Load through the constant address space: with a wave-uniform address the compiler emits
+// s_load (SMEM, SGPR result) instead of a vector load + v_readfirstlane.  Only for buffers
+// that no thread of the running kernel writes.
+template <typename T>
+__device__ __forceinline__ T uniform_load(const T *p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>((uint64_t)p);
+}
+
 constexpr uint32_t kSelBinsMax = 4096;   // histogram bins of block_select (large inputs)
 constexpr uint32_t kSelListMax = 1024;   // members of the rank's bin ranked exactly
 

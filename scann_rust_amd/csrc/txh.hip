@@ -535,14 +535,6 @@ __device__ __forceinline__ void scan_quad_dispatch(const float4 *lut_s, uint32_t
     }
 }
 
-// Load through the constant address space: with a wave-uniform address the compiler emits
-// s_load (SMEM, SGPR result) instead of a vector load + v_readfirstlane.  Only for buffers
-// that no thread of the running kernel writes.
-template <typename T>
-__device__ __forceinline__ T uniform_load(const T *p) {
-    return *reinterpret_cast<const __attribute__((address_space(4))) T *>((uint64_t)p);
-}
-
 // Next tile of this workgroup: XCD x (blockIdx % 8) owns tiles t = x (mod 8) in queue x and
 // steals from the other queues when its own is dry.  kInvalid = no tiles left.
 __device__ __forceinline__ uint32_t grab_tile(uint32_t *queues, uint32_t total_tiles) {
