@@ -12,8 +12,11 @@ already resident in HBM; value = queries/s of the whole job.
 
 One process per GPU.  N > 1 (launched by torch.distributed.run): the database is sharded
 across ranks (row ranges = leaves of a flat partition), every rank scans its shard for
-all queries, one RCCL all_gather moves (merge key, index, exact distance) triples of the
-per-rank best pre_reorder_k, and every rank merges (strong scaling: total work fixed).
+all queries, ONE RCCL all_to_all per step sends each peer the (merge key, index, exact distance)
+triples of the queries that peer merges (xGMI is point-to-point: 1/world of the all_gather volume
+per link), each rank merges its batch/world queries and the k result rows are all_gathered
+(strong scaling: total work fixed).  Steps are software-pipelined: a step's exchange overlaps
+the next step's local stage.
 
 The CPU oracle is used here ONLY as (a) the checker of a few result rows and (b) the
 cpu_baseline leg; the timed path is libscann_hip.so through its C ABI.
@@ -193,20 +196,29 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    def all_gather_start(dst, src):
-        """Enqueue the gather of this step's packed candidates; returns a handle for
-        all_gather_finish.  NCCL/RCCL: asynchronous on the process group's own stream, so the
-        next step's local stage overlaps the transfer."""
+    def all_to_all_start(dst, src):
+        """Enqueue the exchange of this step's destination blocks (one block per peer: xGMI is
+        point-to-point, every rank sends each peer only the candidates of the queries that peer
+        merges).  NCCL/RCCL: asynchronous on the process group's own stream, so the next step's
+        local stage overlaps the transfer."""
         if args.backend == "nccl":
-            return dist.all_gather_into_tensor(dst, src, async_op=True)
-        parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(world)]   # rehearsal path
-        dist.all_gather(parts, src.cpu())
-        dst.copy_(torch.stack(parts).to(dst.device))
+            return dist.all_to_all_single(dst.view(-1), src.view(-1), async_op=True)
+        h = torch.empty(src.numel(), dtype=src.dtype)            # rehearsal path: through host memory
+        dist.all_to_all_single(h, src.view(-1).cpu())
+        dst.view(-1).copy_(h.to(dst.device))
         return None
 
-    def all_gather_finish(work):
+    def wait_for(work):
         if work is not None:
             work.wait()   # the current stream waits for the collective; the host does not block
+
+    def all_gather(dst, src):
+        if args.backend == "nccl":
+            dist.all_gather_into_tensor(dst.view(-1), src.view(-1))
+        else:
+            parts = [torch.empty(src.numel(), dtype=src.dtype) for _ in range(world)]
+            dist.all_gather(parts, src.view(-1).cpu())
+            dst.view(-1).copy_(torch.cat(parts).to(dst.device))
 
     L = hip.load()
     n, dim, S, K, k, Q = args.n, args.dim, args.subspaces, args.num_codes, args.k, args.batch
@@ -324,29 +336,39 @@ def main():
         lopts.exact_reorder = opts.exact_reorder
         lopts.partitions_to_search = opts.partitions_to_search
         if world > 1:
-            # one packed per-rank buffer [keys u64 | idx u32 | exact f32 | count u32] -> ONE
-            # all_gather per step; the merge kernel walks ranks with a byte stride
-            kb, ib, cb = Q * m_local * 8, Q * m_local * 4, Q * 4
-            sec = [0, kb, kb + ib, kb + 2 * ib]
-            pack_bytes = (kb + 2 * ib + cb + 255) // 256 * 256
-            # double-buffered: step i+1's local stage runs while step i's gather is in flight
-            packs = [torch.zeros((pack_bytes,), dtype=torch.uint8, device=device) for _ in range(2)]
-            g_packs = [torch.zeros((world, pack_bytes), dtype=torch.uint8, device=device) for _ in range(2)]
+            if Q % world:
+                raise SystemExit("--batch must be a multiple of the number of ranks")
+            from scann_rust_amd import sharding as _sh
+            Qr = Q // world
+            # local stage output (SoA, [Q][m_local]) -> destination blocks -> ONE all_to_all per
+            # step -> merge of this rank's Qr queries -> all_gather of the k result rows (tiny)
+            kb, ib = Q * m_local * 8, Q * m_local * 4
+            soa = torch.zeros((kb + 2 * ib + Q * 4,), dtype=torch.uint8, device=device)
+            ssec = [0, kb, kb + ib, kb + 2 * ib]
+            bk, bi, be, bc, block_bytes = _sh.block_layout(Q, m_local, world)
+            bsec = [bk, bi, be, bc]
+            # double-buffered: step i+1's local stage runs while step i's exchange is in flight
+            sends = [torch.zeros((world, block_bytes), dtype=torch.uint8, device=device) for _ in range(2)]
+            recvs = [torch.zeros((world, block_bytes), dtype=torch.uint8, device=device) for _ in range(2)]
+            rb = Qr * k * 4
+            res_local = torch.zeros((2 * rb + Qr * 4,), dtype=torch.uint8, device=device)
+            res_all = torch.zeros((world, 2 * rb + Qr * 4), dtype=torch.uint8, device=device)
             mstatus = torch.zeros((1,), dtype=torch.int32, device=device)
             pending = []
 
-            def sect(t, i):
-                return ctypes.c_void_p(t.data_ptr() + sec[i])
+            def at(t, off):
+                return ctypes.c_void_p(t.data_ptr() + off)
 
             def finish_step():
                 work, b = pending.pop(0)
-                all_gather_finish(work)
-                g_pack = g_packs[b]
-                hip.check(L.scann_hip_txh_merge_device(hip.context(local_rank), world, Q, m_local, m,
-                                                       k, pack_bytes, sect(g_pack, 0), sect(g_pack, 1),
-                                                       sect(g_pack, 2), sect(g_pack, 3), dev_ptr(out_idx),
-                                                       dev_ptr(out_dist), dev_ptr(out_cnt),
+                wait_for(work)
+                rv = recvs[b]
+                hip.check(L.scann_hip_txh_merge_device(hip.context(local_rank), world, Qr, m_local, m,
+                                                       k, block_bytes, at(rv, bsec[0]), at(rv, bsec[1]),
+                                                       at(rv, bsec[2]), at(rv, bsec[3]), at(res_local, 0),
+                                                       at(res_local, rb), at(res_local, 2 * rb),
                                                        dev_ptr(mstatus), sptr))
+                all_gather(res_all, res_local)
         hip.check(L.scann_hip_index_reserve(index.h, Q, k, ctypes.byref(lopts)))
 
         def step(i):
@@ -356,15 +378,18 @@ def main():
                                                             ctypes.byref(lopts), dev_ptr(out_idx),
                                                             dev_ptr(out_dist), dev_ptr(out_cnt), sptr))
             else:
-                # software pipeline over steps: local stage(i) -> gather(i) in flight ->
-                # [merge(i-1)] ; the last merge is drained by flush_steps()
+                # software pipeline over steps: local stage(i) -> exchange(i) in flight ->
+                # [merge(i-1) + result gather]; the last merge is drained by flush_steps()
                 b = i & 1
-                pack = packs[b]
                 hip.check(L.scann_hip_txh_search_local_device(index.h, dev_ptr(qd), Q, dim, k,
-                                                              ctypes.byref(lopts), sect(pack, 0),
-                                                              sect(pack, 1), sect(pack, 2),
-                                                              sect(pack, 3), sptr))
-                work = all_gather_start(g_packs[b], pack)
+                                                              ctypes.byref(lopts), at(soa, ssec[0]),
+                                                              at(soa, ssec[1]), at(soa, ssec[2]),
+                                                              at(soa, ssec[3]), sptr))
+                hip.check(L.scann_hip_txh_pack_blocks_device(hip.context(local_rank), world, Q, m_local,
+                                                             at(soa, ssec[0]), at(soa, ssec[1]),
+                                                             at(soa, ssec[2]), at(soa, ssec[3]),
+                                                             dev_ptr(sends[b]), block_bytes, sptr))
+                work = all_to_all_start(recvs[b], sends[b])
                 if pending:
                     finish_step()
                 pending.append((work, b))
@@ -408,6 +433,13 @@ def main():
                 raise SystemExit("merge reported status %d" % int(t[1].item()))
         break
     qps = Q * args.steps / elapsed
+    if world > 1:   # result rows of the last step, gathered from the ranks that merged them
+        ra = res_all.cpu().numpy()
+        rb_ = (Q // world) * k * 4
+        out_idx = torch.from_numpy(np.concatenate([ra[g, :rb_].view(np.int32).reshape(-1, k)
+                                                   for g in range(world)]))
+        out_dist = torch.from_numpy(np.concatenate([ra[g, rb_:2 * rb_].view(np.float32).reshape(-1, k)
+                                                    for g in range(world)]))
 
     # ---------------- recall10@10 (bin/ann_benchmark.rs:427-471 semantics) ------------------
     recall = None
@@ -522,7 +554,7 @@ def main():
                        "partitions_to_search": args.partitions_to_search if args.workload == "txh" else None,
                        "recall10@10": recall,
                        "oracle_check": checked,
-                       "parallelism": "1 process/GPU, leaf(row-range)-sharded x%d + RCCL all_gather"
+                       "parallelism": "1 process/GPU, leaf(row-range)-sharded x%d + RCCL all_to_all of candidates"
                                       % world if world > 1 else "single GPU"},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -219,6 +219,18 @@ int scann_hip_txh_merge_device(scann_hip_ctx *ctx, uint32_t world, uint32_t nq, 
                                const uint32_t *d_idx, const float *d_exact,
                                const uint32_t *d_count, uint32_t *d_out_idx, float *d_out_dist,
                                uint32_t *d_out_count, uint32_t *d_status, void *hip_stream);
+/* Exchange by all_to_all instead of all_gather (xGMI is point-to-point: every rank sends each peer
+ * only the candidates of the queries that peer merges).  Repacks the local stage's arrays
+ * [nq][m_local] into `world` destination blocks, block d = the queries [d*nq/world, (d+1)*nq/world):
+ * [keys u64 | idx u32 | exact f32 | count u32], block_bytes apart (>= (nq/world)*(16*m_local + 4),
+ * multiple of 8).  After all_to_all_single (equal splits) a rank holds one block per source rank
+ * and calls scann_hip_txh_merge_device with nq/world queries and rank_stride_bytes = block_bytes.
+ * nq must be a multiple of world. */
+int scann_hip_txh_pack_blocks_device(scann_hip_ctx *ctx, uint32_t world, uint32_t nq, uint32_t m_local,
+                                     const uint64_t *d_keys, const uint32_t *d_idx, const float *d_exact,
+                                     const uint32_t *d_count, void *d_out, uint64_t block_bytes,
+                                     void *hip_stream);
+
 /* Greedy size-balanced leaf->rank assignment used by the harness (not in the reference). */
 int scann_hip_assign_leaves(const uint32_t *leaf_sizes, uint32_t num_partitions,
                             uint32_t world, uint32_t *out_owner);

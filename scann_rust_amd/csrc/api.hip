@@ -757,6 +757,18 @@ int scann_hip_txh_merge_device(scann_hip_ctx *ctx, uint32_t world, uint32_t nq, 
                             d_out_dist, d_out_count, d_status, static_cast<hipStream_t>(hip_stream));
 }
 
+int scann_hip_txh_pack_blocks_device(scann_hip_ctx *ctx, uint32_t world, uint32_t nq, uint32_t m_local,
+                                     const uint64_t *d_keys, const uint32_t *d_idx, const float *d_exact,
+                                     const uint32_t *d_count, void *d_out, uint64_t block_bytes,
+                                     void *hip_stream) {
+    if (!ctx) return fail(SCANN_HIP_INVALID_ARGUMENT, "ctx is null");
+    if (!d_keys || !d_idx || !d_exact || !d_count || !d_out)
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "null buffer");
+    SCANN_TRY(set_device(ctx));
+    return txh_launch_pack_blocks(world, nq, m_local, d_keys, d_idx, d_exact, d_count, d_out,
+                                  (size_t)block_bytes, static_cast<hipStream_t>(hip_stream));
+}
+
 int scann_hip_assign_leaves(const uint32_t *sizes, uint32_t L, uint32_t world, uint32_t *owner) {
     if (!sizes || !owner || world == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "bad arguments");
     std::vector<uint32_t> order(L);

@@ -162,6 +162,10 @@ int txh_launch_merge(uint32_t world, uint32_t nq, uint32_t m_local, uint32_t m, 
                      const uint32_t *d_count, uint32_t *d_out_idx, float *d_out_dist,
                      uint32_t *d_out_count, uint32_t *d_status, hipStream_t stream);
 
+int txh_launch_pack_blocks(uint32_t world, uint32_t nq, uint32_t m_local, const uint64_t *d_keys,
+                           const uint32_t *d_idx, const float *d_exact, const uint32_t *d_count,
+                           void *d_out, size_t block_bytes, hipStream_t stream);
+
 int txh_launch_lut_from_query(const TxhIndexDev &ix, const float *d_queries, uint32_t nq,
                               uint32_t q_stride, const uint32_t *d_leaf_for_query,
                               float *d_out_lut, hipStream_t stream);

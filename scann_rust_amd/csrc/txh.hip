@@ -1773,6 +1773,48 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
     return SCANN_HIP_OK;
 }
 
+// Per-destination blocks for the all_to_all exchange: rank d merges the queries
+// [d * nq/world, (d+1) * nq/world), so it needs exactly those rows of every rank's candidate
+// arrays.  Block d = [keys u64 Qr*m | idx u32 Qr*m | exact f32 Qr*m | count u32 Qr], blocks
+// block_bytes apart -- the layout txh_merge_device reads with rank_stride_bytes = block_bytes.
+__global__ void pack_blocks_kernel(uint32_t world, uint32_t nq, uint32_t m,
+                                   const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx,
+                                   const float *__restrict__ exact, const uint32_t *__restrict__ count,
+                                   unsigned char *__restrict__ out, size_t block_bytes) {
+    const uint32_t qr = nq / world;
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (uint64_t)nq * m) {
+        const uint32_t q = (uint32_t)(e / m), i = (uint32_t)(e - (uint64_t)q * m);
+        const uint32_t d = q / qr, ql = q - d * qr;
+        unsigned char *blk = out + (size_t)d * block_bytes;
+        const size_t slot = (size_t)ql * m + i, per = (size_t)qr * m;
+        reinterpret_cast<uint64_t *>(blk)[slot] = keys[e];
+        reinterpret_cast<uint32_t *>(blk + per * 8)[slot] = idx[e];
+        reinterpret_cast<float *>(blk + per * 12)[slot] = exact[e];
+    }
+    if (e < nq) {
+        const uint32_t q = (uint32_t)e, d = q / qr, ql = q - d * qr;
+        reinterpret_cast<uint32_t *>(out + (size_t)d * block_bytes + (size_t)qr * m * 16)[ql] = count[q];
+    }
+}
+
+int txh_launch_pack_blocks(uint32_t world, uint32_t nq, uint32_t m_local, const uint64_t *d_keys,
+                           const uint32_t *d_idx, const float *d_exact, const uint32_t *d_count,
+                           void *d_out, size_t block_bytes, hipStream_t st) {
+    if (nq == 0) return SCANN_HIP_OK;
+    if (world == 0 || nq % world != 0)
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "the batch must divide evenly over the ranks");
+    const size_t need = (size_t)(nq / world) * m_local * 16 + (size_t)(nq / world) * 4;
+    if (block_bytes < need || (block_bytes & 7u))
+        return fail(SCANN_HIP_INVALID_ARGUMENT, "block_bytes too small or not a multiple of 8");
+    const uint64_t work = std::max<uint64_t>((uint64_t)nq * m_local, nq);
+    hipLaunchKernelGGL(pack_blocks_kernel, dim3((uint32_t)ceil_div_u64(work, 256)), dim3(256), 0, st, world, nq,
+                       m_local, d_keys, d_idx, d_exact, d_count, static_cast<unsigned char *>(d_out),
+                       block_bytes);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
 int txh_launch_merge(uint32_t world, uint32_t nq, uint32_t m_local, uint32_t m, uint32_t k,
                      size_t rank_stride_bytes, const uint64_t *d_keys, const uint32_t *d_idx,
                      const float *d_exact, const uint32_t *d_count, uint32_t *d_out_idx,

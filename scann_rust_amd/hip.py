@@ -32,7 +32,7 @@ EXPORTS = [
     "scann_hip_assign_leaves", "scann_hip_txh_partition", "scann_hip_lut_from_query",
     "scann_hip_adc_distances", "scann_hip_lut16_distances_batch", "scann_hip_encode",
     "scann_hip_bf_distances", "scann_hip_bf_search_radius", "scann_hip_bf_assign_nearest",
-    "scann_hip_kmeans_init_pp", "scann_hip_kmeans_lloyd", "scann_hip_index_size", "scann_hip_index_dimensionality",
+    "scann_hip_kmeans_init_pp", "scann_hip_kmeans_lloyd", "scann_hip_txh_pack_blocks_device", "scann_hip_index_size", "scann_hip_index_dimensionality",
     "scann_hip_index_destroy", "scann_hip_index_enable_timing",
     "scann_hip_index_last_kernel_ms",
 ]
@@ -123,6 +123,8 @@ def load():
                                    C.c_uint64, C.c_uint32, f32p, u32p, u8p]
     L.scann_hip_bf_distances.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, f32p]
     L.scann_hip_bf_assign_nearest.argtypes = [vp, f32p, C.c_uint32, u32p, f32p]
+    L.scann_hip_txh_pack_blocks_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp,
+                                                   C.c_uint64, vp]
     L.scann_hip_kmeans_init_pp.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, f32p]
     L.scann_hip_kmeans_lloyd.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, C.c_uint32, C.c_uint32,
                                          C.c_double, u32p, u32p, C.POINTER(C.c_double), u32p,

@@ -65,3 +65,39 @@ def merge_reference(keys, idx, exact, counts, m, k):
         out_idx[q, :o2.size] = ii[o2]
         out_dist[q, :o2.size] = ee[o2]
     return out_idx, out_dist, out_cnt
+
+
+def block_layout(nq, m_local, world):
+    """Byte offsets inside one destination block of the all_to_all exchange
+    (scann_hip_txh_pack_blocks_device): (keys, idx, exact, count, block_bytes) for nq/world queries."""
+    qr = nq // world
+    per = qr * m_local
+    need = per * 16 + qr * 4
+    return 0, per * 8, per * 12, per * 16, (need + 255) // 256 * 256
+
+
+def pack_blocks_reference(keys, idx, exact, counts, world):
+    """Numpy statement of scann_hip_txh_pack_blocks_device: uint8 array [world][block_bytes]."""
+    nq, m = keys.shape
+    qr = nq // world
+    ok, oi, oe, oc, bb = block_layout(nq, m, world)
+    out = np.zeros((world, bb), np.uint8)
+    for d in range(world):
+        sl = slice(d * qr, (d + 1) * qr)
+        out[d, ok:oi] = np.ascontiguousarray(keys[sl]).view(np.uint8).reshape(-1)
+        out[d, oi:oe] = np.ascontiguousarray(idx[sl]).view(np.uint8).reshape(-1)
+        out[d, oe:oc] = np.ascontiguousarray(exact[sl]).view(np.uint8).reshape(-1)
+        out[d, oc:oc + qr * 4] = np.ascontiguousarray(counts[sl]).view(np.uint8).reshape(-1)
+    return out
+
+
+def unpack_blocks(buf, nq, m_local, world):
+    """Views (keys, idx, exact, counts) [world][nq/world][...] of a received [world][block_bytes] buffer."""
+    qr = nq // world
+    ok, oi, oe, oc, bb = block_layout(nq, m_local, world)
+    buf = np.ascontiguousarray(buf).reshape(world, bb)
+    keys = np.stack([buf[g, ok:oi].view(np.uint64).reshape(qr, m_local) for g in range(world)])
+    idx = np.stack([buf[g, oi:oe].view(np.uint32).reshape(qr, m_local) for g in range(world)])
+    exact = np.stack([buf[g, oe:oc].view(np.float32).reshape(qr, m_local) for g in range(world)])
+    cnt = np.stack([buf[g, oc:oc + qr * 4].view(np.uint32) for g in range(world)])
+    return keys, idx, exact, cnt

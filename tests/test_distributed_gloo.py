@@ -128,3 +128,60 @@ def test_assign_leaves_matches_c_abi():
     sizes = rng.integers(0, 500, 97).astype(np.uint32)
     for world in (1, 2, 3, 8):
         assert np.array_equal(sharding.assign_leaves(sizes, world), hip.assign_leaves(sizes, world))
+
+
+def _worker_a2a(rank, world, port, ret):
+    """The bench's exchange: destination blocks -> all_to_all_single -> merge of the rank's own
+    NQ/world queries -> all_gather of the result rows."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pyoracle as orc
+        from scann_rust_amd import sharding, synth, trainer
+        rows = synth.uniform_f32(N, DIM, 11)
+        queries = synth.uniform_f32(NQ, DIM, 12)
+        data, stride = orc.to_strided(rows)
+        ix = trainer.build_txh_index(rows, L, S, seed=3, kmeans_iters=3, pq_iters=3)
+        kw = sharding.shard_txh_index(ix, data, stride, rank, world)
+        tokens = np.stack([orc.partition(ix["centers"], q, P)[0] for q in queries]).astype(np.int64)
+        keys, idx, exact, cnt = _local_stage(kw, ix, queries, tokens)
+        send = sharding.pack_blocks_reference(keys.view(np.uint64), idx.view(np.uint32), exact,
+                                              cnt.view(np.uint32), world)
+        recv = torch.empty(send.size, dtype=torch.uint8)
+        dist.all_to_all_single(recv, torch.from_numpy(send.reshape(-1)))
+        gk, gi, ge, gc = sharding.unpack_blocks(recv.numpy(), NQ, M, world)
+        oi, od, oc = sharding.merge_reference(gk, gi, ge, gc, M, K)      # my NQ/world queries
+        qr = NQ // world
+        res = torch.from_numpy(np.concatenate([oi.view(np.uint8).reshape(-1), od.view(np.uint8).reshape(-1),
+                                               oc.view(np.uint8).reshape(-1)]))
+        parts = [torch.empty_like(res) for _ in range(world)]
+        dist.all_gather(parts, res)
+        rb = qr * K * 4
+        all_i = np.concatenate([p.numpy()[:rb].view(np.uint32).reshape(qr, K) for p in parts])
+        all_d = np.concatenate([p.numpy()[rb:2 * rb].view(np.float32).reshape(qr, K) for p in parts])
+        all_c = np.concatenate([p.numpy()[2 * rb:].view(np.uint32) for p in parts])
+        oix = orc.TxhIndex(data, stride, DIM, ix["centers"], ix["leaf_off"], ix["leaf_ids"],
+                           ix["codebook"], ix["codes"], partitions_to_search=P,
+                           pre_reorder_multiplier=M / K)
+        ok = True
+        for q in range(NQ):
+            wi, wd = orc.txh_search(oix, queries[q], K)
+            ok = ok and all_c[q] == wi.size and np.array_equal(all_i[q, :wi.size], wi) \
+                and np.array_equal(all_d[q, :wi.size].view(np.uint32), wd.view(np.uint32))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_all_to_all_exchange_matches_single_process(world):
+    assert NQ % world == 0
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_a2a, args=(r, world, port, ret)) for r in range(world)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert all(ret.get(r) for r in range(world)), dict(ret)

@@ -585,3 +585,32 @@ def test_kmeans_init_pp_spreads_seeds():
     # D^2 sampling lands in (almost) every well-separated cluster
     owner = [int(labels[np.flatnonzero((rows == r).all(1))[0]]) for r in a]
     assert len(set(owner)) >= 16
+
+
+def test_pack_blocks_matches_reference():
+    """scann_hip_txh_pack_blocks_device == sharding.pack_blocks_reference (the all_to_all layout)."""
+    import ctypes
+    import torch
+    from scann_rust_amd import sharding
+    world, nq, m = 4, 24, 37
+    rng = np.random.default_rng(5)
+    keys = rng.integers(0, 2 ** 63, size=(nq, m), dtype=np.uint64)
+    idx = rng.integers(0, 2 ** 32, size=(nq, m), dtype=np.uint32)
+    exact = rng.random((nq, m), dtype=np.float32)
+    cnt = rng.integers(0, m + 1, size=nq, dtype=np.uint32)
+    want = sharding.pack_blocks_reference(keys, idx, exact, cnt, world)
+    bb = want.shape[1]
+    dev = torch.device("cuda", 0)
+    tk, ti, te, tc = (torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(dev) for a in (keys, idx, exact, cnt))
+    out = torch.zeros((world, bb), dtype=torch.uint8, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    hip.check(hip.load().scann_hip_txh_pack_blocks_device(hip.context(0), world, nq, m, p(tk), p(ti), p(te), p(tc),
+                                                          p(out), bb, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    _, _, _, oc, _ = sharding.block_layout(nq, m, world)
+    used = oc + (nq // world) * 4
+    assert np.array_equal(got[:, :used], want[:, :used])
+    with pytest.raises(hip.ScannError):
+        hip.check(hip.load().scann_hip_txh_pack_blocks_device(hip.context(0), 5, nq, m, p(tk), p(ti), p(te), p(tc),
+                                                              p(out), bb, None))
