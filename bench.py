@@ -212,13 +212,14 @@ def main():
         if work is not None:
             work.wait()   # the current stream waits for the collective; the host does not block
 
-    def all_gather(dst, src):
+    def all_gather_start(dst, src):
         if args.backend == "nccl":
-            dist.all_gather_into_tensor(dst.view(-1), src.view(-1))
+            return dist.all_gather_into_tensor(dst.view(-1), src.view(-1), async_op=True)
         else:
             parts = [torch.empty(src.numel(), dtype=src.dtype) for _ in range(world)]
             dist.all_gather(parts, src.view(-1).cpu())
             dst.view(-1).copy_(torch.cat(parts).to(dst.device))
+            return None
 
     L = hip.load()
     n, dim, S, K, k, Q = args.n, args.dim, args.subspaces, args.num_codes, args.k, args.batch
@@ -351,10 +352,13 @@ def main():
             sends = [torch.zeros((world, block_bytes), dtype=torch.uint8, device=device) for _ in range(2)]
             recvs = [torch.zeros((world, block_bytes), dtype=torch.uint8, device=device) for _ in range(2)]
             rb = Qr * k * 4
-            res_local = torch.zeros((2 * rb + Qr * 4,), dtype=torch.uint8, device=device)
-            res_all = torch.zeros((world, 2 * rb + Qr * 4), dtype=torch.uint8, device=device)
+            res_locals = [torch.zeros((2 * rb + Qr * 4,), dtype=torch.uint8, device=device) for _ in range(2)]
+            res_alls = [torch.zeros((world, 2 * rb + Qr * 4), dtype=torch.uint8, device=device)
+                        for _ in range(2)]
+            res_work = [None, None]   # result gathers in flight (waited for one step later)
             mstatus = torch.zeros((1,), dtype=torch.int32, device=device)
             pending = []
+            last_res = [0]
 
             def at(t, off):
                 return ctypes.c_void_p(t.data_ptr() + off)
@@ -362,13 +366,15 @@ def main():
             def finish_step():
                 work, b = pending.pop(0)
                 wait_for(work)
-                rv = recvs[b]
+                rv, res_local = recvs[b], res_locals[b]
+                wait_for(res_work[b])          # the gather that last read res_locals[b]
                 hip.check(L.scann_hip_txh_merge_device(hip.context(local_rank), world, Qr, m_local, m,
                                                        k, block_bytes, at(rv, bsec[0]), at(rv, bsec[1]),
                                                        at(rv, bsec[2]), at(rv, bsec[3]), at(res_local, 0),
                                                        at(res_local, rb), at(res_local, 2 * rb),
                                                        dev_ptr(mstatus), sptr))
-                all_gather(res_all, res_local)
+                res_work[b] = all_gather_start(res_alls[b], res_local)
+                last_res[0] = b
         hip.check(L.scann_hip_index_reserve(index.h, Q, k, ctypes.byref(lopts)))
 
         def step(i):
@@ -397,6 +403,9 @@ def main():
         def flush_steps():
             while world > 1 and pending:
                 finish_step()
+            if world > 1:
+                for wk in res_work:
+                    wait_for(wk)
 
         # ---------------- warmup, then EXACTLY K timed steps -------------------------------
         for i in range(args.warmup):
@@ -434,7 +443,7 @@ def main():
         break
     qps = Q * args.steps / elapsed
     if world > 1:   # result rows of the last step, gathered from the ranks that merged them
-        ra = res_all.cpu().numpy()
+        ra = res_alls[last_res[0]].cpu().numpy()
         rb_ = (Q // world) * k * 4
         out_idx = torch.from_numpy(np.concatenate([ra[g, :rb_].view(np.int32).reshape(-1, k)
                                                    for g in range(world)]))
