@@ -80,10 +80,13 @@ def test_ah_lut16_1m_properties_and_oracle(big):
     assert prev > 0.9
 
 
-@pytest.mark.parametrize("measure", [hip.DOT_PRODUCT, hip.SQUARED_L2])
-def test_brute_force_1m_properties_and_oracle(big, measure):
+@pytest.mark.parametrize("measure,nq", [(hip.DOT_PRODUCT, 40), (hip.SQUARED_L2, 40), (hip.SQUARED_L2, 300),
+                                        (hip.L2, 300)])
+def test_brute_force_1m_properties_and_oracle(big, measure, nq):
+    """nq = 40 runs the generic row-per-thread kernel (MFMA kernel for DotProduct), nq = 300 the
+    one-query-per-lane kernel."""
     index = hip.bf_create(big["data"], N, DIM, big["stride"], measure)
-    q = big["q"][:40]
+    q = synth.uniform_f32(nq, DIM, 123)
     idx, dist, cnt = index.search_batched(q, K)
     assert np.all(cnt == K) and np.all(np.diff(dist, axis=1) >= 0)
     # oracle on 2 full queries (TopK over all 1M rows)
@@ -101,3 +104,46 @@ def test_brute_force_1m_properties_and_oracle(big, measure):
     # batch-split invariance
     a, b, _ = index.search_batched(q[:5], K)
     assert np.array_equal(a, idx[:5]) and np.array_equal(b.view(np.uint32), dist[:5].view(np.uint32))
+
+
+def test_txh_1m_gpu_build_and_oracle():
+    """Tree-X-Hybrid at 1M x 128 with the index built by the library's GPU k-means (partitioner +
+    per-subspace codebook on residuals + residual encode), searched on the GPU and checked stage
+    by stage against the oracle on a few queries (the oracle scans only the selected leaves)."""
+    n, dim, L, S, P, m, k = 1_000_000, 128, 1000, 32, 10, 300, 10
+    rows, _ = synth.clustered_f32(n, dim, 7, n_clusters=1000)
+    stride = hip.compute_stride(dim)
+    data = np.ascontiguousarray(rows)
+    bf = hip.bf_create(data, n, dim, stride, hip.SQUARED_L2)
+    centers, assign, sizes, _, iters, _ = hip.kmeans_lloyd(bf, hip.kmeans_init_pp(bf, L, seed=42),
+                                                            max_iterations=10)
+    bf.close()
+    assert sizes.sum() == n and iters >= 1
+    order = np.argsort(assign, kind="stable").astype(np.uint32)
+    leaf_off = np.zeros(L + 1, np.uint32)
+    leaf_off[1:] = np.cumsum(sizes)
+    resid = rows[order] - centers[assign[order]]
+    sub = np.ascontiguousarray(resid[:: n // 131072])
+    rbf = hip.bf_create(sub, sub.shape[0], dim, stride, hip.SQUARED_L2)
+    dsub = dim // S
+    cb = np.stack([hip.kmeans_lloyd(rbf, hip.kmeans_init_pp(rbf, 16, seed=42 + s, col_offset=s * dsub,
+                                                            sub_dim=dsub),
+                                    max_iterations=10, col_offset=s * dsub)[0] for s in range(S)])
+    rbf.close()
+    codes = hip.encode(cb, np.ascontiguousarray(resid), stride=stride)
+    assert np.array_equal(codes[::9973], orc.encode_many(cb, resid[::9973]))
+    index = hip.txh_create(data=data, n_rows=n, dim=dim, stride=stride, centers=centers,
+                           leaf_offsets=leaf_off, leaf_ids=order, codebook=cb, codes=codes,
+                           use_residuals=True, partitions_to_search=P, pre_reorder_multiplier=m / k)
+    q, _ = synth.clustered_f32(256, dim, 8, n_clusters=1000)
+    o = hip.default_opts()
+    o.partitions_to_search, o.pre_reorder_k = P, m
+    idx, dist, cnt, (tok, tokd, ci, cd, cc) = index.search_batched(q, k, o, stages=True)
+    assert np.all(cnt == k) and np.all(np.diff(dist, axis=1) >= 0)
+    oix = orc.TxhIndex(data, stride, dim, centers, leaf_off, order, cb, codes, use_residuals=True,
+                       partitions_to_search=P, pre_reorder_multiplier=m / k)
+    for i in range(0, 256, 16):
+        H.check_txh_query(oix, q[i], k, idx[i, :cnt[i]], dist[i, :cnt[i]], tok[i], tokd[i],
+                          ci[i, :cc[i]], cd[i, :cc[i]], what="q%d" % i)
+    a, b, _ = index.search_batched(q[:7], k, o)      # batch-split invariance
+    assert np.array_equal(b.view(np.uint32), dist[:7].view(np.uint32))
