@@ -487,6 +487,18 @@ static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallP
         while (sq > 8 && all_chunks * ((quads_per_leaf + sq - 1) / sq) < 6144) sq >>= 1;
         w->qpt = sq;
         if (const char *e = std::getenv("SCANN_HIP_QPT")) w->qpt = (uint32_t)std::max(1, std::atoi(e));
+        // long leaves scanned by many queries (AsymmetricHasher mode, few big partitions): tables
+        // resident in LDS over a range of chunks (adc_scan_res_kernel); needs 4-bit codes with
+        // S <= 32.  With few quads per leaf (typical Tree-X-Hybrid batches: measured at 10M / 1000
+        // leaves) the per-chunk kernel is as fast or faster.
+        const uint64_t rtp = (uint64_t)kResThreads * kScanPPT;
+        const uint64_t res_chunks_per_leaf = std::max<uint64_t>(1, (t.n_local / std::max(1u, L)) / rtp);
+        w->resident = (t.code_bits == 4 && t.S <= 32 && res_chunks_per_leaf >= 4 && quads_per_leaf >= 32) ? 1u : 0u;
+        if (const char *e = std::getenv("SCANN_HIP_RESIDENT")) w->resident = std::atoi(e) ? w->resident : 0u;
+        const uint64_t qgroups = std::max<uint64_t>(1, (quads_per_leaf + kResQuads - 1) / kResQuads);
+        const uint64_t units = (t.n_local / rtp + L) * qgroups;       // (chunk, quad group) pairs
+        w->res_cl = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, units / 4096));
+        if (const char *e = std::getenv("SCANN_HIP_RES_CL")) w->res_cl = (uint32_t)std::max(1, std::atoi(e));
     }
     w->sbase = s.sbase.as<uint32_t>();
     w->pair_sbase = s.pair_sbase.as<uint32_t>();

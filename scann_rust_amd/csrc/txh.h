@@ -6,7 +6,10 @@ namespace scann {
 
 // Tunables of the scan decomposition (see DESIGN.md "Leaf scan").
 constexpr uint32_t kScanThreads = 256;
-constexpr uint32_t kScanPPT = 2;                          // points per thread per chunk
+#ifndef SCANN_SCAN_PPT
+#define SCANN_SCAN_PPT 2
+#endif
+constexpr uint32_t kScanPPT = SCANN_SCAN_PPT;              // points per thread per chunk
 constexpr uint32_t kScanTP = kScanThreads * kScanPPT;     // points per tile chunk
 constexpr uint32_t kScanQuadsPerTile = 32;                // query quads per tile
 #ifndef SCANN_SCAN_DEPTH
@@ -17,6 +20,8 @@ constexpr uint32_t kScanQuadsPerTile = 32;                // query quads per til
 #endif
 constexpr uint32_t kScanDepth = SCANN_SCAN_DEPTH;         // gather software-pipeline depth (subspaces)
 constexpr uint32_t kScanWaves = SCANN_SCAN_WAVES;         // workgroups per CU = waves per SIMD (S <= 32)
+constexpr uint32_t kResThreads = 512;                     // resident-table scan: threads per workgroup
+constexpr uint32_t kResQuads = 4;                         // ... quads whose tables stay in LDS
 constexpr uint32_t kSortCap = 16384;                      // u64 keys sorted in LDS (select)
 #ifndef SCANN_SAMPLE_TARGET
 #define SCANN_SAMPLE_TARGET 32768
@@ -120,6 +125,7 @@ struct TxhWork {
     uint32_t *vbase;           // [nq][P+1] prefix of global leaf sizes in token order
     uint32_t st, scap, sqpt;   // sample stride, per-query sample capacity, quads per sample tile
     uint32_t qpt;              // quads per scan tile
+    uint32_t resident, res_cl; // resident-table scan kernel (long leaves) and its chunks per tile
     uint32_t *sbase;           // [nq][P+2] prefix of per-leaf sample counts; [P]=samples, [P+1]=local points
     uint32_t *pair_sbase;      // [max_slots]
     uint32_t *stile_off;       // [L+1] tile table of the sample pass

@@ -231,7 +231,8 @@ __global__ void worklist_count_kernel(uint32_t npairs, int ah, const uint32_t *_
 
 __global__ __launch_bounds__(1024) void worklist_scan_kernel(
     uint32_t L, const uint32_t *__restrict__ leaf_cnt, const uint32_t *__restrict__ leaf_off,
-    uint32_t tp, uint32_t quads_per_tile, uint32_t st, uint32_t squads_per_tile,
+    uint32_t tp, uint32_t quads_per_tile, uint32_t chunks_per_tile, uint32_t stp, uint32_t st,
+    uint32_t squads_per_tile,
     uint32_t *__restrict__ pair_off, uint32_t *__restrict__ tile_off,
     uint32_t *__restrict__ stile_off, uint32_t *__restrict__ counters) {
     __shared__ uint32_t s_pairs[1024], s_tiles[1024], s_stiles[1024];
@@ -242,8 +243,9 @@ __global__ __launch_bounds__(1024) void worklist_scan_kernel(
     auto tiles_of = [&](uint32_t c, uint32_t pad, uint32_t sz, uint32_t *smp) {
         if (!c) { *smp = 0; return 0u; }
         const uint32_t ssz = (sz + st - 1) / st;
-        *smp = ((ssz + tp - 1) / tp) * ((pad / 4 + squads_per_tile - 1) / squads_per_tile);
-        return ((sz + tp - 1) / tp) * ((pad / 4 + quads_per_tile - 1) / quads_per_tile);
+        *smp = ((ssz + stp - 1) / stp) * ((pad / 4 + squads_per_tile - 1) / squads_per_tile);
+        const uint32_t nch = (sz + tp - 1) / tp;
+        return ((nch + chunks_per_tile - 1) / chunks_per_tile) * ((pad / 4 + quads_per_tile - 1) / quads_per_tile);
     };
     uint32_t sp = 0, stl = 0, sst = 0;
     for (uint32_t l = b; l < e; ++l) {
@@ -550,7 +552,10 @@ __device__ __forceinline__ uint32_t grab_tile(uint32_t *queues, uint32_t total_t
     return kInvalid;
 }
 
-constexpr uint32_t kScanStage = 128;   // LDS-staged survivors per (quad, query); <= kScanThreads
+#ifndef SCANN_SCAN_STAGE
+#define SCANN_SCAN_STAGE 128
+#endif
+constexpr uint32_t kScanStage = SCANN_SCAN_STAGE;   // LDS-staged survivors per (quad, query); <= kScanThreads
 static_assert(kScanStage <= kScanThreads, "the flush copies one survivor per thread");
 
 struct ScanArgs {
@@ -562,6 +567,7 @@ struct ScanArgs {
     uint64_t *cand;
     uint32_t cap;
     uint32_t qpt;            // query quads per tile
+    uint32_t res_cl;         // resident-table kernel: chunks per tile
     const uint64_t *allow;   // optional allow-bitmap (device), bit = datapoint index
     uint64_t allow_bits;
 };
@@ -743,6 +749,181 @@ __global__ __launch_bounds__(kScanThreads, C::WGS) void adc_scan_kernel(TxhIndex
                 }
             }
             __syncthreads();
+        }
+    }
+}
+
+// =====================================================================================
+// K6b: ADC scan with RESIDENT tables, for long leaves (AsymmetricHasher mode, big partitions).
+//
+// adc_scan_kernel above re-stages a quad's table for every 512-point chunk and synchronises
+// the workgroup twice per quad.  Here a tile = (leaf, kResQuads quads, a RANGE of chunks): the
+// quads' tables are loaded into LDS once per tile and stay read-only while the workgroup (8
+// waves) walks the chunk range, so the steady state has NO workgroup barrier and no table
+// traffic: waves drift freely and the LDS gather and the VALU adds of different waves overlap.
+// Survivors are staged per WAVE (kResStage slots per (wave, query), double-buffered by chunk):
+// the wave reserves global slots for chunk c-1's survivors with one returning atomic per query
+// issued BEFORE chunk c's gather and writes them out after it, so the atomic's latency hides
+// under the compute.  Arithmetic, keys and the filter are those of adc_scan_kernel.
+// =====================================================================================
+constexpr uint32_t kResStage = 8;      // staged survivors per (wave, query, chunk)
+
+template <typename C>
+__host__ __device__ constexpr size_t res_lds_bytes() {
+    return (size_t)kResQuads * C::LUT4 * 16 + (size_t)(kResThreads / 64) * 2 * kResQuads * 4 * kResStage * 8 +
+           (size_t)(kResThreads / 64) * 2 * kResQuads * 4 * 4 + kResQuads * 4 * 4 + 16;
+}
+
+template <typename C>
+__global__ __launch_bounds__(kResThreads, 6) void adc_scan_res_kernel(TxhIndexDev ix, ScanArgs a) {
+    static_assert(C::PPT == 2, "resident-table scan: 2 points per thread");
+    constexpr int LUT4 = C::LUT4;
+    constexpr int NQS = kResQuads * 4;                                   // resident (query, leaf) pairs
+    constexpr int NWV = kResThreads / 64;
+    constexpr uint32_t TPR = kResThreads * C::PPT;                       // points per chunk
+    extern __shared__ __attribute__((aligned(16))) float4 lut_s[];       // [kResQuads * LUT4]
+    uint64_t (*skey)[2][NQS][kResStage] =
+        reinterpret_cast<uint64_t (*)[2][NQS][kResStage]>(lut_s + kResQuads * LUT4);   // [NWV]
+    uint32_t (*scnt)[2][NQS] = reinterpret_cast<uint32_t (*)[2][NQS]>(skey + NWV);      // [NWV]
+    uint32_t *sq = reinterpret_cast<uint32_t *>(scnt + NWV);                             // [NQS] query ids
+    uint32_t &tile_sh = sq[NQS];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t total_tiles = a.counters[CNT_TOTAL_TILES];
+
+    for (;;) {
+        __syncthreads();                       // the previous tile's table reads are done
+        if (tid == 0) tile_sh = grab_tile(a.counters + CNT_XQ, total_tiles);
+        __syncthreads();
+        const uint32_t tile = __builtin_amdgcn_readfirstlane(tile_sh);
+        if (tile == kInvalid) break;
+
+        uint32_t lo = 0, hi = ix.L;            // leaf = largest l with tile_off[l] <= tile
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (uniform_load(a.tile_off + mid) <= tile) lo = mid; else hi = mid;
+        }
+        const uint32_t leaf = lo;
+        const uint32_t lb = uniform_load(ix.leaf_off + leaf);
+        const uint32_t size = uniform_load(ix.leaf_off + leaf + 1) - lb;
+        const uint32_t nchunks = (size + TPR - 1) / TPR;
+        const uint32_t nranges = (nchunks + a.res_cl - 1) / a.res_cl;
+        const uint32_t local = tile - uniform_load(a.tile_off + leaf);
+        const uint32_t range = local % nranges, qg = local / nranges;
+        const uint32_t slot0 = uniform_load(a.pair_off + leaf);
+        const uint32_t nquads = (uniform_load(a.pair_off + leaf + 1) - slot0) >> 2;
+        const uint32_t q0 = qg * kResQuads;
+        const uint32_t nq_t = min(kResQuads, nquads - q0);       // resident quads of this tile
+        const uint32_t c_begin = range * a.res_cl, c_end = min(nchunks, c_begin + a.res_cl);
+
+        // tables of the tile's quads -> LDS (LDS-DMA, destination = wave-uniform base + lane * 16)
+        {
+            const float4 *gl = reinterpret_cast<const float4 *>(a.lutq) + (size_t)((slot0 >> 2) + q0) * LUT4;
+            const uint32_t n4 = nq_t * LUT4;
+            for (uint32_t e0 = (tid & ~63u); e0 < n4; e0 += kResThreads)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(gl + e0 + lane),
+                    (__attribute__((address_space(3))) void *)(&lut_s[e0]), 16, 0, 0);
+        }
+        if (tid < (uint32_t)NQS) sq[tid] = tid < nq_t * 4 ? a.pair_q[slot0 + q0 * 4 + tid] : kInvalid;
+        if (lane < (uint32_t)NQS) {
+            scnt[wave][0][lane] = 0;
+            scnt[wave][1][lane] = 0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // this lane's slot of the wave-level flush: pair j = lane (lanes 0 .. NQS-1)
+        const uint32_t my_q = lane < (uint32_t)NQS ? sq[lane] : kInvalid;
+        uint32_t raw[C::PPT][C::NWORDS];
+        auto fetch_codes = [&](uint32_t c) {
+#pragma unroll
+            for (int i = 0; i < C::PPT; ++i) {
+                const uint32_t j = c * TPR + tid + kResThreads * i;
+                C::load_words(ix.codes + (size_t)(lb + (j < size ? j : 0)) * C::NWORDS, raw[i]);
+            }
+        };
+        fetch_codes(c_begin);
+        for (uint32_t c = c_begin; c <= c_end; ++c) {      // one extra trip flushes the last chunk
+            const uint32_t buf = (c - c_begin) & 1u;
+            const bool live = c < c_end;
+            const bool flush = c > c_begin;                // stage buf^1 holds chunk c-1's survivors
+            uint32_t regs[C::PPT][C::REGS];
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < C::PPT; ++i) C::unpack(raw[i], regs[i]);
+                if (c + 1 < c_end) fetch_codes(c + 1);     // in flight during this chunk's gathers
+            }
+            // A. reserve global slots for the previous chunk's survivors (result used in C)
+            uint32_t fcnt = 0, fbase = 0;
+            if (flush && my_q != kInvalid) {
+                fcnt = min(scnt[wave][buf ^ 1u][lane], kResStage);
+                if (fcnt) fbase = atomicAdd(&a.cand_cnt[my_q], fcnt);
+            }
+            // B. gather + accumulate + filter, quad after quad against the resident tables
+            if (live) {
+                const uint32_t c0 = c * TPR;
+                const uint32_t npts = min(TPR, size - c0);
+                const uint32_t nsub = (npts + kResThreads - 1) / kResThreads;
+                for (uint32_t qd = 0; qd < nq_t; ++qd) {
+                    const uint32_t slot = slot0 + (q0 + qd) * 4;
+                    uint32_t f_pq[4], f_vb[4], f_thi[4], f_tlo[4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        f_pq[p] = uniform_load(a.pair_q + slot + p);
+                        f_vb[p] = uniform_load(a.pair_vbase + slot + p);
+                        const uint64_t T = uniform_load(a.pair_thr + slot + p);
+                        f_thi[p] = (uint32_t)(T >> 32);
+                        f_tlo[p] = (uint32_t)T;
+                    }
+                    float acc[4][C::PPT];
+                    const float4 *lq = lut_s + qd * LUT4;
+                    if (nsub == 1) scan_quad_compute<C, 1, 0, 0>(lq, regs, acc);
+                    else scan_quad_compute<C, 2, 0, 0>(lq, regs, acc);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const uint32_t pq = f_pq[p];
+                        if (pq == kInvalid) continue;   // wave-uniform
+                        const uint64_t T = ((uint64_t)f_thi[p] << 32) | f_tlo[p];
+                        const uint32_t Thi = f_thi[p];
+                        const float Tf = (Thi == 0xFFFFFFFFu) ? __builtin_inff() : ordered_to_f32(Thi);
+                        const uint32_t vb = f_vb[p];
+#pragma unroll
+                        for (int i = 0; i < C::PPT; ++i) {
+                            if (i < (int)nsub && acc[p][i] <= Tf) {
+                                const uint32_t j = c0 + tid + kResThreads * i;
+                                if (j < size) {
+                                    const uint64_t key = make_key(acc[p][i], vb + j);
+                                    if (key <= T && row_allowed(ix, a.allow, a.allow_bits, lb + j)) {
+                                        const uint32_t sl = atomicAdd(&scnt[wave][buf][qd * 4 + p], 1u);
+                                        if (sl < kResStage) {
+                                            skey[wave][buf][qd * 4 + p][sl] = key;
+                                        } else {   // stage full: direct (slow) append
+                                            const uint32_t pos = atomicAdd(&a.cand_cnt[pq], 1u);
+                                            if (pos < a.cap) a.cand[(size_t)pq * a.cap + pos] = key;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            // C. write the previous chunk's survivors: lane = (pair j, entry e)
+            if (flush) {
+                constexpr int PER = 64 / NQS;                          // entries per pair per pass
+#pragma unroll
+                for (int e0 = 0; e0 < (int)kResStage; e0 += PER) {
+                    const uint32_t j = lane / PER, e = e0 + lane % PER;
+                    const uint32_t cj = (uint32_t)__shfl((int)fcnt, (int)j);
+                    const uint32_t bj = (uint32_t)__shfl((int)fbase, (int)j);
+                    const uint32_t qj = (uint32_t)__shfl((int)my_q, (int)j);
+                    if (e < cj) {
+                        const uint32_t pos = bj + e;
+                        if (pos < a.cap) a.cand[(size_t)qj * a.cap + pos] = skey[wave][buf ^ 1u][j][e];
+                    }
+                }
+                if (lane < (uint32_t)NQS) scnt[wave][buf ^ 1u][lane] = 0;
+            }
         }
     }
 }
@@ -1673,6 +1854,17 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
     if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
     uint32_t wgs = (uint32_t)cus * 8u;
     if (const char *e = std::getenv("SCANN_HIP_WGS")) wgs = (uint32_t)cus * (uint32_t)std::max(1, std::atoi(e));
+    a.res_cl = w.res_cl;
+    if constexpr (C::BITS == 4 && C::S <= 32) {
+        if (w.resident) {
+            SCANN_TRY(set_dyn_lds(adc_scan_res_kernel<C>, res_lds_bytes<C>()));
+            hipLaunchKernelGGL(adc_scan_res_kernel<C>, dim3((uint32_t)cus * 4u), dim3(kResThreads),
+                               res_lds_bytes<C>(), st, ix, a);
+            LAUNCH_CHECK();
+            if (ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
+            return SCANN_HIP_OK;
+        }
+    }
     SCANN_TRY(set_dyn_lds(adc_scan_kernel<C>, scan_lds_bytes<C>()));
     hipLaunchKernelGGL(adc_scan_kernel<C>, dim3(wgs), dim3(kScanThreads), scan_lds_bytes<C>(), st, ix, a);
     LAUNCH_CHECK();
@@ -1697,7 +1889,9 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
                        npairs, ix.ah_mode, w.tokens, ix.leaf_off, w.leaf_cnt);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(worklist_scan_kernel, dim3(1), dim3(1024), 0, st, ix.L, w.leaf_cnt,
-                       ix.leaf_off, scan_tile_points(ix), w.qpt, w.st, w.sqpt, w.pair_off, w.tile_off,
+                       ix.leaf_off, w.resident ? kResThreads * kScanPPT : scan_tile_points(ix),
+                       w.resident ? kResQuads : w.qpt, w.resident ? w.res_cl : 1u, scan_tile_points(ix), w.st,
+                       w.sqpt, w.pair_off, w.tile_off,
                        w.stile_off, w.counters);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(worklist_fill_kernel, dim3(ceil_div_u32(npairs, 256)), dim3(256), 0, st, w.nq,
