@@ -572,7 +572,7 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
         SCANN_TRY(txh_launch_search(ix->tx, w, false, ix->stream, ix->ev0,
                                     ix->ev1));
         ix->timing_valid = ix->timing;
-        ix->timed_kernel = "adc_scan_kernel";
+        ix->timed_kernel = w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
         uint32_t counters[CNT_N];
         SCANN_HIP_CHECK(hipMemcpyAsync(counters, w.counters, sizeof(counters), hipMemcpyDeviceToHost,
                                        ix->stream));
@@ -639,7 +639,7 @@ int scann_hip_search_batched(scann_hip_index *ix, const float *queries, uint32_t
                                ix->stream, ix->ev0,
                                ix->ev1);
         ix->timing_valid = ix->timing && s == SCANN_HIP_OK;
-        ix->timed_kernel = "bf_mfma_kernel";
+        ix->timed_kernel = bf_pass_kernel_name(ix->bf, nq);
         return s;
     }
     if (q_dim != ix->tx.dim)  // tree_x_hybrid/mod.rs:251-253, hashes/hasher.rs:167-171
@@ -680,7 +680,7 @@ int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries,
                                  d_out_count, st, ix->ev0,
                                  ix->ev1);
         ix->timing_valid = ix->timing && s == SCANN_HIP_OK;
-        ix->timed_kernel = "bf_mfma_kernel";
+        ix->timed_kernel = bf_pass_kernel_name(ix->bf, nq);
         return s;
     }
     TxhCallParams p;
@@ -701,7 +701,7 @@ int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries,
     SCANN_TRY(txh_launch_search(ix->tx, w, false, st, ix->ev0,
                                 ix->ev1));
     ix->timing_valid = ix->timing;
-    ix->timed_kernel = "adc_scan_kernel";
+    ix->timed_kernel = w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
     return SCANN_HIP_OK;
 }
 
@@ -752,7 +752,7 @@ int scann_hip_txh_search_local_device(scann_hip_index *ix, const float *d_querie
     SCANN_TRY(txh_launch_search(ix->tx, w, true, st, ix->ev0,
                                 ix->ev1));
     ix->timing_valid = ix->timing;
-    ix->timed_kernel = "adc_scan_kernel";
+    ix->timed_kernel = w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
     return SCANN_HIP_OK;
 }
 

@@ -19,6 +19,8 @@ constexpr uint32_t kBfSampleRows = 8192;   // rows of the threshold sample (== L
 
 int bf_reserve(const BfIndexDev &ix, BfWorkspace &w, uint32_t max_nq, uint32_t max_k);
 
+const char *bf_pass_kernel_name(const BfIndexDev &ix, uint32_t nq);
+
 // Host-pointer entry (copies in/out, synchronises).
 int bf_search_host(const BfIndexDev &ix, BfWorkspace &w, const float *queries, uint32_t nq,
                    uint32_t q_stride, uint32_t k, uint32_t *out_idx, float *out_dist,

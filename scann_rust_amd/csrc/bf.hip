@@ -662,6 +662,15 @@ static bool vq_eligible(const BfIndexDev &ix, const BfPass &p) {
     return p.nq >= 128;
 }
 
+// name of the kernel launch_pass picks for a batch of nq queries (timing reports)
+const char *bf_pass_kernel_name(const BfIndexDev &ix, uint32_t nq) {
+    BfPass p{};
+    p.nq = nq;
+    if (mfma_eligible(ix)) return "bf_mfma_dot_kernel";
+    if (vq_eligible(ix, p)) return "bf_vq_kernel";
+    return "bf_generic_kernel";
+}
+
 static int launch_pass(const BfIndexDev &ix, const BfPass &p, hipStream_t st) {
     if (p.nq == 0 || p.nrows == 0) return SCANN_HIP_OK;
     if (mfma_eligible(ix)) {
