@@ -614,3 +614,52 @@ def test_pack_blocks_matches_reference():
     with pytest.raises(hip.ScannError):
         hip.check(hip.load().scann_hip_txh_pack_blocks_device(hip.context(0), 5, nq, m, p(tk), p(ti), p(te), p(tc),
                                                               p(out), bb, None))
+
+
+# ---- resident-table scan kernel (long leaves scanned by >= 128 queries) ----------------------------
+@pytest.mark.parametrize("n,dim,S,nq,pre_k", [(9000, 128, 32, 160, 300), (30000, 64, 16, 256, 77), (5000, 32, 8, 130, 2000)])
+def test_ah_resident_scan_matches_oracle(n, dim, S, nq, pre_k):
+    """>= 32 query quads and >= 4 chunks of 1024 points per leaf select adc_scan_res_kernel
+    (api.hip): same candidates, same results as the oracle for every query."""
+    k = 10
+    rows, data, stride, ix, kw = H.make_ah_case(n, dim, S, seed=81, pq_iters=2)
+    index = hip.txh_create(**kw)
+    q = synth.uniform_f32(nq, dim, 82)
+    o = hip.default_opts()
+    o.exact_reorder, o.pre_reorder_k = 1, pre_k
+    idx, dist, cnt = index.search_batched(q, k, o)
+    bits_ = hip.allow_bitmap(n, np.arange(0, n, 3))
+    fidx, fdist, fcnt = index.search_batched(q, k, o, allow=bits_)
+    sub = np.arange(0, n, 3)
+    for i in range(0, nq, 7):
+        oi, od = orc.ah_search_with_reordering(ix["codebook"], ix["codes"], data, stride, q[i], k, pre_k)
+        H.assert_topk_equal_up_to_ties(idx[i, :cnt[i]], dist[i, :cnt[i]], oi, od, what="res q%d" % i)
+        oi, od = orc.ah_search_with_reordering(ix["codebook"], np.ascontiguousarray(ix["codes"][sub]),
+                                               np.ascontiguousarray(data.reshape(n, stride)[sub]), stride,
+                                               q[i], k, pre_k)
+        H.assert_topk_equal_up_to_ties(fidx[i, :fcnt[i]], fdist[i, :fcnt[i]], sub[oi].astype(np.uint32), od,
+                                       what="res filtered q%d" % i)
+
+
+def test_txh_resident_scan_two_big_leaves():
+    """Two big partitions, every query searches both: 64 quads per leaf -> resident-table kernel."""
+    n, dim, S, nq, k = 12000, 64, 16, 256, 10
+    rows = synth.uniform_f32(n, dim, 83)
+    centers = np.stack([np.full(dim, 0.25, np.float32), np.full(dim, 0.75, np.float32)])
+    assign = (rows.mean(1) > 0.5).astype(np.int64)
+    built = trainer.build_txh_index(rows, 2, S, centers=centers, assign=assign, pq_iters=2)
+    data, stride = orc.to_strided(rows)
+    oix = orc.TxhIndex(data, stride, dim, built["centers"], built["leaf_off"], built["leaf_ids"],
+                       built["codebook"], built["codes"], partitions_to_search=2,
+                       pre_reorder_multiplier=20.0)
+    index = hip.txh_create(data=data, n_rows=n, dim=dim, stride=stride, centers=built["centers"],
+                           leaf_offsets=built["leaf_off"], leaf_ids=built["leaf_ids"],
+                           codebook=built["codebook"], codes=built["codes"], partitions_to_search=2,
+                           pre_reorder_multiplier=20.0)
+    q = synth.uniform_f32(nq, dim, 84)
+    o = hip.default_opts()
+    o.partitions_to_search, o.pre_reorder_k = 2, orc.pre_reorder_k(k, 20.0)
+    idx, dist, cnt, (tok, tokd, ci, cd, cc) = index.search_batched(q, k, o, stages=True)
+    for i in range(0, nq, 9):
+        H.check_txh_query(oix, q[i], k, idx[i, :cnt[i]], dist[i, :cnt[i]], tok[i], tokd[i],
+                          ci[i, :cc[i]], cd[i, :cc[i]], what="res txh q%d" % i)
