@@ -493,11 +493,19 @@ static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallP
         // leaves) the per-chunk kernel is as fast or faster.
         const uint64_t rtp = (uint64_t)kResThreads * kScanPPT;
         const uint64_t res_chunks_per_leaf = std::max<uint64_t>(1, (t.n_local / std::max(1u, L)) / rtp);
-        w->resident = (t.code_bits == 4 && t.S <= 32 && res_chunks_per_leaf >= 4 && quads_per_leaf >= 32) ? 1u : 0u;
-        if (const char *e = std::getenv("SCANN_HIP_RESIDENT")) w->resident = std::atoi(e) ? w->resident : 0u;
         const uint64_t qgroups = std::max<uint64_t>(1, (quads_per_leaf + kResQuads - 1) / kResQuads);
         const uint64_t units = (t.n_local / rtp + L) * qgroups;       // (chunk, quad group) pairs
-        w->res_cl = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, units / 4096));
+        // a tile must cover >= 8 chunks to amortise its table load, and there must be >= 2 tiles
+        // per resident workgroup (small shards: measured at 125k-500k rows)
+        w->res_cl = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(8, units / 4096));
+        w->resident = (t.code_bits == 4 && t.S <= 32 && res_chunks_per_leaf >= 8 && quads_per_leaf >= 32 &&
+                       units / w->res_cl >= 1536) ? 1u : 0u;
+        // SCANN_HIP_RESIDENT: 0 = never, 2 = whenever the code layout allows (tests), else the heuristic
+        if (const char *e = std::getenv("SCANN_HIP_RESIDENT")) {
+            const int v = std::atoi(e);
+            if (v == 0) w->resident = 0u;
+            if (v == 2) w->resident = (t.code_bits == 4 && t.S <= 32) ? 1u : 0u;
+        }
         if (const char *e = std::getenv("SCANN_HIP_RES_CL")) w->res_cl = (uint32_t)std::max(1, std::atoi(e));
     }
     w->sbase = s.sbase.as<uint32_t>();

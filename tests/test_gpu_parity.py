@@ -617,10 +617,19 @@ def test_pack_blocks_matches_reference():
 
 
 # ---- resident-table scan kernel (long leaves scanned by >= 128 queries) ----------------------------
-@pytest.mark.parametrize("n,dim,S,nq,pre_k", [(9000, 128, 32, 160, 300), (30000, 64, 16, 256, 77), (5000, 32, 8, 130, 2000)])
-def test_ah_resident_scan_matches_oracle(n, dim, S, nq, pre_k):
-    """>= 32 query quads and >= 4 chunks of 1024 points per leaf select adc_scan_res_kernel
-    (api.hip): same candidates, same results as the oracle for every query."""
+@pytest.fixture
+def force_resident(monkeypatch):
+    """adc_scan_res_kernel is selected by a size heuristic (api.hip); SCANN_HIP_RESIDENT=2 selects it
+    for every 4-bit S <= 32 index so that small test cases run it too."""
+    monkeypatch.setenv("SCANN_HIP_RESIDENT", "2")
+    monkeypatch.setenv("SCANN_HIP_RES_CL", "3")
+
+
+@pytest.mark.parametrize("n,dim,S,nq,pre_k", [(9000, 128, 32, 160, 300), (30000, 64, 16, 256, 77), (5000, 32, 8, 130, 2000),
+                                              (700, 32, 8, 5, 40)])
+def test_ah_resident_scan_matches_oracle(force_resident, n, dim, S, nq, pre_k):
+    """Resident-table scan kernel: same candidates, same results as the oracle for every query
+    (incl. a partial last chunk, fewer quads than the kernel keeps resident, and a filter)."""
     k = 10
     rows, data, stride, ix, kw = H.make_ah_case(n, dim, S, seed=81, pq_iters=2)
     index = hip.txh_create(**kw)
@@ -641,7 +650,7 @@ def test_ah_resident_scan_matches_oracle(n, dim, S, nq, pre_k):
                                        what="res filtered q%d" % i)
 
 
-def test_txh_resident_scan_two_big_leaves():
+def test_txh_resident_scan_two_big_leaves(force_resident):
     """Two big partitions, every query searches both: 64 quads per leaf -> resident-table kernel."""
     n, dim, S, nq, k = 12000, 64, 16, 256, 10
     rows = synth.uniform_f32(n, dim, 83)
