@@ -161,6 +161,13 @@ typedef struct {
      * (what scann.hpp's search_with_filter does). */
     const uint64_t *allow_bitmap;
     uint64_t allow_bitmap_bits;
+    /* Brute-force handles.  0 (default): large batches on large indexes take the bf16-shortlist
+     * path (bf16 MFMA scores shortlist 4k rows per query, the reference's f32 arithmetic re-scores
+     * them, and an error bound proves that no other row can enter the top k; results are
+     * bit-identical to the exact kernels).  A query whose result cannot be proven sets status
+     * Aborted: the host entry point repeats the batch on the exact kernels by itself, callers of the
+     * *_device entry point repeat it with bf_exact = 1.  1: exact kernels only. */
+    int32_t bf_exact;
 } scann_hip_search_opts;
 
 void scann_hip_search_opts_default(scann_hip_search_opts *opts);

@@ -66,7 +66,7 @@ struct scann_hip_index {
 
     // ---- brute force ----
     BfIndexDev bf{};
-    DevBuf bf_rows;
+    DevBuf bf_rows, bf_rows_b, bf_rows_bl, bf_norm2;
     BfWorkspace bfw;
 
     // ---- tree-x-hybrid / AH ----
@@ -208,6 +208,23 @@ int scann_hip_bf_create(scann_hip_ctx *ctx, const float *data, uint64_t n, uint3
     ix->bf.dim = dim;
     ix->bf.stride = stride;
     ix->bf.measure = measure;
+    ix->bf.rows_b = nullptr;
+    ix->bf.rows_bl = nullptr;
+    ix->bf.norm2 = nullptr;
+    ix->bf.max_norm = 0.0f;
+    if ((stride & 3u) == 0) {   // bf16 copy + norms for the shortlist path (big indexes only)
+        s = bf_build_shortlist_data(ix->bf, ix->bf_rows_b, ix->bf_rows_bl, ix->bf_norm2, &ix->bf.max_norm,
+                                    ix->stream);
+        if (s != SCANN_HIP_OK) {
+            scann_hip_index_destroy(ix);
+            return s;
+        }
+        if (ix->bf_rows_b.p) {
+            ix->bf.rows_b = ix->bf_rows_b.as<uint16_t>();
+            ix->bf.rows_bl = ix->bf_rows_bl.as<uint16_t>();
+            ix->bf.norm2 = ix->bf_norm2.as<float>();
+        }
+    }
     *out = ix;
     return SCANN_HIP_OK;
 }
@@ -643,11 +660,11 @@ int scann_hip_search_batched(scann_hip_index *ix, const float *queries, uint32_t
         std::lock_guard<std::mutex> lock(ix->mu);
         SCANN_TRY(set_device(ix->ctx));
         ix->next_events();
-        int s = bf_search_host(ix->bf, ix->bfw, queries, nq, q_stride, k, out_idx, out_dist, out_count,
-                               ix->stream, ix->ev0,
-                               ix->ev1);
+        int s = bf_search_host(ix->bf, ix->bfw, queries, nq, q_stride, k, opts && opts->bf_exact, out_idx,
+                               out_dist, out_count, ix->stream, ix->ev0, ix->ev1);
         ix->timing_valid = ix->timing && s == SCANN_HIP_OK;
-        ix->timed_kernel = bf_pass_kernel_name(ix->bf, nq);
+        ix->timed_kernel = (!(opts && opts->bf_exact) && bf_shortlist_eligible(ix->bf, nq, k))
+                               ? "bf_bf16_kernel" : bf_pass_kernel_name(ix->bf, nq);
         return s;
     }
     if (q_dim != ix->tx.dim)  // tree_x_hybrid/mod.rs:251-253, hashes/hasher.rs:167-171
@@ -684,11 +701,12 @@ int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries,
     SCANN_TRY(set_device(ix->ctx));
     if (ix->kind == KIND_BF) {
         ix->next_events();
-        int s = bf_search_device(ix->bf, ix->bfw, d_queries, nq, q_stride, k, d_out_idx, d_out_dist,
-                                 d_out_count, st, ix->ev0,
-                                 ix->ev1);
+        const bool exact_only = opts && opts->bf_exact;
+        int s = bf_search_device(ix->bf, ix->bfw, d_queries, nq, q_stride, k, exact_only, d_out_idx,
+                                 d_out_dist, d_out_count, st, ix->ev0, ix->ev1);
         ix->timing_valid = ix->timing && s == SCANN_HIP_OK;
-        ix->timed_kernel = bf_pass_kernel_name(ix->bf, nq);
+        ix->timed_kernel = (!exact_only && bf_shortlist_eligible(ix->bf, nq, k)) ? "bf_bf16_kernel"
+                                                                                : bf_pass_kernel_name(ix->bf, nq);
         return s;
     }
     TxhCallParams p;
@@ -715,9 +733,10 @@ int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries,
 
 int scann_hip_index_last_device_status(scann_hip_index *ix, void *hip_stream) {
     if (!ix) return fail(SCANN_HIP_INVALID_ARGUMENT, "index is null");
-    if (ix->kind != KIND_TXH || !ix->ws.counters.p) return SCANN_HIP_OK;
     SCANN_TRY(set_device(ix->ctx));
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (ix->kind == KIND_BF) return bf_last_status(ix->bfw, st);
+    if (ix->kind != KIND_TXH || !ix->ws.counters.p) return SCANN_HIP_OK;
     uint32_t counters[CNT_N];
     SCANN_HIP_CHECK(hipMemcpyAsync(counters, ix->ws.counters.p, sizeof(counters),
                                    hipMemcpyDeviceToHost, st));

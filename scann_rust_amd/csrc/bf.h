@@ -9,11 +9,23 @@ struct BfIndexDev {
     uint64_t n;
     uint32_t dim, stride;
     int measure;         // scann_hip_measure
+    // bf16 shortlist (bf_shortlist_*): a bf16 copy of the rows [n][dim], f32 squared norms and the
+    // largest row norm; nullptr when the index does not qualify (dim % 16, size)
+    const uint16_t *rows_b, *rows_bl;   // hi and lo halves of the split bf16 copy
+    const float *norm2;
+    float max_norm;
 };
 
 struct BfWorkspace {
     DevBuf queries, sample, thr, cand_cnt, cand, counters, out_idx, out_dist, out_count;
+    DevBuf q_b, q_bl, q_n2, sl_idx, sl_approx, sl_cnt, sl_exact, sl_fail;   // bf16 shortlist path
 };
+
+// bf16 copy + squared norms of the rows (index creation); *max_norm = largest row norm.
+int bf_build_shortlist_data(const BfIndexDev &ix, DevBuf &rows_b, DevBuf &rows_bl, DevBuf &norm2,
+                            float *max_norm, hipStream_t stream);
+// true if searches on this index may take the bf16-shortlist path for (nq, k)
+bool bf_shortlist_eligible(const BfIndexDev &ix, uint32_t nq, uint32_t k);
 
 constexpr uint32_t kBfSampleRows = 8192;   // rows of the threshold sample (== LDS sort size)
 
@@ -23,13 +35,18 @@ const char *bf_pass_kernel_name(const BfIndexDev &ix, uint32_t nq);
 
 // Host-pointer entry (copies in/out, synchronises).
 int bf_search_host(const BfIndexDev &ix, BfWorkspace &w, const float *queries, uint32_t nq,
-                   uint32_t q_stride, uint32_t k, uint32_t *out_idx, float *out_dist,
+                   uint32_t q_stride, uint32_t k, bool exact_only, uint32_t *out_idx, float *out_dist,
                    uint32_t *out_count, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
 
 // Device-pointer entry (enqueue only).
+// exact_only = false: searches that qualify take the bf16-shortlist path (status Aborted in the
+// counters if a query's result could not be verified: repeat with exact_only = true).
 int bf_search_device(const BfIndexDev &ix, BfWorkspace &w, const float *d_queries, uint32_t nq,
-                     uint32_t q_stride, uint32_t k, uint32_t *d_out_idx, float *d_out_dist,
-                     uint32_t *d_out_count, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+                     uint32_t q_stride, uint32_t k, bool exact_only, uint32_t *d_out_idx,
+                     float *d_out_dist, uint32_t *d_out_count, hipStream_t stream, hipEvent_t ev0,
+                     hipEvent_t ev1);
+// OK, or the status the last enqueued search left in the workspace counters (synchronises).
+int bf_last_status(const BfWorkspace &w, hipStream_t stream);
 
 // Dense [nq][n] distance matrix to host memory.
 int bf_distances_host(const BfIndexDev &ix, BfWorkspace &w, const float *queries, uint32_t nq,

@@ -19,6 +19,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace scann {
@@ -467,6 +469,331 @@ __global__ __launch_bounds__(256) void assign_nearest_kernel(BfIndexDev ix, cons
 }
 
 // =====================================================================================
+// bf16 shortlist path (exact results, verified).  MI355X runs bf16 MFMA at 16x the f32 MFMA
+// rate, but bf16 scores cannot meet the parity bar.  They CAN order the database
+// coarsely: a bf16 pass shortlists kp >= 4k rows per query, the reference's f32 arithmetic
+// re-scores only those, and the result is accepted when the k-th exact distance is below
+// (kp-th smallest bf16 score) - E, where E bounds |bf16 score - exact| for EVERY row, so no row
+// outside the shortlist can beat or tie the k-th result.  Plain bf16 (u = 2^-8) gives
+// E = 2u |q||x|, as large as the gaps between neighbours at 1M x 128; the pass therefore uses
+// SPLIT operands x = hi + lo (both bf16, lo = bf16(x - hi)) and three MFMAs per k-step,
+//   q.x ~ qh.xh + qh.xl + ql.xh,   |error| <= (3 u^2 + O(u^3)) |q||x| + f32 accumulation
+// -- 3/16 of the f32-MFMA time at 1/200 of the plain-bf16 error.  Queries that fail the test set
+// status Aborted (and a per-query flag) and are repeated on the exact kernels (bf_search_host does
+// it itself).  Accepted results are bit-identical to the exact path: same arithmetic, same rows.
+// =====================================================================================
+constexpr float kBf16DotErr = 7.5e-5f;     // 3 u^2 (1 + u) + 3 K 2^-24 slack, K <= 256, rounded up
+constexpr float kF32SqErr = 6.0e-5f;       // f32 rounding of norms / the squared-distance identity
+constexpr uint32_t kShortMax = 256;        // largest shortlist per query
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);   // NaN stays NaN
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+
+// rows (or queries) -> split bf16 [n][dim] (hi, lo) + squared norms (f32, sequential)
+__global__ void bf_to_bf16_kernel(const float *__restrict__ src, uint64_t n, uint32_t dim, uint32_t stride,
+                                  uint16_t *__restrict__ dst_hi, uint16_t *__restrict__ dst_lo,
+                                  float *__restrict__ norm2) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *row = src + i * stride;
+    float s2 = 0.0f;
+    for (uint32_t j = 0; j < dim; j += 8) {
+        uint16_t bh[8], bl[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = row[j + e];
+            s2 = s2 + v * v;
+            bh[e] = f32_to_bf16_rne(v);
+            bl[e] = f32_to_bf16_rne(v - bf16_bits_to_f32(bh[e]));   // exact difference, then rounded
+        }
+        uint4 ph, pl;
+        ph.x = bh[0] | ((uint32_t)bh[1] << 16); ph.y = bh[2] | ((uint32_t)bh[3] << 16);
+        ph.z = bh[4] | ((uint32_t)bh[5] << 16); ph.w = bh[6] | ((uint32_t)bh[7] << 16);
+        pl.x = bl[0] | ((uint32_t)bl[1] << 16); pl.y = bl[2] | ((uint32_t)bl[3] << 16);
+        pl.z = bl[4] | ((uint32_t)bl[5] << 16); pl.w = bl[6] | ((uint32_t)bl[7] << 16);
+        *reinterpret_cast<uint4 *>(dst_hi + i * dim + j) = ph;
+        *reinterpret_cast<uint4 *>(dst_lo + i * dim + j) = pl;
+    }
+    norm2[i] = s2;
+}
+
+__global__ void bf_max_norm_kernel(const float *__restrict__ norm2, uint64_t n, uint32_t *__restrict__ out_bits) {
+    float m = 0.0f;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float v = norm2[i];
+        m = (v > m || v != v) ? v : m;     // NaN propagates -> nothing verifies -> exact path
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(m, o);
+        m = (t > m || t != t) ? t : m;
+    }
+    if ((threadIdx.x & 63u) == 0) atomicMax(out_bits, __float_as_uint(m));   // non-negative floats order as uints
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// bf16 MFMA pass.  Block = 4 waves x 32 queries (B fragments resident), 32-row X tiles
+// LDS-DMA'd and XOR-swizzled like bf_mfma_dot_kernel; v_mfma_f32_32x32x16_bf16:
+//   A[i = lane & 31][k = 8h + j] = X[row i][16t + 8h + j], B[k][n = lane & 31] = Q[n][16t + 8h + j].
+// Score = -dot (DotProduct) or |q|^2 + |x|^2 - 2 dot (SquaredL2 / L2: squared domain).
+constexpr int kB16Waves = 4;      // waves per block: 8 x 32 = 256 queries share a stage
+constexpr int kB16Sub = 1;        // 32-row sub-tiles per stage (one barrier per 64 rows)
+
+template <int TS, int MEASURE>
+__global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev ix, BfPass p,
+                                                                    const uint16_t *__restrict__ qb,
+                                                                    const uint16_t *__restrict__ qbl,
+                                                                    const float *__restrict__ qn2, uint32_t nx,
+                                                                    uint32_t ny) {
+    constexpr int DIM = TS * 16;
+    constexpr int CPR = DIM / 8;                                       // 16-B chunks per bf16 row
+    constexpr uint32_t SW = (CPR % 16 == 0) ? 15u : (CPR % 8 == 0 ? 7u : (CPR % 4 == 0 ? 3u : 1u));
+    constexpr int RT = 32 * kB16Sub;                                   // rows per stage
+    constexpr int TILE_B = RT * DIM * 2;                               // bytes of one (hi or lo) stage
+    constexpr int NI = TILE_B / 1024;                                  // 1 KiB wave-instructions per stage
+    constexpr int NBUF = 2;
+    constexpr int STAGE_B = 2 * TILE_B + 256;                          // hi | lo | RT norms (<= 64)
+    constexpr int MYI = (NI + kB16Waves - 1) / kB16Waves;              // DMA instruction pairs per wave
+    static_assert(RT <= 64, "one 4-byte DMA instruction carries the stage's norms");
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsb[];   // [NBUF][STAGE_B]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t h = lane >> 5, li = lane & 31u;
+    const uint32_t bid = blockIdx.x, xcd = bid & 7u, slot = bid >> 3;
+    const uint32_t x = xcd + 8u * (slot / ny), y = slot % ny;
+    const uint32_t ntiles = (p.nrows + RT - 1u) / RT;
+    const uint32_t q = y * (kB16Waves * 32u) + wave * 32u + li;
+    const uint32_t qc = min(q, p.nq - 1u);
+    bf16x8 qf[TS], ql[TS];
+#pragma unroll
+    for (int t = 0; t < TS; ++t) {
+        qf[t] = *reinterpret_cast<const bf16x8 *>(qb + (size_t)qc * DIM + 16 * t + 8 * h);
+        ql[t] = *reinterpret_cast<const bf16x8 *>(qbl + (size_t)qc * DIM + 16 * t + 8 * h);
+    }
+    const float q2 = MEASURE == SCANN_HIP_DOT_PRODUCT ? 0.0f : qn2[qc];
+    uint64_t T = 0;
+    float Tf = 0.0f;
+    if (p.filter) {
+        T = p.thr[qc];
+        Tf = bf_thr_float(T);
+    }
+    const bool qvalid = q < p.nq;
+
+    // per-lane pieces of the DMA source address that do not depend on the tile
+    uint32_t lane_row[MYI], lane_col[MYI];
+#pragma unroll
+    for (int i = 0; i < MYI; ++i) {
+        const uint32_t ci = (wave + (uint32_t)kB16Waves * i) * 64u + lane;   // linear chunk index in the stage
+        const uint32_t r = ci / CPR, pos = ci - r * CPR;
+        lane_row[i] = r;
+        lane_col[i] = 8u * (pos ^ (r & SW));
+    }
+    const size_t row_pitch = (size_t)p.row_mult * DIM;                 // elements between virtual rows
+    auto dma_tile = [&](uint32_t tile, uint32_t buf) {
+        unsigned char *stage = xsb + (size_t)buf * STAGE_B;
+        const bool last = tile * RT + RT > p.nrows;                    // wave-uniform: clamp only here
+#pragma unroll
+        for (int i = 0; i < MYI; ++i) {
+            const uint32_t gi = wave + (uint32_t)kB16Waves * i;
+            if (gi < (uint32_t)NI) {
+                uint32_t vr = tile * RT + lane_row[i];
+                if (last) vr = min(vr, p.nrows - 1u);
+                const size_t off = (size_t)vr * row_pitch + lane_col[i];
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(ix.rows_b + off),
+                    (__attribute__((address_space(3))) void *)(stage + gi * 1024u), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(ix.rows_bl + off),
+                    (__attribute__((address_space(3))) void *)(stage + TILE_B + gi * 1024u), 16, 0, 0);
+            }
+        }
+        if (MEASURE != SCANN_HIP_DOT_PRODUCT && tid < (uint32_t)RT) {
+            const uint32_t vr = min(tile * RT + tid, p.nrows - 1u);
+            reinterpret_cast<float *>(stage + 2 * TILE_B)[tid] = ix.norm2[(size_t)vr * p.row_mult];
+        }
+    };
+    // squared norms of the stage's rows (plain loads: staged after the MFMAs so that their wait
+    // coincides with the end-of-iteration wait for the DMA)
+    auto stage_norms = [&](uint32_t tile, uint32_t buf) {
+        if (MEASURE != SCANN_HIP_DOT_PRODUCT && tid < (uint32_t)RT) {
+            const uint32_t vr = min(tile * RT + tid, p.nrows - 1u);
+            reinterpret_cast<float *>(xsb + (size_t)buf * STAGE_B + 2 * TILE_B)[tid] =
+                ix.norm2[(size_t)vr * p.row_mult];
+        }
+    };
+
+    uint32_t tile = x;
+    if (tile >= ntiles) return;   // uniform per block
+    dma_tile(tile, 0);
+    stage_norms(tile, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
+                         0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const uint32_t sw = li & SW;
+    for (uint32_t it = 0; tile < ntiles; tile += nx, ++it) {
+        const uint32_t buf = it % NBUF;
+        const bool more = tile + nx < ntiles;
+        if (more) dma_tile(tile + nx, buf ^ 1u);          // in flight during this stage's MFMAs
+        const unsigned char *stage = xsb + (size_t)buf * STAGE_B;
+#pragma unroll
+        for (int sub = 0; sub < kB16Sub; ++sub) {
+            const uint32_t row0 = tile * RT + 32u * sub;
+            if (row0 >= p.nrows) break;                                 // uniform
+            const float *nrm = reinterpret_cast<const float *>(stage + 2 * TILE_B) + 32 * sub;
+            f32x16 acc = zero;
+            const unsigned char *xrow = stage + (size_t)(32 * sub + li) * DIM * 2;
+#pragma unroll
+            for (int t = 0; t < TS; ++t) {
+                const uint32_t c0 = 2u * t + h;
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(xrow + 16u * (c0 ^ sw));
+                const bf16x8 al = *reinterpret_cast<const bf16x8 *>(xrow + TILE_B + 16u * (c0 ^ sw));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[t], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qf[t], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ql[t], acc, 0, 0, 0);
+            }
+            float sc[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (MEASURE == SCANN_HIP_DOT_PRODUCT) {
+                    sc[r] = -acc[r];
+                } else {
+                    sc[r] = (q2 + nrm[(r & 3) + 8 * (r >> 2) + 4 * h]) - 2.0f * acc[r];
+                }
+            }
+            const bool full = row0 + 32u <= p.nrows;
+            if (p.filter) {
+                float dmin = sc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) dmin = fminf(dmin, sc[r]);
+                if (__any(qvalid && (dmin <= Tf || !full))) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t vrow = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (qvalid && vrow < p.nrows) bf_emit(p, q, vrow, sc[r], Tf, T);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t vrow = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (qvalid && (full || vrow < p.nrows)) p.out[(size_t)q * p.ld + vrow] = sc[r];
+                }
+            }
+        }
+        if (more) stage_norms(tile + nx, buf ^ 1u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage's DMA has landed
+        __syncthreads();
+    }
+}
+
+// exact f32 score of the shortlisted rows with the reference's arithmetic (simd/x86.rs:72-96,
+// 139-165): 8 lanes per candidate = the 8 AVX2 FMA lane chains, hsum tree by shuffles, scalar tail.
+template <int MEASURE>
+__global__ __launch_bounds__(256) void bf_rerank_kernel(BfIndexDev ix, const float *__restrict__ queries,
+                                                        uint32_t q_stride, uint32_t kp,
+                                                        const uint32_t *__restrict__ sl_idx,
+                                                        const uint32_t *__restrict__ sl_cnt,
+                                                        float *__restrict__ sl_exact) {
+    extern __shared__ __attribute__((aligned(16))) float s_q[];   // [dim]
+    const uint32_t q = blockIdx.y, tid = threadIdx.x;
+    const uint32_t nsel = min(sl_cnt[q], kp);
+    const uint32_t c0 = blockIdx.x * 32u;
+    if (c0 >= nsel) return;   // uniform
+    const uint32_t dim = ix.dim;
+    for (uint32_t j = tid; j < dim; j += blockDim.x) s_q[j] = queries[(size_t)q * q_stride + j];
+    __syncthreads();
+    const uint32_t chunks = dim >> 3, lane8 = tid & 7u;
+    const uint32_t c = c0 + (tid >> 3);
+    const bool act = c < nsel;
+    float accv = 0.0f;
+    const float *row = ix.rows;
+    if (act) row = ix.rows + (size_t)sl_idx[(size_t)q * kp + c] * ix.stride;
+    for (uint32_t i0 = 0; i0 < chunks; i0 += 8) {
+        float xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = (act && i0 + u < chunks) ? row[8 * (i0 + u) + lane8] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u < chunks) {
+                const float qv = s_q[8 * (i0 + u) + lane8];
+                if (MEASURE == SCANN_HIP_DOT_PRODUCT) {
+                    accv = fmaf(qv, xv[u], accv);
+                } else {
+                    const float diff = qv - xv[u];
+                    accv = fmaf(diff, diff, accv);
+                }
+            }
+        }
+    }
+    float s = accv + __shfl_down(accv, 4, 8);
+    float t = s + __shfl_down(s, 1, 8);
+    float r = t + __shfl_down(t, 2, 8);
+    if (act && lane8 == 0) {
+        for (uint32_t j = chunks * 8; j < dim; ++j) {   // scalar tail, not fused
+            if (MEASURE == SCANN_HIP_DOT_PRODUCT) {
+                r = r + s_q[j] * row[j];
+            } else {
+                const float diff = s_q[j] - row[j];
+                r = r + diff * diff;
+            }
+        }
+        sl_exact[(size_t)q * kp + c] = MEASURE == SCANN_HIP_DOT_PRODUCT ? -r : r;   // L2: squared here
+    }
+}
+
+// per query (one wave): sort the shortlist by (exact, index), emit the first k, verify.
+template <int MEASURE>
+__global__ __launch_bounds__(64) void bf_shortlist_final_kernel(
+    uint32_t n, uint32_t k, uint32_t kp, float max_norm, const float *__restrict__ qn2,
+    const uint32_t *__restrict__ sl_idx, const float *__restrict__ sl_approx,
+    const uint32_t *__restrict__ sl_cnt, const float *__restrict__ sl_exact,
+    uint32_t *__restrict__ counters, uint32_t *__restrict__ fail_flag, uint32_t *__restrict__ out_idx,
+    float *__restrict__ out_dist, uint32_t *__restrict__ out_count) {
+    __shared__ uint64_t skeys[kShortMax];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t nsel = min(sl_cnt[q], kp);
+    uint32_t n2 = 1;
+    while (n2 < nsel) n2 <<= 1;
+    for (uint32_t i = tid; i < n2; i += nt)
+        skeys[i] = i < nsel ? make_key(sl_exact[(size_t)q * kp + i], sl_idx[(size_t)q * kp + i]) : SCANN_KEY_MAX;
+    __syncthreads();
+    bitonic_sort_lds(skeys, n2);
+    const uint32_t nout = min(k, nsel);
+    for (uint32_t i = tid; i < k; i += nt) {
+        float d = __builtin_inff();
+        uint32_t id = kBfInvalid;
+        if (i < nout) {
+            id = (uint32_t)skeys[i];
+            d = ordered_to_f32((uint32_t)(skeys[i] >> 32));
+            if (MEASURE == SCANN_HIP_L2) d = sqrtf(d);
+        }
+        out_idx[(size_t)q * k + i] = id;
+        out_dist[(size_t)q * k + i] = d;
+    }
+    if (tid == 0) {
+        out_count[q] = nout;
+        bool ok = nsel >= n;                         // everything was re-scored
+        if (!ok && nout == k && nsel == kp) {
+            // every row outside the shortlist scores >= the shortlist's largest bf16 score
+            const float floor_b = sl_approx[(size_t)q * kp + kp - 1];
+            const float dk = ordered_to_f32((uint32_t)(skeys[k - 1] >> 32));   // k-th exact (squared for L2)
+            const float qn = sqrtf(qn2[q]);
+            float E;
+            if (MEASURE == SCANN_HIP_DOT_PRODUCT) E = kBf16DotErr * qn * max_norm;
+            else E = 2.0f * kBf16DotErr * qn * max_norm + kF32SqErr * (qn * qn + max_norm * max_norm);
+            ok = dk < floor_b - E * 1.0001f;         // NaNs compare false -> exact path
+        }
+        fail_flag[q] = ok ? 0u : 1u;
+        if (!ok) atomicMax(&counters[BF_CNT_STATUS], (uint32_t)SCANN_HIP_ABORTED);
+    }
+}
+
+// =====================================================================================
 // threshold from the sample matrix [nq][ns]; when the sample is the whole dataset
 // (row_mult == 1, ns == n) the sorted sample IS the answer and is written directly.
 // =====================================================================================
@@ -816,31 +1143,237 @@ static int enqueue_search(const BfIndexDev &ix, BfWorkspace &w, const BfPlan &pl
     return SCANN_HIP_OK;
 }
 
+// ---- bf16 shortlist path --------------------------------------------------------------------
+static uint32_t env_u32(const char *name, uint32_t dflt) {
+    const char *e = std::getenv(name);
+    return e ? (uint32_t)std::strtoul(e, nullptr, 10) : dflt;
+}
+
+static bool shortlist_dims_ok(uint32_t dim) {
+    switch (dim) {
+        case 32: case 64: case 96: case 128: case 192: case 256: return true;
+        default: return false;
+    }
+}
+
+int bf_build_shortlist_data(const BfIndexDev &ix, DevBuf &rows_b, DevBuf &rows_bl, DevBuf &norm2,
+                            float *max_norm, hipStream_t st) {
+    *max_norm = 0.0f;
+    if (ix.n == 0 || !shortlist_dims_ok(ix.dim)) return SCANN_HIP_OK;
+    // SCANN_HIP_BF_SHORTLIST_MIN_ROWS: below this the exact kernels are fast enough (tests set 1)
+    if (ix.n < env_u32("SCANN_HIP_BF_SHORTLIST_MIN_ROWS", 65536)) return SCANN_HIP_OK;
+    SCANN_TRY(rows_b.ensure((size_t)ix.n * ix.dim * 2));
+    SCANN_TRY(rows_bl.ensure((size_t)ix.n * ix.dim * 2));
+    SCANN_TRY(norm2.ensure((size_t)ix.n * 4));
+    DevBuf mx;
+    SCANN_TRY(mx.ensure(4));
+    SCANN_HIP_CHECK(hipMemsetAsync(mx.p, 0, 4, st));
+    hipLaunchKernelGGL(bf_to_bf16_kernel, dim3((uint32_t)ceil_div_u64(ix.n, 256)), dim3(256), 0, st, ix.rows,
+                       ix.n, ix.dim, ix.stride, rows_b.as<uint16_t>(), rows_bl.as<uint16_t>(), norm2.as<float>());
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(bf_max_norm_kernel, dim3(256), dim3(256), 0, st, norm2.as<float>(), ix.n,
+                       mx.as<uint32_t>());
+    LAUNCH_CHECK();
+    uint32_t bits = 0;
+    SCANN_HIP_CHECK(hipMemcpyAsync(&bits, mx.p, 4, hipMemcpyDeviceToHost, st));
+    SCANN_HIP_CHECK(hipStreamSynchronize(st));
+    float m2;
+    std::memcpy(&m2, &bits, 4);
+    *max_norm = std::sqrt(m2) * 1.000001f;
+    return SCANN_HIP_OK;
+}
+
+// shortlist size: 4k, at least 32, at most kShortMax
+static uint32_t shortlist_size(uint32_t k) { return std::min(kShortMax, std::max(32u, 4u * k)); }
+
+bool bf_shortlist_eligible(const BfIndexDev &ix, uint32_t nq, uint32_t k) {
+    if (!ix.rows_b || !ix.rows_bl || !ix.norm2) return false;
+    if (!(ix.max_norm == ix.max_norm) || std::isinf(ix.max_norm)) return false;
+    if (k == 0 || 4u * k > kShortMax) return false;
+    if ((uint64_t)shortlist_size(k) * 8 > ix.n) return false;   // a shortlist that is most of the data
+    return nq >= env_u32("SCANN_HIP_BF_SHORTLIST_MIN_QUERIES", 32);
+}
+
+template <int TS>
+static int launch_bf16(const BfIndexDev &ix, const BfPass &p, const uint16_t *qb, const uint16_t *qbl,
+                       const float *qn2, hipStream_t st) {
+    const uint32_t ny = ceil_div_u32(p.nq, kB16Waves * 32);
+    const uint32_t ntiles = ceil_div_u32(p.nrows, 32 * kB16Sub);
+    uint32_t want = std::max<uint32_t>(1, (2u * (uint32_t)num_cus()) / ny);
+    want = std::min(want, ntiles);
+    const uint32_t nx = 8u * ceil_div_u32(want, 8);
+    const size_t lds = (size_t)2 * (2 * 32 * kB16Sub * (TS * 16) * 2 + 256);   // two (hi | lo | norms) stages
+    if (ix.measure == SCANN_HIP_DOT_PRODUCT) {
+        SCANN_TRY(set_dyn_lds((bf_bf16_kernel<TS, SCANN_HIP_DOT_PRODUCT>), lds));
+        hipLaunchKernelGGL((bf_bf16_kernel<TS, SCANN_HIP_DOT_PRODUCT>), dim3(nx * ny), dim3(kB16Waves * 64), lds, st,
+                           ix, p, qb, qbl, qn2, nx, ny);
+    } else {
+        SCANN_TRY(set_dyn_lds((bf_bf16_kernel<TS, SCANN_HIP_SQUARED_L2>), lds));
+        hipLaunchKernelGGL((bf_bf16_kernel<TS, SCANN_HIP_SQUARED_L2>), dim3(nx * ny), dim3(kB16Waves * 64), lds, st,
+                           ix, p, qb, qbl, qn2, nx, ny);
+    }
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+static int launch_bf16_pass(const BfIndexDev &ix, const BfPass &p, const uint16_t *qb, const uint16_t *qbl,
+                            const float *qn2, hipStream_t st) {
+    switch (ix.dim / 16) {
+        case 2: return launch_bf16<2>(ix, p, qb, qbl, qn2, st);
+        case 4: return launch_bf16<4>(ix, p, qb, qbl, qn2, st);
+        case 6: return launch_bf16<6>(ix, p, qb, qbl, qn2, st);
+        case 8: return launch_bf16<8>(ix, p, qb, qbl, qn2, st);
+        case 12: return launch_bf16<12>(ix, p, qb, qbl, qn2, st);
+        default: return launch_bf16<16>(ix, p, qb, qbl, qn2, st);
+    }
+}
+
+// bf16 scores -> shortlist of kp rows -> exact re-score -> first k + verification
+static int enqueue_shortlist_search(const BfIndexDev &ix, BfWorkspace &w, uint32_t k, const float *d_queries,
+                                    uint32_t nq, uint32_t q_stride, uint32_t *d_out_idx, float *d_out_dist,
+                                    uint32_t *d_out_count, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    const uint32_t n = (uint32_t)ix.n, kp = shortlist_size(k);
+    const uint32_t ns = std::min(n, kBfSampleRows), rs = n / ns;
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(n, 2ull * kp * rs + 16ull * rs + 256ull);
+    SCANN_TRY(w.q_b.ensure((size_t)nq * ix.dim * 2));
+    SCANN_TRY(w.q_bl.ensure((size_t)nq * ix.dim * 2));
+    SCANN_TRY(w.sl_fail.ensure((size_t)nq * 4));
+    SCANN_TRY(w.q_n2.ensure((size_t)nq * 4));
+    SCANN_TRY(w.sample.ensure((size_t)nq * ns * 4));
+    SCANN_TRY(w.thr.ensure((size_t)nq * 8));
+    SCANN_TRY(w.cand_cnt.ensure((size_t)nq * 4));
+    SCANN_TRY(w.cand.ensure((size_t)nq * cap * 8));
+    SCANN_TRY(w.counters.ensure(BF_CNT_N * 4));
+    SCANN_TRY(w.sl_idx.ensure((size_t)nq * kp * 4));
+    SCANN_TRY(w.sl_approx.ensure((size_t)nq * kp * 4));
+    SCANN_TRY(w.sl_exact.ensure((size_t)nq * kp * 4));
+    SCANN_TRY(w.sl_cnt.ensure((size_t)nq * 4));
+    SCANN_HIP_CHECK(hipMemsetAsync(w.counters.p, 0, BF_CNT_N * 4, st));
+    SCANN_HIP_CHECK(hipMemsetAsync(w.cand_cnt.p, 0, (size_t)nq * 4, st));
+    hipLaunchKernelGGL(bf_to_bf16_kernel, dim3(ceil_div_u32(nq, 256)), dim3(256), 0, st, d_queries, (uint64_t)nq,
+                       ix.dim, q_stride, w.q_b.as<uint16_t>(), w.q_bl.as<uint16_t>(), w.q_n2.as<float>());
+    LAUNCH_CHECK();
+    // 1. bf16 scores of an evenly spaced sample -> bound of the kp-th best bf16 score
+    BfPass a{};
+    a.queries = d_queries;
+    a.nq = nq;
+    a.q_stride = q_stride;
+    a.nrows = ns;
+    a.row_mult = rs;
+    a.filter = 0;
+    a.out = w.sample.as<float>();
+    a.ld = ns;
+    SCANN_TRY(launch_bf16_pass(ix, a, w.q_b.as<uint16_t>(), w.q_bl.as<uint16_t>(), w.q_n2.as<float>(), st));
+    const SelCfg tcfg = sel_cfg(ns);
+    const size_t lds_thr = (size_t)next_pow2_u32(ns) * 8 + (size_t)tcfg.bins * 4 + (size_t)tcfg.list * 8 + 48 * 8;
+    SCANN_TRY(set_dyn_lds(bf_threshold_kernel, lds_thr));
+    hipLaunchKernelGGL(bf_threshold_kernel, dim3(nq), dim3(kBfSelectThreads), lds_thr, st, w.sample.as<float>(),
+                       ns, rs, kp, 0, w.thr.as<uint64_t>(), (uint32_t *)nullptr, (float *)nullptr,
+                       (uint32_t *)nullptr);
+    LAUNCH_CHECK();
+    // 2. bf16 scores of every row, filtered by that bound
+    BfPass b = a;
+    b.nrows = n;
+    b.row_mult = 1;
+    b.filter = 1;
+    b.out = nullptr;
+    b.ld = 0;
+    b.thr = w.thr.as<uint64_t>();
+    b.cand_cnt = w.cand_cnt.as<uint32_t>();
+    b.cand = w.cand.as<uint64_t>();
+    b.cap = cap;
+    if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
+    SCANN_TRY(launch_bf16_pass(ix, b, w.q_b.as<uint16_t>(), w.q_bl.as<uint16_t>(), w.q_n2.as<float>(), st));
+    if (ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
+    // 3. the kp best bf16 scores (sorted): the shortlist
+    const SelCfg scfg = sel_cfg(kBfSortCap);
+    const size_t lds_sel = (size_t)kBfSortCap * 8 + (kBfSelectThreads / 64 + 4) * 4 + (size_t)kBfMaxK * 8 +
+                           (size_t)scfg.bins * 4 + (size_t)scfg.list * 8 + 48 * 8;
+    SCANN_TRY(set_dyn_lds(bf_select_kernel, lds_sel));
+    hipLaunchKernelGGL(bf_select_kernel, dim3(nq), dim3(kBfSelectThreads), lds_sel, st, kp, cap,
+                       w.cand_cnt.as<uint32_t>(), w.cand.as<uint64_t>(), w.counters.as<uint32_t>(),
+                       w.sl_idx.as<uint32_t>(), w.sl_approx.as<float>(), w.sl_cnt.as<uint32_t>());
+    LAUNCH_CHECK();
+    // 4. exact f32 score of the shortlist, 5. first k + verification
+    const size_t lds_rr = (size_t)ix.dim * 4;
+    dim3 grid(ceil_div_u32(kp, 32), nq);
+    if (ix.measure == SCANN_HIP_DOT_PRODUCT) {
+        hipLaunchKernelGGL(bf_rerank_kernel<SCANN_HIP_DOT_PRODUCT>, grid, dim3(256), lds_rr, st, ix, d_queries,
+                           q_stride, kp, w.sl_idx.as<uint32_t>(), w.sl_cnt.as<uint32_t>(), w.sl_exact.as<float>());
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(bf_shortlist_final_kernel<SCANN_HIP_DOT_PRODUCT>, dim3(nq), dim3(64), 0, st, n, k, kp,
+                           ix.max_norm, w.q_n2.as<float>(), w.sl_idx.as<uint32_t>(), w.sl_approx.as<float>(),
+                           w.sl_cnt.as<uint32_t>(), w.sl_exact.as<float>(), w.counters.as<uint32_t>(),
+                           w.sl_fail.as<uint32_t>(), d_out_idx, d_out_dist, d_out_count);
+    } else {
+        hipLaunchKernelGGL(bf_rerank_kernel<SCANN_HIP_SQUARED_L2>, grid, dim3(256), lds_rr, st, ix, d_queries,
+                           q_stride, kp, w.sl_idx.as<uint32_t>(), w.sl_cnt.as<uint32_t>(), w.sl_exact.as<float>());
+        LAUNCH_CHECK();
+        if (ix.measure == SCANN_HIP_L2)
+            hipLaunchKernelGGL(bf_shortlist_final_kernel<SCANN_HIP_L2>, dim3(nq), dim3(64), 0, st, n, k, kp,
+                               ix.max_norm, w.q_n2.as<float>(), w.sl_idx.as<uint32_t>(), w.sl_approx.as<float>(),
+                               w.sl_cnt.as<uint32_t>(), w.sl_exact.as<float>(), w.counters.as<uint32_t>(),
+                               w.sl_fail.as<uint32_t>(), d_out_idx, d_out_dist, d_out_count);
+        else
+            hipLaunchKernelGGL(bf_shortlist_final_kernel<SCANN_HIP_SQUARED_L2>, dim3(nq), dim3(64), 0, st, n, k, kp,
+                               ix.max_norm, w.q_n2.as<float>(), w.sl_idx.as<uint32_t>(), w.sl_approx.as<float>(),
+                               w.sl_cnt.as<uint32_t>(), w.sl_exact.as<float>(), w.counters.as<uint32_t>(),
+                               w.sl_fail.as<uint32_t>(), d_out_idx, d_out_dist, d_out_count);
+    }
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+int bf_last_status(const BfWorkspace &w, hipStream_t st) {
+    if (!w.counters.p) return SCANN_HIP_OK;
+    uint32_t counters[BF_CNT_N];
+    SCANN_HIP_CHECK(hipMemcpyAsync(counters, w.counters.p, sizeof(counters), hipMemcpyDeviceToHost, st));
+    SCANN_HIP_CHECK(hipStreamSynchronize(st));
+    if (counters[BF_CNT_STATUS] == SCANN_HIP_ABORTED)
+        return fail(SCANN_HIP_ABORTED, "a bf16-shortlist result could not be verified: repeat the batch with "
+                                       "opts.bf_exact = 1 (the host entry point does it itself)");
+    if (counters[BF_CNT_STATUS] != SCANN_HIP_OK)
+        return fail((int)counters[BF_CNT_STATUS], "candidate buffer overflow on the device path (use the host "
+                                                  "entry point, which retries with a full-size buffer)");
+    return SCANN_HIP_OK;
+}
+
 int bf_search_device(const BfIndexDev &ix, BfWorkspace &w, const float *d_queries, uint32_t nq,
-                     uint32_t q_stride, uint32_t k, uint32_t *d_out_idx, float *d_out_dist,
+                     uint32_t q_stride, uint32_t k, bool exact_only, uint32_t *d_out_idx, float *d_out_dist,
                      uint32_t *d_out_count, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     if (ix.n == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "empty dataset on the device path");
     BfPlan pl;
     SCANN_TRY(make_plan(ix, k, false, &pl));
     if (pl.k != k)
         return fail(SCANN_HIP_INVALID_ARGUMENT, "k > dataset size on the device path (row pitch)");
+    if (!exact_only && bf_shortlist_eligible(ix, nq, k))
+        return enqueue_shortlist_search(ix, w, k, d_queries, nq, q_stride, d_out_idx, d_out_dist, d_out_count, st,
+                                        ev0, ev1);
     SCANN_TRY(ensure_ws(ix, w, nq, pl, false, q_stride, false));
     return enqueue_search(ix, w, pl, d_queries, nq, q_stride, d_out_idx, d_out_dist, d_out_count, st,
                           ev0, ev1);
 }
 
 int bf_search_host(const BfIndexDev &ix, BfWorkspace &w, const float *queries, uint32_t nq,
-                   uint32_t q_stride, uint32_t k, uint32_t *out_idx, float *out_dist,
+                   uint32_t q_stride, uint32_t k, bool exact_only, uint32_t *out_idx, float *out_dist,
                    uint32_t *out_count, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    // attempt 0: bf16 shortlist (if the search qualifies); 1: exact kernels; 2: exact, full buffers
+    const uint32_t kk = (uint32_t)std::min<uint64_t>(k, ix.n);
+    for (int attempt = (!exact_only && bf_shortlist_eligible(ix, nq, kk) && kk == k) ? 0 : 1; attempt < 3;
+         ++attempt) {
         BfPlan pl;
-        SCANN_TRY(make_plan(ix, k, attempt == 1, &pl));
+        SCANN_TRY(make_plan(ix, k, attempt == 2, &pl));
         SCANN_TRY(ensure_ws(ix, w, nq, pl, true, q_stride, true));
         SCANN_HIP_CHECK(hipMemcpyAsync(w.queries.p, queries, (size_t)nq * q_stride * 4,
                                        hipMemcpyHostToDevice, st));
-        SCANN_TRY(enqueue_search(ix, w, pl, w.queries.as<float>(), nq, q_stride,
-                                 w.out_idx.as<uint32_t>(), w.out_dist.as<float>(),
-                                 w.out_count.as<uint32_t>(), st, ev0, ev1));
+        if (attempt == 0)
+            SCANN_TRY(enqueue_shortlist_search(ix, w, k, w.queries.as<float>(), nq, q_stride,
+                                               w.out_idx.as<uint32_t>(), w.out_dist.as<float>(),
+                                               w.out_count.as<uint32_t>(), st, ev0, ev1));
+        else
+            SCANN_TRY(enqueue_search(ix, w, pl, w.queries.as<float>(), nq, q_stride,
+                                     w.out_idx.as<uint32_t>(), w.out_dist.as<float>(),
+                                     w.out_count.as<uint32_t>(), st, ev0, ev1));
         uint32_t counters[BF_CNT_N];
         SCANN_HIP_CHECK(hipMemcpyAsync(counters, w.counters.p, sizeof(counters), hipMemcpyDeviceToHost, st));
         std::vector<uint32_t> ti((size_t)nq * pl.k);
@@ -857,8 +1390,39 @@ int bf_search_host(const BfIndexDev &ix, BfWorkspace &w, const float *queries, u
                 }
             return SCANN_HIP_OK;
         }
-        if (counters[BF_CNT_STATUS] != SCANN_HIP_RESOURCE_EXHAUSTED || attempt == 1)
-            return fail((int)counters[BF_CNT_STATUS], "device reported a search failure");
+        if (attempt == 0 && counters[BF_CNT_STATUS] == SCANN_HIP_ABORTED) {
+            // shortlist results that could not be proven exact: only those queries go through the
+            // exact kernels again
+            std::vector<uint32_t> flags(nq);
+            SCANN_HIP_CHECK(hipMemcpy(flags.data(), w.sl_fail.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+            std::vector<uint32_t> redo;
+            for (uint32_t q = 0; q < nq; ++q) {
+                if (flags[q]) {
+                    redo.push_back(q);
+                    continue;
+                }
+                for (uint32_t i = 0; i < k; ++i) {
+                    out_idx[(size_t)q * k + i] = i < pl.k ? ti[(size_t)q * pl.k + i] : kBfInvalid;
+                    out_dist[(size_t)q * k + i] = i < pl.k ? td[(size_t)q * pl.k + i] : INFINITY;
+                }
+            }
+            const uint32_t nr = (uint32_t)redo.size();
+            std::vector<float> sub((size_t)nr * q_stride);
+            for (uint32_t r = 0; r < nr; ++r)
+                std::memcpy(&sub[(size_t)r * q_stride], queries + (size_t)redo[r] * q_stride, (size_t)q_stride * 4);
+            std::vector<uint32_t> ri((size_t)nr * k), rc(nr);
+            std::vector<float> rd((size_t)nr * k);
+            SCANN_TRY(bf_search_host(ix, w, sub.data(), nr, q_stride, k, true, ri.data(), rd.data(), rc.data(), st,
+                                     nullptr, nullptr));
+            for (uint32_t r = 0; r < nr; ++r) {
+                std::memcpy(out_idx + (size_t)redo[r] * k, &ri[(size_t)r * k], (size_t)k * 4);
+                std::memcpy(out_dist + (size_t)redo[r] * k, &rd[(size_t)r * k], (size_t)k * 4);
+                out_count[redo[r]] = rc[r];
+            }
+            return SCANN_HIP_OK;
+        }
+        const bool retry = (attempt == 0) || (attempt == 1 && counters[BF_CNT_STATUS] == SCANN_HIP_RESOURCE_EXHAUSTED);
+        if (!retry) return fail((int)counters[BF_CNT_STATUS], "device reported a search failure");
     }
     return fail(SCANN_HIP_INTERNAL, "unreachable");
 }

@@ -75,6 +75,7 @@ class SearchOpts(C.Structure):
         ("tokens", u32p), ("token_dists", f32p),
         ("cand_idx", u32p), ("cand_dist", f32p), ("cand_count", u32p),
         ("allow_bitmap", u64p), ("allow_bitmap_bits", C.c_uint64),
+        ("bf_exact", C.c_int32),
     ]
 
 

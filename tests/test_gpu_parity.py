@@ -672,3 +672,71 @@ def test_txh_resident_scan_two_big_leaves(force_resident):
     for i in range(0, nq, 9):
         H.check_txh_query(oix, q[i], k, idx[i, :cnt[i]], dist[i, :cnt[i]], tok[i], tokd[i],
                           ci[i, :cc[i]], cd[i, :cc[i]], what="res txh q%d" % i)
+
+
+# ---- bf16 shortlist path of the brute-force searcher ----------------------------------------------
+@pytest.fixture
+def force_shortlist(monkeypatch):
+    """The bf16-shortlist path is taken by big batches on big indexes; these knobs select it for
+    small test cases (read at index creation / per search)."""
+    monkeypatch.setenv("SCANN_HIP_BF_SHORTLIST_MIN_ROWS", "1")
+    monkeypatch.setenv("SCANN_HIP_BF_SHORTLIST_MIN_QUERIES", "1")
+
+
+@pytest.mark.parametrize("measure", [hip.DOT_PRODUCT, hip.SQUARED_L2, hip.L2])
+@pytest.mark.parametrize("n,dim,k,nq", [(20000, 128, 10, 40), (9000, 64, 3, 130), (30000, 96, 16, 33), (5000, 32, 1, 7),
+                                        (12000, 256, 10, 20)])
+def test_bf_shortlist_matches_oracle(force_shortlist, measure, n, dim, k, nq):
+    """bf16 MFMA scores shortlist 4k rows, the reference's f32 arithmetic re-scores them, an error
+    bound proves nothing else can enter the top k: results bit-identical to the oracle."""
+    rows = synth.uniform_f32(n, dim, 42)
+    data, stride = orc.to_strided(rows)
+    index = hip.bf_create(data, n, dim, stride, measure)
+    index.enable_timing(True)
+    q = synth.uniform_f32(nq, dim, 123)
+    idx, dist, cnt = index.search_batched(q, k)
+    assert index.last_kernel_ms()[1] == "bf_bf16_kernel"
+    for i in range(nq):
+        oi, od = orc.bf_search(data, n, dim, stride, measure, q[i], k)
+        assert cnt[i] == oi.size
+        H.assert_topk_equal_up_to_ties(idx[i, :cnt[i]], dist[i, :cnt[i]], oi, od, what="sl q%d" % i)
+    o = hip.default_opts()
+    o.bf_exact = 1
+    idx2, dist2, _ = index.search_batched(q, k, o)      # the exact kernels give the same rows
+    assert np.array_equal(bits(dist2), bits(dist))
+
+
+@pytest.mark.parametrize("measure", [hip.DOT_PRODUCT, hip.SQUARED_L2])
+def test_bf_shortlist_unverifiable_falls_back(force_shortlist, measure):
+    """Near-duplicate rows: bf16 scores cannot separate them, the verification fails, the host
+    entry point repeats the batch on the exact kernels (device entry: status Aborted)."""
+    import ctypes
+    import torch
+    n, dim, k, nq = 8000, 64, 10, 48
+    base = synth.uniform_f32(1, dim, 5)
+    rows = (base + np.float32(1e-4) * synth.uniform_f32(n, dim, 6)).astype(np.float32)
+    data, stride = orc.to_strided(rows)
+    index = hip.bf_create(data, n, dim, stride, measure)
+    q = synth.uniform_f32(nq, dim, 7)
+    idx, dist, cnt = index.search_batched(q, k)
+    for i in range(0, nq, 5):
+        oi, od = orc.bf_search(data, n, dim, stride, measure, q[i], k)
+        H.assert_topk_equal_up_to_ties(idx[i], dist[i], oi, od, what="dup q%d" % i)
+    dev = torch.device("cuda", 0)
+    qd = torch.from_numpy(q).to(dev)
+    oi_t = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    od_t = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    oc_t = torch.empty((nq,), dtype=torch.int32, device=dev)
+    sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    L = hip.load()
+    hip.check(L.scann_hip_search_batched_device(index.h, p(qd), nq, dim, k, None, p(oi_t), p(od_t), p(oc_t), sp))
+    with pytest.raises(hip.ScannError) as e:
+        hip.check(L.scann_hip_index_last_device_status(index.h, sp))
+    assert e.value.code == 10     # Aborted: repeat with bf_exact = 1
+    o = hip.default_opts()
+    o.bf_exact = 1
+    hip.check(L.scann_hip_search_batched_device(index.h, p(qd), nq, dim, k, ctypes.byref(o), p(oi_t), p(od_t),
+                                                p(oc_t), sp))
+    hip.check(L.scann_hip_index_last_device_status(index.h, sp))
+    assert np.array_equal(bits(od_t.cpu().numpy()), bits(dist))

@@ -8,7 +8,7 @@ for w in ah bf_dot; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d $O/pmc_${w}_$c -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-recall > $O/pmc_${w}_$c.log 2>&1
     cp $(find $O/pmc_${w}_$c -name "*counter_collection.csv" | head -1) $O/r01_e_pmc_${w}_$c.csv
-    python3 tools/pmc_summary.py $O/r01_e_pmc_${w}_$c.csv $( [ $w = ah ] && echo adc_scan_res_kernel || echo bf_mfma_dot_kernel )
+    python3 tools/pmc_summary.py $O/r01_e_pmc_${w}_$c.csv $( [ $w = ah ] && echo adc_scan_res_kernel || echo bf_bf16_kernel )
   done
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_txh -- python3 bench.py --workload txh --dist clustered --partitions-to-search 10 --pre-reorder-k 1000 --steps 20 --no-cpu-baseline --no-recall > $O/ks_txh.log 2>&1
