@@ -482,8 +482,16 @@ __global__ __launch_bounds__(256) void assign_nearest_kernel(BfIndexDev ix, cons
 // status Aborted (and a per-query flag) and are repeated on the exact kernels (bf_search_host does
 // it itself).  Accepted results are bit-identical to the exact path: same arithmetic, same rows.
 // =====================================================================================
-constexpr float kBf16DotErr = 7.5e-5f;     // 3 u^2 (1 + u) + 3 K 2^-24 slack, K <= 256, rounded up
-constexpr float kF32SqErr = 6.0e-5f;       // f32 rounding of norms / the squared-distance identity
+// |q.x - (qh.xh + qh.xl + ql.xh)| <= c(dim) |q||x| for EVERY row, with u = 2^-8:
+//   dropped terms  ql.xl + qh.ex + eq.x (+ O(u^3))        <= 3.1 u^2 |q||x|
+//   f32 accumulation of the 3 dim exact products (one rounding each, <= 2^-23 relative to the
+//   running magnitude, which covers truncating alignment) and of the exact path itself
+//                                                          <= (3 dim + 64) 2^-23 |q||x|
+static inline float shortlist_dot_err(uint32_t dim) {
+    return 1.01f * (3.1f / 65536.0f + (3.0f * (float)dim + 64.0f) / 8388608.0f);
+}
+constexpr float kF32SqErr = 6.0e-5f;       // f32 rounding of the norms, of |q|^2 + |x|^2 - 2 q.x and of the
+                                           // exact (q - x)^2 sum, relative to |q|^2 + |x|^2 (dim <= 256)
 constexpr uint32_t kShortMax = 256;        // largest shortlist per query
 
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
@@ -749,7 +757,7 @@ __global__ __launch_bounds__(256) void bf_rerank_kernel(BfIndexDev ix, const flo
 // per query (one wave): sort the shortlist by (exact, index), emit the first k, verify.
 template <int MEASURE>
 __global__ __launch_bounds__(64) void bf_shortlist_final_kernel(
-    uint32_t n, uint32_t k, uint32_t kp, float max_norm, const float *__restrict__ qn2,
+    uint32_t n, uint32_t k, uint32_t kp, float max_norm, float dot_err, const float *__restrict__ qn2,
     const uint32_t *__restrict__ sl_idx, const float *__restrict__ sl_approx,
     const uint32_t *__restrict__ sl_cnt, const float *__restrict__ sl_exact,
     uint32_t *__restrict__ counters, uint32_t *__restrict__ fail_flag, uint32_t *__restrict__ out_idx,
@@ -784,8 +792,8 @@ __global__ __launch_bounds__(64) void bf_shortlist_final_kernel(
             const float dk = ordered_to_f32((uint32_t)(skeys[k - 1] >> 32));   // k-th exact (squared for L2)
             const float qn = sqrtf(qn2[q]);
             float E;
-            if (MEASURE == SCANN_HIP_DOT_PRODUCT) E = kBf16DotErr * qn * max_norm;
-            else E = 2.0f * kBf16DotErr * qn * max_norm + kF32SqErr * (qn * qn + max_norm * max_norm);
+            if (MEASURE == SCANN_HIP_DOT_PRODUCT) E = dot_err * qn * max_norm;
+            else E = 2.0f * dot_err * qn * max_norm + kF32SqErr * (qn * qn + max_norm * max_norm);
             ok = dk < floor_b - E * 1.0001f;         // NaNs compare false -> exact path
         }
         fail_flag[q] = ok ? 0u : 1u;
@@ -1302,7 +1310,7 @@ static int enqueue_shortlist_search(const BfIndexDev &ix, BfWorkspace &w, uint32
                            q_stride, kp, w.sl_idx.as<uint32_t>(), w.sl_cnt.as<uint32_t>(), w.sl_exact.as<float>());
         LAUNCH_CHECK();
         hipLaunchKernelGGL(bf_shortlist_final_kernel<SCANN_HIP_DOT_PRODUCT>, dim3(nq), dim3(64), 0, st, n, k, kp,
-                           ix.max_norm, w.q_n2.as<float>(), w.sl_idx.as<uint32_t>(), w.sl_approx.as<float>(),
+                           ix.max_norm, shortlist_dot_err(ix.dim), w.q_n2.as<float>(), w.sl_idx.as<uint32_t>(), w.sl_approx.as<float>(),
                            w.sl_cnt.as<uint32_t>(), w.sl_exact.as<float>(), w.counters.as<uint32_t>(),
                            w.sl_fail.as<uint32_t>(), d_out_idx, d_out_dist, d_out_count);
     } else {
@@ -1311,12 +1319,12 @@ static int enqueue_shortlist_search(const BfIndexDev &ix, BfWorkspace &w, uint32
         LAUNCH_CHECK();
         if (ix.measure == SCANN_HIP_L2)
             hipLaunchKernelGGL(bf_shortlist_final_kernel<SCANN_HIP_L2>, dim3(nq), dim3(64), 0, st, n, k, kp,
-                               ix.max_norm, w.q_n2.as<float>(), w.sl_idx.as<uint32_t>(), w.sl_approx.as<float>(),
+                               ix.max_norm, shortlist_dot_err(ix.dim), w.q_n2.as<float>(), w.sl_idx.as<uint32_t>(), w.sl_approx.as<float>(),
                                w.sl_cnt.as<uint32_t>(), w.sl_exact.as<float>(), w.counters.as<uint32_t>(),
                                w.sl_fail.as<uint32_t>(), d_out_idx, d_out_dist, d_out_count);
         else
             hipLaunchKernelGGL(bf_shortlist_final_kernel<SCANN_HIP_SQUARED_L2>, dim3(nq), dim3(64), 0, st, n, k, kp,
-                               ix.max_norm, w.q_n2.as<float>(), w.sl_idx.as<uint32_t>(), w.sl_approx.as<float>(),
+                               ix.max_norm, shortlist_dot_err(ix.dim), w.q_n2.as<float>(), w.sl_idx.as<uint32_t>(), w.sl_approx.as<float>(),
                                w.sl_cnt.as<uint32_t>(), w.sl_exact.as<float>(), w.counters.as<uint32_t>(),
                                w.sl_fail.as<uint32_t>(), d_out_idx, d_out_dist, d_out_count);
     }

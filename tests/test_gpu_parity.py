@@ -740,3 +740,36 @@ def test_bf_shortlist_unverifiable_falls_back(force_shortlist, measure):
                                                 p(oc_t), sp))
     hip.check(L.scann_hip_index_last_device_status(index.h, sp))
     assert np.array_equal(bits(od_t.cpu().numpy()), bits(dist))
+
+
+def test_bf_shortlist_error_bound_holds(force_shortlist):
+    """The verification relies on |split-bf16 score - exact| <= E for every row.  Restate the
+    split-bf16 score on the CPU (f64 sum of the three product groups) for adversarial magnitudes
+    and check it against the bound; the GPU's f32 accumulation is covered by the bound's second
+    term, checked through the GPU result staying exact on the same data."""
+    dim, n = 128, 4096
+    rng = np.random.default_rng(3)
+    rows = (rng.standard_normal((n, dim)) * np.exp(rng.uniform(-6, 6, (n, 1)))).astype(np.float32)
+    q = (rng.standard_normal((8, dim)) * 100).astype(np.float32)
+
+    def bf16(x):
+        u = x.view(np.uint32).astype(np.uint64)
+        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+        return r.astype(np.uint32).view(np.float32)
+
+    xh = bf16(rows); xl = bf16(rows - xh)
+    qh = bf16(q); ql = bf16(q - qh)
+    approx = (qh.astype(np.float64) @ xh.T.astype(np.float64) + qh.astype(np.float64) @ xl.T.astype(np.float64)
+              + ql.astype(np.float64) @ xh.T.astype(np.float64))
+    exact = q.astype(np.float64) @ rows.T.astype(np.float64)
+    c = 1.01 * (3.1 / 65536 + (3 * dim + 64) / 8388608)
+    bound = c * np.linalg.norm(q.astype(np.float64), axis=1)[:, None] * np.linalg.norm(rows.astype(np.float64), axis=1)[None, :]
+    assert np.all(np.abs(approx - exact) <= bound)
+    assert np.abs(approx - exact).max() <= 0.5 * bound.max()        # the dropped-terms part alone: slack for f32
+    data, stride = orc.to_strided(rows)
+    for measure in (hip.DOT_PRODUCT, hip.SQUARED_L2):
+        index = hip.bf_create(data, n, dim, stride, measure)
+        idx, dist, cnt = index.search_batched(np.tile(q, (5, 1)), 10)
+        for i in range(8):
+            oi, od = orc.bf_search(data, n, dim, stride, measure, q[i], 10)
+            H.assert_topk_equal_up_to_ties(idx[i], dist[i], oi, od, what="scaled q%d" % i)
