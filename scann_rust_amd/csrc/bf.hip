@@ -530,6 +530,27 @@ __global__ void bf_to_bf16_kernel(const float *__restrict__ src, uint64_t n, uin
     norm2[i] = s2;
 }
 
+// queries -> split bf16 + squared norms, one WAVE per query (a batch has few rows: the row-per-
+// thread kernel above would run on a handful of threads)
+__global__ __launch_bounds__(256) void bf_q_prep_kernel(const float *__restrict__ src, uint32_t nq, uint32_t dim,
+                                                        uint32_t stride, uint16_t *__restrict__ dst_hi,
+                                                        uint16_t *__restrict__ dst_lo, float *__restrict__ norm2) {
+    const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (q >= nq) return;
+    const float *row = src + (size_t)q * stride;
+    float s2 = 0.0f;
+    for (uint32_t j = lane; j < dim; j += 64) {
+        const float v = row[j];
+        s2 = s2 + v * v;
+        const uint16_t bh = f32_to_bf16_rne(v);
+        dst_hi[(size_t)q * dim + j] = bh;
+        dst_lo[(size_t)q * dim + j] = f32_to_bf16_rne(v - bf16_bits_to_f32(bh));
+    }
+    for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+    // upper bound of |q|^2 is what the error bound needs: one ulp of slack for the tree order
+    if (lane == 0) norm2[q] = s2 * 1.0000002f;
+}
+
 __global__ void bf_max_norm_kernel(const float *__restrict__ norm2, uint64_t n, uint32_t *__restrict__ out_bits) {
     float m = 0.0f;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -1258,8 +1279,8 @@ static int enqueue_shortlist_search(const BfIndexDev &ix, BfWorkspace &w, uint32
     SCANN_TRY(w.sl_cnt.ensure((size_t)nq * 4));
     SCANN_HIP_CHECK(hipMemsetAsync(w.counters.p, 0, BF_CNT_N * 4, st));
     SCANN_HIP_CHECK(hipMemsetAsync(w.cand_cnt.p, 0, (size_t)nq * 4, st));
-    hipLaunchKernelGGL(bf_to_bf16_kernel, dim3(ceil_div_u32(nq, 256)), dim3(256), 0, st, d_queries, (uint64_t)nq,
-                       ix.dim, q_stride, w.q_b.as<uint16_t>(), w.q_bl.as<uint16_t>(), w.q_n2.as<float>());
+    hipLaunchKernelGGL(bf_q_prep_kernel, dim3(ceil_div_u32(nq, 4)), dim3(256), 0, st, d_queries, nq, ix.dim,
+                       q_stride, w.q_b.as<uint16_t>(), w.q_bl.as<uint16_t>(), w.q_n2.as<float>());
     LAUNCH_CHECK();
     // 1. bf16 scores of an evenly spaced sample -> bound of the kp-th best bf16 score
     BfPass a{};
