@@ -100,7 +100,19 @@ int scann_hip_bf_create(scann_hip_ctx *ctx, const float *data, uint64_t n, uint3
  * Multi-GPU leaf sharding (one process per GPU): each rank passes only the leaves
  * it owns (unowned leaves have zero local length) plus leaf_sizes_global, so every
  * rank derives identical merge keys; data then holds only the local rows in CSR row
- * order (data_is_csr_order = 1).  leaf_sizes_global == NULL means unsharded. */
+ * order (data_is_csr_order = 1).  leaf_sizes_global == NULL means unsharded.
+ *
+ * Scann facade modes (scann.rs:181-294) are configurations of the same index:
+ *   SearchMode::TreeAH       use_residuals = 0, codebook trained on the raw rows, searched with
+ *                            pre_reorder_k = k (and exact_reorder = 0, or 1 for the exact
+ *                            reordering of the k-truncated list, scann.rs:199-209);
+ *   SearchMode::Hashed       num_partitions = 0, same options;
+ *   SearchMode::Partitioned  codebook == NULL && codes == NULL && num_subspaces == 0: every row
+ *                            of the selected leaves is scored exactly with distance_measure
+ *                            (search_partitioned, scann.rs:213-252); needs data, unsharded.
+ * distance_measure (SCANN_HIP_SQUARED_L2 = 0 / L2 / DOT_PRODUCT) is the measure of the exact
+ * re-ordering (ReorderingHelper, utils/reordering.rs:23-54) and of the Partitioned scan;
+ * TreeXHybridSearcher and AsymmetricHasher always re-rank by squared L2 (mod.rs:350-358). */
 typedef struct {
     const float *data;
     uint64_t n_rows;
@@ -123,6 +135,7 @@ typedef struct {
     int32_t use_residuals;            /* TreeXHybridConfig.use_residuals (mod.rs:31) */
     uint32_t partitions_to_search;    /* TreeXHybridConfig.partitions_to_search (mod.rs:27) */
     float pre_reorder_multiplier;     /* TreeXHybridConfig.pre_reorder_multiplier (mod.rs:33) */
+    int32_t distance_measure;         /* ScannConfig.distance_measure (config.rs:32-36); 0 = SquaredL2 */
 } scann_hip_txh_desc;
 
 /* Replaces the search side of TreeXHybridSearcher::build / AsymmetricHasher::build.

@@ -119,6 +119,16 @@ def lib():
                                             u32p, f32p, u32p, C.c_int]
         L.or_reorder.restype = sz
         L.or_reorder.argtypes = [f32p, sz, sz, f32p, u32p, sz, sz, u32p, f32p]
+        L.or_measure_distance.restype = C.c_float
+        L.or_measure_distance.argtypes = [C.c_int, f32p, f32p, sz]
+        L.or_reorder_measure.restype = sz
+        L.or_reorder_measure.argtypes = [f32p, sz, sz, C.c_int, f32p, u32p, sz, sz, u32p, f32p]
+        L.or_scann_search_partitioned.restype = C.c_int
+        L.or_scann_search_partitioned.argtypes = [f32p, sz, sz, u32p, u32p, f32p, sz, C.c_int, f32p, sz, sz,
+                                                  u32p, f32p]
+        L.or_scann_search_tree_ah.restype = C.c_int
+        L.or_scann_search_tree_ah.argtypes = [f32p, sz, sz, u32p, u32p, f32p, sz, sz, sz, u8p, f32p, sz,
+                                              C.c_int, C.c_int, f32p, sz, sz, u32p, f32p]
         L.or_exact_ground_truth.argtypes = [f32p, sz, sz, sz, f32p, sz, sz, sz, u32p, C.c_int]
         L.or_max_threads.restype = C.c_int
         _lib = L
@@ -481,6 +491,41 @@ def reorder(data, stride, dim, q, cand_idx, k):
     oi = np.empty(max(n, 1), np.uint32); od = np.empty(max(n, 1), np.float32)
     r = lib().or_reorder(pd, stride, dim, pq, pc, n, k, oi.ctypes.data_as(u32p),
                          od.ctypes.data_as(f32p))
+    return oi[:r].copy(), od[:r].copy()
+
+
+def reorder_measure(data, stride, dim, measure, q, cand_idx, k):
+    """ReorderingHelper::reorder with the configured measure (utils/reordering.rs:23-54)."""
+    data, pd = _f(data); q, pq = _f(q); cand_idx, pc = _u32(cand_idx)
+    n = cand_idx.size
+    oi = np.empty(max(n, 1), np.uint32); od = np.empty(max(n, 1), np.float32)
+    r = lib().or_reorder_measure(pd, stride, dim, measure, pq, pc, n, k, oi.ctypes.data_as(u32p),
+                                 od.ctypes.data_as(f32p))
+    return oi[:r].copy(), od[:r].copy()
+
+
+def scann_search_partitioned(centers, leaf_off, leaf_ids, data, stride, measure, q, P, k):
+    """Scann::search_partitioned (scann.rs:213-252)."""
+    centers, pc = _f(centers); data, pd = _f(data); q, pq = _f(q)
+    leaf_off, po = _u32(leaf_off); leaf_ids, pi = _u32(leaf_ids)
+    L, dim = centers.shape
+    oi = np.empty(max(k, 1), np.uint32); od = np.empty(max(k, 1), np.float32)
+    r = lib().or_scann_search_partitioned(pc, L, dim, po, pi, pd, stride, measure, pq, P, k,
+                                          oi.ctypes.data_as(u32p), od.ctypes.data_as(f32p))
+    return oi[:r].copy(), od[:r].copy()
+
+
+def scann_search_tree_ah(centers, leaf_off, leaf_ids, codebook, codes, data, stride, measure, reorder, q, P, k):
+    """Scann::search_tree_ah (scann.rs:255-294) + the exact reordering of search_impl (:199-209);
+    codes [n][S] by datapoint index."""
+    centers, pc = _f(centers); data, pd = _f(data); q, pq = _f(q); codebook, pb = _f(codebook)
+    leaf_off, po = _u32(leaf_off); leaf_ids, pi = _u32(leaf_ids); codes, pcd = _u8(codes)
+    L, dim = centers.shape
+    S, K, dsub = codebook.shape
+    oi = np.empty(max(k, 1), np.uint32); od = np.empty(max(k, 1), np.float32)
+    r = lib().or_scann_search_tree_ah(pc, L, dim, po, pi, pb, S, K, dsub, pcd, pd, stride, measure,
+                                      1 if reorder else 0, pq, P, k, oi.ctypes.data_as(u32p),
+                                      od.ctypes.data_as(f32p))
     return oi[:r].copy(), od[:r].copy()
 
 

@@ -903,6 +903,99 @@ int or_txh_search_batched(const or_txh_index *ix, const float *queries, size_t n
     return err;
 }
 
+/* ------------------------------------------------------------------------ */
+/* Scann facade modes: scann.rs:181-294                                     */
+/* ------------------------------------------------------------------------ */
+float or_measure_distance(int measure, const float *a, const float *b, size_t dim) {
+    if (measure == OR_DOT_PRODUCT) return -or_dot_product_avx2(a, b, dim); /* one_to_one.rs:464-469 */
+    float d = or_squared_l2_avx2(a, b, dim);                               /* :162-171 */
+    return measure == OR_L2 ? sqrtf(d) : d;                                /* :156-158 */
+}
+
+size_t or_reorder_measure(const float *data, size_t stride, size_t dim, int measure, const float *q,
+                          const uint32_t *cand_idx, size_t n_cand, size_t k, uint32_t *out_idx,
+                          float *out_dist) {
+    pair_t *c = (pair_t *)malloc((n_cand ? n_cand : 1) * sizeof(pair_t));
+    for (size_t i = 0; i < n_cand; ++i) { /* reordering.rs:35-44 */
+        c[i].idx = cand_idx[i];
+        c[i].dist = or_measure_distance(measure, q, data + (size_t)cand_idx[i] * stride, dim);
+    }
+    sort_pairs(c, n_cand);                 /* :47-50 */
+    size_t r = n_cand < k ? n_cand : k;    /* :53 */
+    for (size_t i = 0; i < r; ++i) {
+        out_idx[i] = c[i].idx;
+        out_dist[i] = c[i].dist;
+    }
+    free(c);
+    return r;
+}
+
+int or_scann_search_partitioned(const float *centers, size_t L, size_t dim, const uint32_t *leaf_off,
+                                const uint32_t *leaf_ids, const float *data, size_t stride, int measure,
+                                const float *q, size_t P, size_t k, uint32_t *out_idx, float *out_dist) {
+    uint32_t *tokens = (uint32_t *)malloc((L ? L : 1) * sizeof(uint32_t));
+    float *tdist = (float *)malloc((L ? L : 1) * sizeof(float));
+    size_t np = or_partition(centers, L, dim, q, P, tokens, tdist); /* scann.rs:222-225 */
+    size_t total = 0;
+    for (size_t t = 0; t < np; ++t) total += leaf_off[tokens[t] + 1] - leaf_off[tokens[t]];
+    pair_t *c = (pair_t *)malloc((total ? total : 1) * sizeof(pair_t));
+    size_t o = 0;
+    for (size_t t = 0; t < np; ++t) /* :228-233 candidates in token order, then leaf order */
+        for (uint32_t r = leaf_off[tokens[t]]; r < leaf_off[tokens[t] + 1]; ++r) {
+            c[o].idx = leaf_ids[r];
+            c[o].dist = or_measure_distance(measure, q, data + (size_t)leaf_ids[r] * stride, dim); /* :237-246 */
+            ++o;
+        }
+    sort_pairs(c, total);                  /* :249 */
+    size_t r = total < k ? total : k;      /* :250 */
+    for (size_t i = 0; i < r; ++i) {
+        out_idx[i] = c[i].idx;
+        out_dist[i] = c[i].dist;
+    }
+    free(c);
+    free(tokens);
+    free(tdist);
+    return (int)r;
+}
+
+int or_scann_search_tree_ah(const float *centers, size_t L, size_t dim, const uint32_t *leaf_off,
+                            const uint32_t *leaf_ids, const float *codebook, size_t S, size_t K,
+                            size_t dsub, const uint8_t *codes, const float *data, size_t stride,
+                            int measure, int reorder, const float *q, size_t P, size_t k,
+                            uint32_t *out_idx, float *out_dist) {
+    uint32_t *tokens = (uint32_t *)malloc((L ? L : 1) * sizeof(uint32_t));
+    float *tdist = (float *)malloc((L ? L : 1) * sizeof(float));
+    size_t np = or_partition(centers, L, dim, q, P, tokens, tdist); /* scann.rs:266-269 */
+    size_t total = 0;
+    for (size_t t = 0; t < np; ++t) total += leaf_off[tokens[t] + 1] - leaf_off[tokens[t]];
+    pair_t *c = (pair_t *)malloc((total ? total : 1) * sizeof(pair_t));
+    float *lut = (float *)malloc(S * K * sizeof(float));
+    or_lut_from_query(codebook, S, K, dsub, q, lut); /* :277-280: the same table for every token */
+    size_t o = 0;
+    for (size_t t = 0; t < np; ++t)
+        for (uint32_t r = leaf_off[tokens[t]]; r < leaf_off[tokens[t] + 1]; ++r) { /* :282-286 */
+            c[o].idx = leaf_ids[r];
+            c[o].dist = or_lut_distance(lut, S, K, codes + (size_t)leaf_ids[r] * S);
+            ++o;
+        }
+    sort_pairs(c, total);                  /* :291 */
+    size_t r = total < k ? total : k;      /* :292 */
+    if (reorder) {                         /* scann.rs:199-209 on the truncated list */
+        for (size_t i = 0; i < r; ++i)
+            c[i].dist = or_measure_distance(measure, q, data + (size_t)c[i].idx * stride, dim);
+        sort_pairs(c, r);
+    }
+    for (size_t i = 0; i < r; ++i) {
+        out_idx[i] = c[i].idx;
+        out_dist[i] = c[i].dist;
+    }
+    free(lut);
+    free(c);
+    free(tokens);
+    free(tdist);
+    return (int)r;
+}
+
 /* bin/ann_benchmark.rs:427-450: sequential scalar squared_l2, stable sort, take k. */
 void or_exact_ground_truth(const float *train, size_t n, size_t dim, size_t stride,
                            const float *queries, size_t nq, size_t q_stride, size_t k,

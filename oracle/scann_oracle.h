@@ -177,6 +177,29 @@ size_t or_reorder(const float *data, size_t stride, size_t dim, const float *q,
                   const uint32_t *cand_idx, size_t n_cand, size_t k,
                   uint32_t *out_idx, float *out_dist);
 
+/* ---- Scann facade modes (scann.rs:181-294) -------------------------------------------- */
+/* DistanceMeasure::distance for dense f32 (distance_measures/mod.rs:70-81 ->
+ * one_to_one.rs:156-171, 320-345, 464-469 -> simd/dispatch.rs single-pair kernels). */
+float or_measure_distance(int measure, const float *a, const float *b, size_t dim);
+/* ReorderingHelper::reorder (utils/reordering.rs:23-54) with the configured measure. */
+size_t or_reorder_measure(const float *data, size_t stride, size_t dim, int measure, const float *q,
+                          const uint32_t *cand_idx, size_t n_cand, size_t k, uint32_t *out_idx,
+                          float *out_dist);
+/* Scann::search_partitioned (scann.rs:213-252): rows of the P nearest leaves (token order, then
+ * leaf order), exact distance by `measure`, stable sort, first k.  leaf_ids[leaf_off[l]..] are the
+ * datapoint indices of leaf l.  Returns the count. */
+int or_scann_search_partitioned(const float *centers, size_t L, size_t dim, const uint32_t *leaf_off,
+                                const uint32_t *leaf_ids, const float *data, size_t stride, int measure,
+                                const float *q, size_t P, size_t k, uint32_t *out_idx, float *out_dist);
+/* Scann::search_tree_ah (scann.rs:255-294): one non-residual table for the query, every row of the
+ * P nearest leaves scored by it, stable sort, first k; codes [n][S] by datapoint index.
+ * reorder != 0: search_impl's exact reordering of the k-truncated list (scann.rs:199-209). */
+int or_scann_search_tree_ah(const float *centers, size_t L, size_t dim, const uint32_t *leaf_off,
+                            const uint32_t *leaf_ids, const float *codebook, size_t S, size_t K,
+                            size_t dsub, const uint8_t *codes, const float *data, size_t stride,
+                            int measure, int reorder, const float *q, size_t P, size_t k,
+                            uint32_t *out_idx, float *out_dist);
+
 /* harness helpers: bin/ann_benchmark.rs:427-471 */
 void or_exact_ground_truth(const float *train, size_t n, size_t dim, size_t stride,
                            const float *queries, size_t nq, size_t q_stride,

@@ -238,17 +238,27 @@ int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_
     if (d->n_local == 0)  // tree_x_hybrid/mod.rs:132-134, hashes/hasher.rs:110-112
         return fail(SCANN_HIP_INVALID_ARGUMENT, "Cannot build from empty dataset");
     if (d->n_local >= 0xFFFFFFFFull) return fail(SCANN_HIP_OUT_OF_RANGE, "DatapointIndex is u32");
-    if (!d->codebook || !d->codes) return fail(SCANN_HIP_INVALID_ARGUMENT, "codebook/codes null");
-    const uint32_t S = d->num_subspaces, K = d->num_codes, dsub = d->dims_per_subspace;
-    if (S == 0 || d->dim == 0 || d->dim % S != 0 || dsub != d->dim / S)  // codebook.rs:154-159
+    // SearchMode::Partitioned (scann.rs:213-252): no codebook, the selected leaves are scored exactly
+    const bool exact = !d->codebook && !d->codes && d->num_subspaces == 0;
+    if (!exact && (!d->codebook || !d->codes)) return fail(SCANN_HIP_INVALID_ARGUMENT, "codebook/codes null");
+    if (d->distance_measure < SCANN_HIP_SQUARED_L2 || d->distance_measure > SCANN_HIP_DOT_PRODUCT)
+        return fail(SCANN_HIP_UNIMPLEMENTED, "distance_measure must be SquaredL2, L2 or DotProduct");
+    const uint32_t S = d->num_subspaces, K = exact ? 16u : d->num_codes, dsub = d->dims_per_subspace;
+    if (d->dim == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "dim is 0");
+    if (exact) {
+        if (ah || !d->data || d->leaf_sizes_global || d->n_rows != d->n_local)
+            return fail(SCANN_HIP_INVALID_ARGUMENT,
+                        "the exact leaf scan needs centers, the dataset rows and an unsharded index");
+    } else if (S == 0 || d->dim % S != 0 || dsub != d->dim / S) {  // codebook.rs:154-159
         return fail(SCANN_HIP_INVALID_ARGUMENT,
                     "Dimensionality " + std::to_string(d->dim) +
                         " must be divisible by num_subspaces " + std::to_string(S));
+    }
     if (K == 0 || K > 256)
         return fail(SCANN_HIP_UNIMPLEMENTED, "num_codes must be 1..256");
     // K <= 16: 4-bit packed codes + 16-slot tables (LUT16); else bytes + 256-slot tables
     const uint32_t bits = K <= 16 ? 4u : 8u;
-    if (bits == 4 && (S % 8 != 0 || S > 64 || S == 40 || S == 56))
+    if (!exact && bits == 4 && (S % 8 != 0 || S > 64 || S == 40 || S == 56))
         return fail(SCANN_HIP_UNIMPLEMENTED, "num_subspaces must be 8,16,24,32,48 or 64 for num_codes <= 16");
     if (bits == 8 && S != 4 && S != 8 && S != 16)
         return fail(SCANN_HIP_UNIMPLEMENTED, "num_subspaces must be 4, 8 or 16 for 16 < num_codes <= 256");
@@ -304,7 +314,9 @@ int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_
     std::vector<uint32_t> words;
     const uint32_t *code_words = nullptr;
     const size_t bpp = S / 2;
-    if (d->codes_packed4) {
+    if (exact) {
+        // no codes
+    } else if (d->codes_packed4) {
         if ((reinterpret_cast<uintptr_t>(d->codes) & 3u) == 0) {
             code_words = reinterpret_cast<const uint32_t *>(d->codes);
         } else {
@@ -330,8 +342,10 @@ int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_
 
     if ((s = upload(ix->d_leaf_off, off.data(), (size_t)(L + 1) * 4)) != SCANN_HIP_OK) return bail(s);
     if ((s = upload(ix->d_leaf_gsize, gsz.data(), (size_t)L * 4)) != SCANN_HIP_OK) return bail(s);
-    if ((s = upload(ix->d_codes, code_words, (size_t)n * nw * 4)) != SCANN_HIP_OK) return bail(s);
-    if ((s = upload(ix->d_codebook, d->codebook, (size_t)S * K * dsub * 4)) != SCANN_HIP_OK) return bail(s);
+    if (!exact) {
+        if ((s = upload(ix->d_codes, code_words, (size_t)n * nw * 4)) != SCANN_HIP_OK) return bail(s);
+        if ((s = upload(ix->d_codebook, d->codebook, (size_t)S * K * dsub * 4)) != SCANN_HIP_OK) return bail(s);
+    }
     if (!ah) {
         if ((s = upload(ix->d_centers, d->centers, (size_t)L * d->dim * 4)) != SCANN_HIP_OK) return bail(s);
         if ((s = upload(ix->d_leaf_ids, d->leaf_ids, (size_t)n * 4)) != SCANN_HIP_OK) return bail(s);
@@ -356,11 +370,13 @@ int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_
     t.leaf_off = ix->d_leaf_off.as<uint32_t>();
     t.leaf_gsize = ix->d_leaf_gsize.as<uint32_t>();
     t.leaf_ids = ah ? nullptr : ix->d_leaf_ids.as<uint32_t>();
-    t.codes = ix->d_codes.as<uint32_t>();
+    t.codes = exact ? nullptr : ix->d_codes.as<uint32_t>();
+    t.measure = d->distance_measure;
+    t.exact_scan = exact ? 1 : 0;
     t.rows = d->data ? ix->d_rows.as<float>() : nullptr;
     // AH mode: CSR row == datapoint index.  Sharded: rows arrive in CSR order.
     t.rows_csr = (ah || d->data_is_csr_order) ? 1 : 0;
-    t.codebook = ix->d_codebook.as<float>();
+    t.codebook = exact ? nullptr : ix->d_codebook.as<float>();
     t.use_residuals = (!ah && d->use_residuals) ? 1 : 0;
     t.ah_mode = ah ? 1 : 0;
     ix->default_P = ah ? 1u : std::max(1u, d->partitions_to_search);
@@ -392,8 +408,13 @@ static int resolve_params(const scann_hip_index *ix, uint32_t k, const scann_hip
     if (ix->tx.ah_mode) P = 1;
     if (P > kMaxPartitionsToSearch)
         return fail(SCANN_HIP_UNIMPLEMENTED, "partitions_to_search > 4096");
+    const bool exact_reorder = o->exact_reorder && !ix->tx.exact_scan;   // the scan's distances ARE exact
+    if (ix->tx.exact_scan) {
+        full_cap = true;   // dense key lists: one slot per scanned row, no threshold
+        if (o->allow_bitmap) return fail(SCANN_HIP_UNIMPLEMENTED, "the exact leaf scan takes no filter");
+    }
     uint32_t m;
-    if (!o->exact_reorder) {
+    if (!exact_reorder) {
         m = k;
     } else if (o->pre_reorder_k) {
         m = o->pre_reorder_k;
@@ -405,7 +426,7 @@ static int resolve_params(const scann_hip_index *ix, uint32_t k, const scann_hip
         return fail(SCANN_HIP_UNIMPLEMENTED,
                     "pre-reorder candidate count " + std::to_string(m) + " exceeds " +
                         std::to_string(kMaxPreReorderK));
-    if (o->exact_reorder && !ix->tx.rows)  // hasher.rs:194-197
+    if (exact_reorder && !ix->tx.rows)  // hasher.rs:194-197
         return fail(SCANN_HIP_FAILED_PRECONDITION, "Dataset not stored");
     const uint64_t ms = std::min<uint64_t>(std::max<uint64_t>(1, max_stream(ix, P)), 0xFFFFFFFFull);
     uint32_t st, scap;
@@ -423,7 +444,7 @@ static int resolve_params(const scann_hip_index *ix, uint32_t k, const scann_hip
     out->m = m;
     out->k = k;
     out->cap = (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFull);
-    out->exact_reorder = o->exact_reorder ? 1 : 0;
+    out->exact_reorder = exact_reorder ? 1 : 0;
     out->no_threshold = full_cap ? 1 : 0;
     return SCANN_HIP_OK;
 }
@@ -597,7 +618,7 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
         SCANN_TRY(txh_launch_search(ix->tx, w, false, ix->stream, ix->ev0,
                                     ix->ev1));
         ix->timing_valid = ix->timing;
-        ix->timed_kernel = w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
+        ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
         uint32_t counters[CNT_N];
         SCANN_HIP_CHECK(hipMemcpyAsync(counters, w.counters, sizeof(counters), hipMemcpyDeviceToHost,
                                        ix->stream));
@@ -727,7 +748,7 @@ int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries,
     SCANN_TRY(txh_launch_search(ix->tx, w, false, st, ix->ev0,
                                 ix->ev1));
     ix->timing_valid = ix->timing;
-    ix->timed_kernel = w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
+    ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
     return SCANN_HIP_OK;
 }
 
@@ -779,7 +800,7 @@ int scann_hip_txh_search_local_device(scann_hip_index *ix, const float *d_querie
     SCANN_TRY(txh_launch_search(ix->tx, w, true, st, ix->ev0,
                                 ix->ev1));
     ix->timing_valid = ix->timing;
-    ix->timed_kernel = w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
+    ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
     return SCANN_HIP_OK;
 }
 

@@ -93,6 +93,8 @@ struct TxhIndexDev {
     const float *codebook;        // [S][K][dsub]
     int use_residuals;
     int ah_mode;                  // single implicit leaf, no centroid stage
+    int measure;                  // measure of the exact re-rank and of the exact leaf scan
+    int exact_scan;               // SearchMode::Partitioned: no codes, rows of the leaves scored exactly
 };
 
 // points of one scan tile chunk for this index's code layout (Codec<S, bits>::TP in txh.hip)

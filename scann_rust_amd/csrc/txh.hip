@@ -1109,6 +1109,145 @@ __global__ __launch_bounds__(kSelectThreads) void threshold_select_kernel(
 }
 
 // =====================================================================================
+// K6c: exact leaf scan -- Scann::search_partitioned (scann.rs:213-252).  Every row of the P
+// selected leaves is scored with the configured measure's single-pair kernel
+// (DistanceMeasure::distance, distance_measures/mod.rs:70-81 -> simd/x86.rs:72-96 / :139-165: 8
+// FMA lane chains, fixed hsum tree, scalar tail); candidates in token order then leaf order,
+// stable sort, first k.  Tile = (leaf, 256-row chunk, group of quads): a thread owns one row and
+// walks the tile's queries eight at a time from LDS, the lane chains as packed-f32 pairs
+// (v_pk_fma_f32).  Every (query, stream position) is written exactly once into the query's
+// dense key list [vbase[P]], from which select_rerank_kernel takes the k smallest keys.
+// =====================================================================================
+constexpr uint32_t kExactRows = 256;   // rows per tile chunk (one per thread)
+constexpr uint32_t kExactQuads = 8;    // quads per tile
+constexpr int kExactQT = 8;            // queries per pass over the row
+
+struct ExactScanArgs {
+    const uint32_t *pair_off, *tile_off, *pair_q, *pair_vbase;
+    uint32_t *counters;
+    const float *queries;
+    uint32_t q_stride;
+    uint64_t *cand;
+    uint32_t cap;
+};
+
+__global__ void stream_counts_kernel(uint32_t nq, uint32_t P, const uint32_t *__restrict__ vbase,
+                                     uint32_t *__restrict__ cand_cnt) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) cand_cnt[q] = vbase[(size_t)q * (P + 1) + P];
+}
+
+template <int MEASURE>
+__global__ __launch_bounds__(256) void leaf_exact_scan_kernel(TxhIndexDev ix, ExactScanArgs a) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) float qs[];   // [kExactQT][dimp]
+    __shared__ uint32_t s_pq[kExactQT], s_vb[kExactQT], tile_sh;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t dim = ix.dim, dimp = (dim + 3u) & ~3u, chunks = dim >> 3;
+    const uint32_t total_tiles = a.counters[CNT_TOTAL_TILES];
+    const bool vec = ((ix.stride & 3u) == 0) && ((reinterpret_cast<uintptr_t>(ix.rows) & 15u) == 0);
+    for (;;) {
+        __syncthreads();   // the previous tile's LDS reads are done
+        if (tid == 0) tile_sh = grab_tile(a.counters + CNT_XQ, total_tiles);
+        __syncthreads();
+        const uint32_t tile = __builtin_amdgcn_readfirstlane(tile_sh);
+        if (tile == kInvalid) break;
+        uint32_t lo = 0, hi = ix.L;   // leaf = largest l with tile_off[l] <= tile
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (uniform_load(a.tile_off + mid) <= tile) lo = mid; else hi = mid;
+        }
+        const uint32_t leaf = lo;
+        const uint32_t lb = uniform_load(ix.leaf_off + leaf);
+        const uint32_t size = uniform_load(ix.leaf_off + leaf + 1) - lb;
+        const uint32_t nchunks = (size + kExactRows - 1) / kExactRows;
+        const uint32_t local = tile - uniform_load(a.tile_off + leaf);
+        const uint32_t chunk = local % nchunks, qg = local / nchunks;
+        const uint32_t slot0 = uniform_load(a.pair_off + leaf);
+        const uint32_t slot_end = uniform_load(a.pair_off + leaf + 1);
+        const uint32_t s_begin = slot0 + qg * kExactQuads * 4u;
+        const uint32_t s_stop = min(s_begin + kExactQuads * 4u, slot_end);
+        const uint32_t j = chunk * kExactRows + tid;
+        const bool valid = j < size;
+        const uint32_t csr = lb + (valid ? j : 0u);
+        const float *row = ix.rows + (size_t)(ix.rows_csr ? csr : ix.leaf_ids[csr]) * ix.stride;
+
+        for (uint32_t sg = s_begin; sg < s_stop; sg += kExactQT) {
+            __syncthreads();
+            if (tid < kExactQT) {
+                const uint32_t sl = sg + tid;
+                s_pq[tid] = sl < s_stop ? a.pair_q[sl] : kInvalid;
+                s_vb[tid] = sl < s_stop ? a.pair_vbase[sl] : 0u;
+            }
+            for (uint32_t i = tid; i < kExactQT * dimp; i += 256) {
+                const uint32_t qi = i / dimp, jj = i - qi * dimp;
+                const uint32_t sl = sg + qi;
+                const uint32_t pq = sl < s_stop ? a.pair_q[sl] : kInvalid;
+                qs[i] = (pq != kInvalid && jj < dim) ? a.queries[(size_t)pq * a.q_stride + jj] : 0.0f;
+            }
+            __syncthreads();
+            f32x2 accv[kExactQT][4];
+#pragma unroll
+            for (int qi = 0; qi < kExactQT; ++qi)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) accv[qi][u] = f32x2{0.0f, 0.0f};
+            for (uint32_t c = 0; c < chunks; ++c) {
+                f32x2 x[4];
+                if (vec) {
+                    const float4 xa = *reinterpret_cast<const float4 *>(row + 8 * c);
+                    const float4 xb = *reinterpret_cast<const float4 *>(row + 8 * c + 4);
+                    x[0] = f32x2{xa.x, xa.y}; x[1] = f32x2{xa.z, xa.w};
+                    x[2] = f32x2{xb.x, xb.y}; x[3] = f32x2{xb.z, xb.w};
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = f32x2{row[8 * c + 2 * u], row[8 * c + 2 * u + 1]};
+                }
+#pragma unroll
+                for (int qi = 0; qi < kExactQT; ++qi) {
+                    const float4 qa = *reinterpret_cast<const float4 *>(qs + qi * dimp + 8 * c);
+                    const float4 qb = *reinterpret_cast<const float4 *>(qs + qi * dimp + 8 * c + 4);
+                    const f32x2 qv[4] = {f32x2{qa.x, qa.y}, f32x2{qa.z, qa.w}, f32x2{qb.x, qb.y},
+                                         f32x2{qb.z, qb.w}};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (MEASURE == SCANN_HIP_DOT_PRODUCT) {
+                            accv[qi][u] = __builtin_elementwise_fma(qv[u], x[u], accv[qi][u]);
+                        } else {
+                            const f32x2 d = qv[u] - x[u];
+                            accv[qi][u] = __builtin_elementwise_fma(d, d, accv[qi][u]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int qi = 0; qi < kExactQT; ++qi) {
+                const uint32_t pq = s_pq[qi];
+                if (pq == kInvalid) continue;   // block-uniform
+                // hsum tree (x86.rs:31-44): lanes (0+4, 1+5), (2+6, 3+7) -> (s0+s1) + (s2+s3)
+                const f32x2 s01 = accv[qi][0] + accv[qi][2], s23 = accv[qi][1] + accv[qi][3];
+                float r = (s01.x + s01.y) + (s23.x + s23.y);
+                for (uint32_t jj = chunks * 8; jj < dim; ++jj) {   // scalar tail, not fused
+                    const float qv = qs[qi * dimp + jj];
+                    if (MEASURE == SCANN_HIP_DOT_PRODUCT) {
+                        r = r + qv * row[jj];
+                    } else {
+                        const float d = qv - row[jj];
+                        r = r + d * d;
+                    }
+                }
+                float dist = r;
+                if (MEASURE == SCANN_HIP_DOT_PRODUCT) dist = -r;
+                if (MEASURE == SCANN_HIP_L2) dist = sqrtf(r);
+                if (valid) {
+                    const uint32_t vpos = s_vb[qi] + j;
+                    if (vpos < a.cap) a.cand[(size_t)pq * a.cap + vpos] = make_key(dist, vpos);
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================
 // K7: select + re-rank.  mod.rs:283-293 and :342-364 for one query per block:
 //   candidates -> exact m best keys (sorted) -> decode -> exact SquaredL2 with the
 //   reference's AVX2 arithmetic (simd/x86.rs:139-165: 8 FMA lane chains, fixed hsum
@@ -1356,8 +1495,12 @@ __global__ __launch_bounds__(256) void rerank_kernel(TxhIndexDev ix, const float
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (i0 + u < chunks) {
-                const float diff = s_q[8 * (i0 + u) + lane8] - xv[u];
-                accv = fmaf(diff, diff, accv);        // _mm256_fmadd_ps(diff, diff, sum)
+                if (ix.measure == SCANN_HIP_DOT_PRODUCT) {   // dot_product_avx2, x86.rs:72-96
+                    accv = fmaf(s_q[8 * (i0 + u) + lane8], xv[u], accv);
+                } else {
+                    const float diff = s_q[8 * (i0 + u) + lane8] - xv[u];
+                    accv = fmaf(diff, diff, accv);        // _mm256_fmadd_ps(diff, diff, sum)
+                }
             }
         }
     }
@@ -1367,9 +1510,16 @@ __global__ __launch_bounds__(256) void rerank_kernel(TxhIndexDev ix, const float
     float r = t + __shfl_down(t, 2, 8);           // lane 0: (s0+s1) + (s2+s3)
     if (act && lane8 == 0) {
         for (uint32_t j = chunks * 8; j < dim; ++j) {   // scalar tail, not fused
-            const float diff = s_q[j] - row[j];
-            r = r + diff * diff;
+            if (ix.measure == SCANN_HIP_DOT_PRODUCT) {
+                r = r + s_q[j] * row[j];
+            } else {
+                const float diff = s_q[j] - row[j];
+                r = r + diff * diff;
+            }
         }
+        // ReorderingHelper with the configured measure (utils/reordering.rs:35-44)
+        if (ix.measure == SCANN_HIP_DOT_PRODUCT) r = -r;
+        if (ix.measure == SCANN_HIP_L2) r = sqrtf(r);
         cand_exact[(size_t)q * m + c] = r;
     }
 }
@@ -1872,6 +2022,48 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
     return SCANN_HIP_OK;
 }
 
+// SearchMode::Partitioned: dense key lists (no threshold), one exact-distance tile kernel.
+static int launch_exact_scan(const TxhIndexDev &ix, const TxhWork &w, hipStream_t st, hipEvent_t ev0,
+                             hipEvent_t ev1) {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    {   // thr = MAX for every query: select_rerank takes the k smallest of the whole stream
+        const SelCfg tcfg = sel_cfg(w.scap);
+        const size_t lds_thr = ((size_t)((w.scap + 3u) & ~3u) + tcfg.bins + tcfg.list) * 4 + 48 * 8;
+        SCANN_TRY(set_dyn_lds(threshold_select_kernel, lds_thr));
+        hipLaunchKernelGGL(threshold_select_kernel, dim3(w.nq), dim3(256), lds_thr, st, w.P, w.m, w.st, 1, w.sbase,
+                           w.samp, w.scap, w.slot_of, w.thr, w.pair_thr);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(stream_counts_kernel, dim3(ceil_div_u32(w.nq, 256)), dim3(256), 0, st, w.nq, w.P, w.vbase,
+                       w.cand_cnt);
+    LAUNCH_CHECK();
+    ExactScanArgs a;
+    a.pair_off = w.pair_off; a.tile_off = w.tile_off; a.pair_q = w.pair_q; a.pair_vbase = w.pair_vbase;
+    a.counters = w.counters; a.queries = w.queries; a.q_stride = w.q_stride; a.cand = w.cand; a.cap = w.cap;
+    const size_t lds = (size_t)kExactQT * ((ix.dim + 3u) & ~3u) * sizeof(float);
+    if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
+    const dim3 grid((uint32_t)cus * 8u), block(256);
+    switch (ix.measure) {
+        case SCANN_HIP_SQUARED_L2:
+            SCANN_TRY(set_dyn_lds(leaf_exact_scan_kernel<SCANN_HIP_SQUARED_L2>, lds));
+            hipLaunchKernelGGL(leaf_exact_scan_kernel<SCANN_HIP_SQUARED_L2>, grid, block, lds, st, ix, a);
+            break;
+        case SCANN_HIP_L2:
+            SCANN_TRY(set_dyn_lds(leaf_exact_scan_kernel<SCANN_HIP_L2>, lds));
+            hipLaunchKernelGGL(leaf_exact_scan_kernel<SCANN_HIP_L2>, grid, block, lds, st, ix, a);
+            break;
+        default:
+            SCANN_TRY(set_dyn_lds(leaf_exact_scan_kernel<SCANN_HIP_DOT_PRODUCT>, lds));
+            hipLaunchKernelGGL(leaf_exact_scan_kernel<SCANN_HIP_DOT_PRODUCT>, grid, block, lds, st, ix, a);
+            break;
+    }
+    LAUNCH_CHECK();
+    if (ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
+    return SCANN_HIP_OK;
+}
+
 int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, hipStream_t st,
                       hipEvent_t ev0, hipEvent_t ev1) {
     if (w.nq == 0) return SCANN_HIP_OK;
@@ -1889,8 +2081,10 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
                        npairs, ix.ah_mode, w.tokens, ix.leaf_off, w.leaf_cnt);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(worklist_scan_kernel, dim3(1), dim3(1024), 0, st, ix.L, w.leaf_cnt,
-                       ix.leaf_off, w.resident ? kResThreads * kScanPPT : scan_tile_points(ix),
-                       w.resident ? kResQuads : w.qpt, w.resident ? w.res_cl : 1u, scan_tile_points(ix), w.st,
+                       ix.leaf_off,
+                       ix.exact_scan ? kExactRows : w.resident ? kResThreads * kScanPPT : scan_tile_points(ix),
+                       ix.exact_scan ? kExactQuads : w.resident ? kResQuads : w.qpt,
+                       (w.resident && !ix.exact_scan) ? w.res_cl : 1u, scan_tile_points(ix), w.st,
                        w.sqpt, w.pair_off, w.tile_off,
                        w.stile_off, w.counters);
     LAUNCH_CHECK();
@@ -1898,6 +2092,9 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
                        w.P, ix.ah_mode, w.tokens, w.vbase, w.sbase, ix.leaf_off, w.pair_off, w.leaf_cursor, w.pair_q,
                        w.pair_leaf, w.pair_vbase, w.pair_sbase, w.slot_of);
     LAUNCH_CHECK();
+    if (ix.exact_scan) {
+        SCANN_TRY(launch_exact_scan(ix, w, st, ev0, ev1));
+    } else {
     const size_t lds_lut = (size_t)4 * ix.dim * sizeof(float);
     SCANN_TRY(set_dyn_lds(lut_build_kernel, lds_lut));
     hipLaunchKernelGGL(lut_build_kernel, dim3(w.max_quads), dim3(256), lds_lut, st, ix, w.queries,
@@ -1917,6 +2114,7 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
         default:
             return fail(SCANN_HIP_UNIMPLEMENTED,
                         "num_subspaces must be 8,16,24,32,48,64 (num_codes <= 16) or 4,8,16 (num_codes <= 256)");
+    }
     }
 
     SelectArgs s;

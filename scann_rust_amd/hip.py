@@ -65,6 +65,7 @@ class TxhDesc(C.Structure):
         ("dims_per_subspace", C.c_uint32),
         ("codes", u8p), ("codes_packed4", C.c_int32), ("use_residuals", C.c_int32),
         ("partitions_to_search", C.c_uint32), ("pre_reorder_multiplier", C.c_float),
+        ("distance_measure", C.c_int32),
     ]
 
 
@@ -265,7 +266,8 @@ def bf_create(data, n, dim, stride, measure, device=0):
 def txh_create(*, data, n_rows, dim, stride, centers, leaf_offsets, leaf_ids, codebook, codes,
                codes_packed4=False, use_residuals=True, partitions_to_search=10,
                pre_reorder_multiplier=3.0, leaf_sizes_global=None, data_is_csr_order=False,
-               device=0):
+               distance_measure=SQUARED_L2, device=0):
+    """codebook=None and codes=None: SearchMode::Partitioned (exact scan of the selected leaves)."""
     d = TxhDesc()
     keep = []
 
@@ -293,10 +295,12 @@ def txh_create(*, data, n_rows, dim, stride, centers, leaf_offsets, leaf_ids, co
     d.leaf_offsets = ptr(leaf_offsets, u32p)
     d.leaf_ids = ptr(leaf_ids, u32p)
     d.leaf_sizes_global = ptr(leaf_sizes_global, u32p)
-    d.n_local = codes.shape[0]
+    d.n_local = codes.shape[0] if codes is not None else leaf_ids.shape[0]
     d.codebook = ptr(codebook, f32p)
-    d.num_subspaces, d.num_codes, d.dims_per_subspace = codebook.shape
+    if codebook is not None:
+        d.num_subspaces, d.num_codes, d.dims_per_subspace = codebook.shape
     d.codes = ptr(codes, u8p)
+    d.distance_measure = distance_measure
     d.codes_packed4 = 1 if codes_packed4 else 0
     d.use_residuals = 1 if use_residuals else 0
     d.partitions_to_search = partitions_to_search

@@ -773,3 +773,113 @@ def test_bf_shortlist_error_bound_holds(force_shortlist):
         for i in range(8):
             oi, od = orc.bf_search(data, n, dim, stride, measure, q[i], 10)
             H.assert_topk_equal_up_to_ties(idx[i], dist[i], oi, od, what="scaled q%d" % i)
+
+
+# ---- Scann facade modes (scann.rs:181-294) as configurations of the same index ------------------
+def _partition_case(n, dim, L, seed):
+    rows = synth.uniform_f32(n, dim, seed)
+    data, stride = orc.to_strided(rows)
+    centers, assign = trainer.kmeans(rows, L, iters=3, seed=seed)
+    order = np.argsort(assign, kind="stable").astype(np.uint32)
+    leaf_off = np.zeros(centers.shape[0] + 1, np.uint32)
+    leaf_off[1:] = np.cumsum(np.bincount(assign, minlength=centers.shape[0]))
+    return rows, data, stride, centers, leaf_off, order
+
+
+@pytest.mark.parametrize("measure", [hip.SQUARED_L2, hip.L2, hip.DOT_PRODUCT])
+@pytest.mark.parametrize("n,dim,L,P,k", [(3000, 64, 20, 5, 10), (5000, 100, 37, 37, 25), (800, 33, 8, 3, 900),
+                                         (20000, 128, 16, 4, 10)])
+def test_scann_partitioned_mode(measure, n, dim, L, P, k):
+    """search_partitioned (scann.rs:213-252): exact distances bit for bit, and -- both sides being a
+    stable sort of the same stream -- identical indices, ties included."""
+    rows, data, stride, centers, leaf_off, leaf_ids = _partition_case(n, dim, L, seed=21)
+    index = hip.txh_create(data=data, n_rows=n, dim=dim, stride=stride, centers=centers,
+                           leaf_offsets=leaf_off, leaf_ids=leaf_ids, codebook=None, codes=None,
+                           partitions_to_search=P, distance_measure=measure)
+    q = synth.uniform_f32(70, dim, 123)
+    q[3] = rows[17]   # an exact hit
+    idx, dist, cnt = index.search_batched(q, k)
+    for i in range(q.shape[0]):
+        oi, od = orc.scann_search_partitioned(centers, leaf_off, leaf_ids, data, stride, measure, q[i], P, k)
+        assert cnt[i] == oi.size
+        assert np.array_equal(bits(dist[i, :oi.size]), bits(od)), (i, dist[i, :oi.size], od)
+        assert np.array_equal(idx[i, :oi.size], oi)
+
+
+def test_scann_partitioned_mode_duplicates():
+    """Duplicate rows tie exactly: the stable order (token order, then leaf order) decides."""
+    rows, data, stride, centers, leaf_off, leaf_ids = _partition_case(2000, 32, 6, seed=5)
+    rows[1000:] = rows[:1000]
+    data, stride = orc.to_strided(rows)
+    centers, assign = trainer.kmeans(rows, 6, iters=3, seed=5)
+    leaf_ids = np.argsort(assign, kind="stable").astype(np.uint32)
+    leaf_off = np.zeros(7, np.uint32)
+    leaf_off[1:] = np.cumsum(np.bincount(assign, minlength=6))
+    index = hip.txh_create(data=data, n_rows=2000, dim=32, stride=stride, centers=centers,
+                           leaf_offsets=leaf_off, leaf_ids=leaf_ids, codebook=None, codes=None,
+                           partitions_to_search=3)
+    q = synth.uniform_f32(20, 32, 9)
+    idx, dist, cnt = index.search_batched(q, 15)
+    for i in range(20):
+        oi, od = orc.scann_search_partitioned(centers, leaf_off, leaf_ids, data, stride, 0, q[i], 3, 15)
+        assert np.array_equal(idx[i, :cnt[i]], oi) and np.array_equal(bits(dist[i, :cnt[i]]), bits(od))
+
+
+@pytest.mark.parametrize("measure,reorder", [(hip.SQUARED_L2, False), (hip.SQUARED_L2, True),
+                                             (hip.DOT_PRODUCT, True), (hip.L2, True)])
+@pytest.mark.parametrize("K,S", [(256, 8), (16, 16)])
+def test_scann_tree_ah_mode(measure, reorder, K, S):
+    """search_tree_ah (scann.rs:255-294): one non-residual table per query, stable sort of every
+    scanned row's LUT sum, first k; then the exact reordering of the truncated list (:199-209)."""
+    n, dim, L, P, k = 4000, 64, 16, 4, 12
+    rows, data, stride, ix, oix, kw = H.make_txh_case(n, dim, L, S, seed=8, K=K, use_residuals=False, P=P,
+                                                      kmeans_iters=3, pq_iters=3)
+    kw["distance_measure"] = measure
+    index = hip.txh_create(**kw)
+    codes_dp = np.empty_like(ix["codes"])
+    codes_dp[ix["leaf_ids"]] = ix["codes"]
+    q = synth.uniform_f32(50, dim, 77)
+    o = hip.default_opts()
+    o.pre_reorder_k = k
+    o.exact_reorder = 1 if reorder else 0
+    idx, dist, cnt = index.search_batched(q, k, opts=o)
+    for i in range(q.shape[0]):
+        oi, od = orc.scann_search_tree_ah(ix["centers"], ix["leaf_off"], ix["leaf_ids"], ix["codebook"],
+                                          codes_dp, data, stride, measure, reorder, q[i], P, k)
+        assert cnt[i] == oi.size
+        assert np.array_equal(bits(dist[i, :oi.size]), bits(od)), (i, dist[i], od)
+        assert np.array_equal(idx[i, :oi.size], oi)
+
+
+@pytest.mark.parametrize("measure", [hip.SQUARED_L2, hip.DOT_PRODUCT])
+def test_scann_hashed_mode_reorder(measure):
+    """SearchMode::Hashed + exact reordering: AsymmetricHasher::search's k rows re-scored with the
+    configured measure (scann.rs:189-209)."""
+    n, dim, S, k = 3000, 64, 8, 10
+    rows, data, stride, ix, kw = H.make_ah_case(n, dim, S, seed=4, K=256, pq_iters=3)
+    kw["distance_measure"] = measure
+    index = hip.txh_create(**kw)
+    q = synth.uniform_f32(40, dim, 5)
+    o = hip.default_opts()
+    o.pre_reorder_k = k
+    o.exact_reorder = 1
+    idx, dist, cnt = index.search_batched(q, k, opts=o)
+    for i in range(q.shape[0]):
+        ai, ad = orc.ah_search(ix["codebook"], ix["codes"], q[i], k)
+        oi, od = orc.reorder_measure(data, stride, dim, measure, q[i], ai, k)
+        assert cnt[i] == oi.size
+        assert np.array_equal(bits(dist[i, :oi.size]), bits(od))
+        H.assert_topk_equal_up_to_ties(idx[i, :oi.size], dist[i, :oi.size], oi, od, what="hashed+reorder")
+
+
+def test_scann_partitioned_mode_errors():
+    rows, data, stride, centers, leaf_off, leaf_ids = _partition_case(500, 16, 4, seed=2)
+    with pytest.raises(hip.ScannError) as e:   # needs the dataset rows
+        hip.txh_create(data=None, n_rows=500, dim=16, stride=stride, centers=centers, leaf_offsets=leaf_off,
+                       leaf_ids=leaf_ids, codebook=None, codes=None)
+    assert e.value.code == hip.INVALID_ARGUMENT
+    index = hip.txh_create(data=data, n_rows=500, dim=16, stride=stride, centers=centers,
+                           leaf_offsets=leaf_off, leaf_ids=leaf_ids, codebook=None, codes=None)
+    with pytest.raises(hip.ScannError) as e:
+        index.search_batched(np.zeros((1, 8), np.float32), 5)
+    assert e.value.code == hip.INVALID_ARGUMENT
