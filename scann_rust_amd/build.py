@@ -36,6 +36,28 @@ def build(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
+HOST = os.path.join(HERE, "host")
+HOST_PROGRAMS = ["host_test", "ann_benchmark"]   # C++ mirror of the reference API + its benchmark CLI
+
+
+def build_host(verbose=False):
+    """Compile the host-side C++ programs (g++, link against libscann_hip.so)."""
+    build()
+    out = []
+    for name in HOST_PROGRAMS:
+        exe, src = os.path.join(HOST, name), os.path.join(HOST, name + ".cpp")
+        deps = [src, os.path.join(HOST, "scann.hpp"), os.path.join(HERE, "..", "include", "scann_hip.h")]
+        if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+            cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-o", exe, src, "-L" + HERE, "-lscann_hip",
+                   "-Wl,-rpath," + HERE, "-lpthread"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        out.append(exe)
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    build_host(verbose=True)
     print(LIB)

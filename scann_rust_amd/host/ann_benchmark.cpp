@@ -1,0 +1,438 @@
+// ann_benchmark -- the reference's ANN-Benchmarks-style runner (src/bin/ann_benchmark.rs) over the
+// C++ mirror of its API (scann.hpp -> libscann_hip.so): same flags, same defaults, same report
+// lines and JSON keys, so a run reads line for line against README.md:711-716.
+//
+// Differences, all additive or documented:
+//  * synthetic data comes from splitmix64 (u >> 40) * 2^-24 -- the construction rand's
+//    gen::<f32>() uses, on a documented counter-based stream instead of StdRng (ChaCha12), whose
+//    stream is not reproducible here; train then test are drawn from one stream (:402-425);
+//  * the per-query loop of the reference (:172-178) is timed as `search_seconds` / `qps`; the same
+//    queries are then sent as ONE batch (Scann::search_batched) and reported as
+//    `batched_search_seconds` / `batched_qps` -- the GPU's natural operating point;
+//  * --distance l1 / cosine parse as in the reference but the GPU library implements
+//    SquaredL2 / L2 / DotProduct only: building such an index fails with Unimplemented.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "scann.hpp"
+
+using namespace scann;
+
+namespace {
+
+enum class Algorithm { BruteForce, Partitioned, Hashed, TreeAh };
+enum class DistanceArg { SquaredL2, L2, L1, Cosine, DotProduct };
+
+struct Args {   // ann_benchmark.rs:74-107
+    std::string data_json;
+    Algorithm algorithm = Algorithm::BruteForce;
+    DistanceArg distance = DistanceArg::SquaredL2;
+    size_t k = 10;
+    uint32_t num_partitions = 100, partitions_to_search = 10, num_blocks = 8;
+    long limit_train = -1, limit_test = -1;
+    size_t synthetic_train = 10000, synthetic_test = 200, dim = 64;
+    uint64_t seed = 42;
+};
+
+struct BenchmarkData {
+    std::vector<std::vector<float>> train, test;
+    std::vector<std::vector<uint32_t>> gt;
+    std::string source;
+    size_t dimension = 0;
+};
+
+[[noreturn]] void die(const std::string &msg) {
+    std::fprintf(stderr, "Error: %s\n", msg.c_str());
+    std::exit(1);
+}
+
+bool parse_algorithm(const std::string &s, Algorithm *a) {   // :22-35
+    if (s == "brute-force" || s == "brute_force" || s == "bruteforce") *a = Algorithm::BruteForce;
+    else if (s == "partitioned") *a = Algorithm::Partitioned;
+    else if (s == "hashed") *a = Algorithm::Hashed;
+    else if (s == "tree-ah" || s == "tree_ah" || s == "treeah") *a = Algorithm::TreeAh;
+    else return false;
+    return true;
+}
+
+bool parse_distance(const std::string &s, DistanceArg *d) {   // :59-72
+    if (s == "squared-l2" || s == "squared_l2") *d = DistanceArg::SquaredL2;
+    else if (s == "l2") *d = DistanceArg::L2;
+    else if (s == "l1") *d = DistanceArg::L1;
+    else if (s == "cosine") *d = DistanceArg::Cosine;
+    else if (s == "dot-product" || s == "dot_product") *d = DistanceArg::DotProduct;
+    else return false;
+    return true;
+}
+
+const char *algorithm_debug(Algorithm a) {   // {:?}
+    switch (a) {
+        case Algorithm::BruteForce: return "BruteForce";
+        case Algorithm::Partitioned: return "Partitioned";
+        case Algorithm::Hashed: return "Hashed";
+        default: return "TreeAh";
+    }
+}
+const char *algorithm_snake(Algorithm a) {   // serde rename_all = "snake_case"
+    switch (a) {
+        case Algorithm::BruteForce: return "brute_force";
+        case Algorithm::Partitioned: return "partitioned";
+        case Algorithm::Hashed: return "hashed";
+        default: return "tree_ah";
+    }
+}
+const char *distance_debug(DistanceArg d) {
+    switch (d) {
+        case DistanceArg::SquaredL2: return "SquaredL2";
+        case DistanceArg::L2: return "L2";
+        case DistanceArg::L1: return "L1";
+        case DistanceArg::Cosine: return "Cosine";
+        default: return "DotProduct";
+    }
+}
+const char *distance_snake(DistanceArg d) {
+    switch (d) {
+        case DistanceArg::SquaredL2: return "squared_l2";
+        case DistanceArg::L2: return "l2";
+        case DistanceArg::L1: return "l1";
+        case DistanceArg::Cosine: return "cosine";
+        default: return "dot_product";
+    }
+}
+
+void print_help() {   // :280-301
+    std::printf(
+        "ann_benchmark\n"
+        "ANN-Benchmarks-style runner for scann-rust (MI355X build).\n\n"
+        "Usage:\n"
+        "  ann_benchmark [options]\n\n"
+        "Options:\n"
+        "  --data-json <path>          JSON file with train/test/neighbors arrays\n"
+        "  --algorithm <name>          brute-force|partitioned|hashed|tree-ah\n"
+        "  --distance <name>           squared-l2|l2|l1|cosine|dot-product\n"
+        "  --k <int>                   neighbors to retrieve (default: 10)\n"
+        "  --num-partitions <int>      partition count (default: 100)\n"
+        "  --partitions-to-search <i>  partitions searched per query (default: 10)\n"
+        "  --num-blocks <int>          hash blocks (default: 8)\n"
+        "  --limit-train <int>         cap train rows from input JSON\n"
+        "  --limit-test <int>          cap test rows from input JSON\n"
+        "  --synthetic-train <int>     train vectors for synthetic mode\n"
+        "  --synthetic-test <int>      test vectors for synthetic mode\n"
+        "  --dim <int>                 dimensionality for synthetic mode\n"
+        "  --seed <int>                RNG seed for synthetic mode\n"
+        "  --help                      print this help\n");
+}
+
+Args parse_args(int argc, char **argv) {   // :206-274
+    Args a;
+    for (int i = 1; i < argc; ++i) {
+        const std::string flag = argv[i];
+        if (flag == "--help" || flag == "-h") {
+            print_help();
+            std::exit(0);
+        }
+        static const char *known[] = {"--data-json", "--algorithm", "--distance", "--k", "--num-partitions",
+                                      "--partitions-to-search", "--num-blocks", "--limit-train", "--limit-test",
+                                      "--synthetic-train", "--synthetic-test", "--dim", "--seed"};
+        bool ok = false;
+        for (const char *kf : known) ok = ok || flag == kf;
+        if (!ok) die("unknown argument: " + flag);
+        if (i + 1 >= argc) die("missing value for " + flag);
+        const std::string v = argv[++i];
+        auto num = [&](const std::string &s) -> unsigned long long {
+            char *end = nullptr;
+            if (s.empty() || s[0] == '-') die("invalid digit found in string");
+            const unsigned long long r = std::strtoull(s.c_str(), &end, 10);
+            if (!end || *end) die("invalid digit found in string");
+            return r;
+        };
+        if (flag == "--data-json") a.data_json = v;
+        else if (flag == "--algorithm") { if (!parse_algorithm(v, &a.algorithm)) die("unsupported algorithm: " + v); }
+        else if (flag == "--distance") { if (!parse_distance(v, &a.distance)) die("unsupported distance: " + v); }
+        else if (flag == "--k") a.k = num(v);
+        else if (flag == "--num-partitions") a.num_partitions = (uint32_t)num(v);
+        else if (flag == "--partitions-to-search") a.partitions_to_search = (uint32_t)num(v);
+        else if (flag == "--num-blocks") a.num_blocks = (uint32_t)num(v);
+        else if (flag == "--limit-train") a.limit_train = (long)num(v);
+        else if (flag == "--limit-test") a.limit_test = (long)num(v);
+        else if (flag == "--synthetic-train") a.synthetic_train = num(v);
+        else if (flag == "--synthetic-test") a.synthetic_test = num(v);
+        else if (flag == "--dim") a.dim = num(v);
+        else if (flag == "--seed") a.seed = num(v);
+    }
+    return a;
+}
+
+// ---- minimal JSON reader for {"train": [[..]], "test": [[..]], "neighbors": [[..]]} (:136-141) ----
+struct Json {
+    const std::string &s;
+    size_t p = 0;
+    explicit Json(const std::string &text) : s(text) {}
+    void ws() { while (p < s.size() && (s[p] == ' ' || s[p] == '\n' || s[p] == '\t' || s[p] == '\r')) ++p; }
+    char peek() { ws(); return p < s.size() ? s[p] : '\0'; }
+    void expect(char c) {
+        if (peek() != c) die(std::string("dataset JSON: expected '") + c + "' at byte " + std::to_string(p));
+        ++p;
+    }
+    std::string string() {
+        expect('"');
+        std::string out;
+        while (p < s.size() && s[p] != '"') {
+            if (s[p] == '\\' && p + 1 < s.size()) ++p;
+            out.push_back(s[p++]);
+        }
+        expect('"');
+        return out;
+    }
+    double number() {
+        ws();
+        char *end = nullptr;
+        const double v = std::strtod(s.c_str() + p, &end);
+        if (end == s.c_str() + p) die("dataset JSON: expected a number at byte " + std::to_string(p));
+        p = (size_t)(end - s.c_str());
+        return v;
+    }
+    void skip_value() {
+        const char c = peek();
+        if (c == '"') { string(); return; }
+        if (c == '[' || c == '{') {
+            const char close = c == '[' ? ']' : '}';
+            ++p;
+            while (peek() != close) {
+                if (c == '{') { string(); expect(':'); }
+                skip_value();
+                if (peek() == ',') ++p;
+            }
+            ++p;
+            return;
+        }
+        if (!std::strncmp(s.c_str() + p, "true", 4)) { p += 4; return; }
+        if (!std::strncmp(s.c_str() + p, "false", 5)) { p += 5; return; }
+        if (!std::strncmp(s.c_str() + p, "null", 4)) { p += 4; return; }
+        number();
+    }
+    template <typename T>
+    std::vector<std::vector<T>> matrix() {
+        std::vector<std::vector<T>> m;
+        expect('[');
+        while (peek() != ']') {
+            expect('[');
+            std::vector<T> row;
+            while (peek() != ']') {
+                row.push_back((T)number());
+                if (peek() == ',') ++p;
+            }
+            ++p;
+            m.push_back(std::move(row));
+            if (peek() == ',') ++p;
+        }
+        ++p;
+        return m;
+    }
+};
+
+BenchmarkData load_json_dataset(const Args &a) {   // :334-383
+    std::ifstream f(a.data_json);
+    if (!f) die("No such file or directory: " + a.data_json);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    const std::string text = ss.str();
+    Json j(text);
+    BenchmarkData d;
+    std::vector<std::vector<uint32_t>> neighbors;
+    bool ht = false, hq = false, hn = false;
+    j.expect('{');
+    while (j.peek() != '}') {
+        const std::string key = j.string();
+        j.expect(':');
+        if (key == "train") { d.train = j.matrix<float>(); ht = true; }
+        else if (key == "test") { d.test = j.matrix<float>(); hq = true; }
+        else if (key == "neighbors") { neighbors = j.matrix<uint32_t>(); hn = true; }
+        else j.skip_value();
+        if (j.peek() == ',') ++j.p;
+    }
+    if (!ht || !hq || !hn) die("dataset JSON: missing field train/test/neighbors");
+    if (a.limit_train >= 0 && (size_t)a.limit_train < d.train.size()) d.train.resize((size_t)a.limit_train);
+    if (a.limit_test >= 0) {
+        if ((size_t)a.limit_test < d.test.size()) d.test.resize((size_t)a.limit_test);
+        if ((size_t)a.limit_test < neighbors.size()) neighbors.resize((size_t)a.limit_test);
+    }
+    if (d.train.empty() || d.test.empty() || neighbors.empty())
+        die("dataset JSON must include non-empty train/test/neighbors");
+    for (auto &row : neighbors)
+        if (row.size() < a.k) die("neighbors rows must have at least " + std::to_string(a.k) + " entries");
+    for (size_t i = 0; i < neighbors.size() && i < d.test.size(); ++i)
+        d.gt.emplace_back(neighbors[i].begin(), neighbors[i].begin() + a.k);
+    d.source = a.data_json;
+    d.dimension = d.train[0].size();
+    return d;
+}
+
+float naive_squared_l2(const float *a, const float *b, size_t n) {   // :442-450: sequential scalar sum
+    float s = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        const float d = a[i] - b[i];
+        s += d * d;
+    }
+    return s;
+}
+
+// :427-440: full stable sort by distance, first k == the k smallest by (distance, index)
+std::vector<std::vector<uint32_t>> exact_ground_truth(const std::vector<std::vector<float>> &train,
+                                                      const std::vector<std::vector<float>> &queries, size_t k) {
+    std::vector<std::vector<uint32_t>> gt(queries.size());
+    const unsigned nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 64));
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t)
+        pool.emplace_back([&, t]() {
+            std::vector<std::pair<float, uint32_t>> d(train.size());
+            for (size_t qi = t; qi < queries.size(); qi += nt) {
+                for (size_t i = 0; i < train.size(); ++i)
+                    d[i] = {naive_squared_l2(queries[qi].data(), train[i].data(), queries[qi].size()), (uint32_t)i};
+                const size_t kk = std::min(k, d.size());
+                std::partial_sort(d.begin(), d.begin() + kk, d.end());
+                for (size_t i = 0; i < kk; ++i) gt[qi].push_back(d[i].second);
+            }
+        });
+    for (auto &th : pool) th.join();
+    return gt;
+}
+
+BenchmarkData generate_synthetic_dataset(const Args &a) {   // :402-425
+    BenchmarkData d;
+    uint64_t state = a.seed;
+    auto gen = [&]() { return (float)(detail::splitmix(state) >> 40) * (1.0f / 16777216.0f); };
+    d.train.assign(a.synthetic_train, std::vector<float>(a.dim));
+    for (auto &row : d.train)
+        for (auto &v : row) v = gen();
+    d.test.assign(a.synthetic_test, std::vector<float>(a.dim));
+    for (auto &row : d.test)
+        for (auto &v : row) v = gen();
+    d.gt = exact_ground_truth(d.train, d.test, a.k);
+    d.source = "synthetic_n" + std::to_string(a.synthetic_train) + "_q" + std::to_string(a.synthetic_test) + "_d" +
+               std::to_string(a.dim);
+    d.dimension = a.dim;
+    return d;
+}
+
+double average_recall_at_k(const std::vector<std::vector<uint32_t>> &retrieved,
+                           const std::vector<std::vector<uint32_t>> &gt, size_t k) {   // :452-471
+    if (retrieved.empty() || gt.empty() || k == 0) return 0.0;
+    const size_t n = std::min(retrieved.size(), gt.size());
+    double total = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        size_t hits = 0;
+        for (size_t a = 0; a < retrieved[i].size() && a < k; ++a)
+            for (size_t b = 0; b < gt[i].size() && b < k; ++b)
+                if (gt[i][b] == retrieved[i][a]) { ++hits; break; }
+        total += (double)hits / (double)k;
+    }
+    return total / (double)n;
+}
+
+long current_rss_bytes() {   // :473-479
+    std::ifstream f("/proc/self/statm");
+    long size_pages = 0, rss_pages = 0;
+    if (!(f >> size_pages >> rss_pages)) return -1;
+    return rss_pages * 4096;
+}
+
+Scann build_index(const std::vector<std::vector<float>> &train, const Args &a, DistanceMeasure distance) {   // :303-332
+    ScannBuilder b;
+    b.num_neighbors((uint32_t)a.k).distance_measure(distance);
+    switch (a.algorithm) {
+        case Algorithm::BruteForce: b.brute_force(); break;
+        case Algorithm::Partitioned: b.tree(a.num_partitions, a.partitions_to_search); break;
+        case Algorithm::Hashed: b.hash(a.num_blocks); break;
+        case Algorithm::TreeAh: b.tree(a.num_partitions, a.partitions_to_search).hash(a.num_blocks); break;
+    }
+    return b.build(DenseDataset::from_vecs(train));
+}
+
+double seconds_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    const Args args = parse_args(argc, argv);
+    try {
+        if (args.distance == DistanceArg::L1 || args.distance == DistanceArg::Cosine)
+            throw ScannError(ErrorCode::Unimplemented,
+                             std::string("distance ") + distance_debug(args.distance) +
+                                 " is not implemented by the GPU library (SquaredL2, L2, DotProduct)");
+        const DistanceMeasure distance = args.distance == DistanceArg::L2           ? DistanceMeasure::L2
+                                         : args.distance == DistanceArg::DotProduct ? DistanceMeasure::DotProduct
+                                                                                    : DistanceMeasure::SquaredL2;
+        const BenchmarkData data = args.data_json.empty() ? generate_synthetic_dataset(args) : load_json_dataset(args);
+
+        const long before_rss = current_rss_bytes();
+        auto t0 = std::chrono::steady_clock::now();
+        const Scann index = build_index(data.train, args, distance);
+        const double build_seconds = seconds_since(t0);
+        const long after_rss = current_rss_bytes();
+
+        t0 = std::chrono::steady_clock::now();
+        std::vector<std::vector<uint32_t>> retrieved;
+        retrieved.reserve(data.test.size());
+        for (auto &query : data.test) {   // :172-178
+            const auto result = index.search(query, args.k);
+            std::vector<uint32_t> ids;
+            for (auto &p : result) ids.push_back(p.first);
+            retrieved.push_back(std::move(ids));
+        }
+        const double search_seconds = seconds_since(t0);
+        const double recall = average_recall_at_k(retrieved, data.gt, args.k);
+        const double qps = search_seconds > 0.0 ? (double)data.test.size() / search_seconds : 0.0;
+
+        t0 = std::chrono::steady_clock::now();
+        const auto batched = index.search_batched(data.test, args.k);
+        const double batched_seconds = seconds_since(t0);
+        const double batched_qps = batched_seconds > 0.0 ? (double)data.test.size() / batched_seconds : 0.0;
+        bool batched_equal = batched.size() == retrieved.size();
+        for (size_t i = 0; batched_equal && i < batched.size(); ++i) {
+            batched_equal = batched[i].size() == retrieved[i].size();
+            for (size_t j = 0; batched_equal && j < batched[i].size(); ++j)
+                batched_equal = batched[i][j].first == retrieved[i][j];
+        }
+
+        std::printf("=== ANN-Benchmarks style report ===\n");
+        std::printf("dataset: %s\n", data.source.c_str());
+        std::printf("algorithm: %s\n", algorithm_debug(args.algorithm));
+        std::printf("distance: %s\n", distance_debug(args.distance));
+        std::printf("k: %zu\n", args.k);
+        std::printf("train/test/dim: %zu/%zu/%zu\n", data.train.size(), data.test.size(), data.dimension);
+        std::printf("build_seconds: %.6f\n", build_seconds);
+        std::printf("search_seconds: %.6f\n", search_seconds);
+        std::printf("qps: %.2f\n", qps);
+        std::printf("recall@%zu: %.6f\n", args.k, recall);
+        const bool rss_ok = before_rss >= 0 && after_rss >= before_rss;
+        if (rss_ok) std::printf("index_rss_delta_bytes: %ld\n", after_rss - before_rss);
+        else std::printf("index_rss_delta_bytes: unavailable\n");
+        std::printf("batched_search_seconds: %.6f\n", batched_seconds);
+        std::printf("batched_qps: %.2f\n", batched_qps);
+        std::printf("batched_equals_sequential: %s\n", batched_equal ? "true" : "false");
+        std::printf("json: {\"dataset\":\"%s\",\"algorithm\":\"%s\",\"distance\":\"%s\",\"k\":%zu,\"train_size\":%zu,"
+                    "\"test_size\":%zu,\"dimension\":%zu,\"build_seconds\":%.9g,\"search_seconds\":%.9g,\"qps\":%.9g,"
+                    "\"recall_at_k\":%.9g,\"index_rss_delta_bytes\":",
+                    data.source.c_str(), algorithm_snake(args.algorithm), distance_snake(args.distance), args.k,
+                    data.train.size(), data.test.size(), data.dimension, build_seconds, search_seconds, qps, recall);
+        if (rss_ok) std::printf("%ld", after_rss - before_rss);
+        else std::printf("null");
+        std::printf(",\"batched_search_seconds\":%.9g,\"batched_qps\":%.9g,\"batched_equals_sequential\":%s}\n",
+                    batched_seconds, batched_qps, batched_equal ? "true" : "false");
+    } catch (const ScannError &e) {
+        std::fprintf(stderr, "Error: ScannError %d: %s\n", (int)e.code, e.what());
+        return 1;
+    }
+    return 0;
+}

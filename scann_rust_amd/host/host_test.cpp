@@ -3,6 +3,7 @@
 //   brute_force/searcher.rs:280-376, tests/unit_tests.rs:204-259
 //   hashes/hasher.rs:322-380
 //   tree_x_hybrid/mod.rs:436-468
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 
@@ -123,13 +124,73 @@ static void tree_x_hybrid_tests() {
     EXPECT(empty);
 }
 
-static void builder_tests() {   // scann.rs:364-426
-    auto bf = ScannBuilder().num_neighbors(3).brute_force().build(cube());
-    EXPECT(bf.search({0, 0, 0}, 3).size() == 3);
-    auto t = ScannBuilder().num_neighbors(10).tree(8, 4).hash(8).reorder(40).build(sin_dataset(400, 32));
-    auto r = t.search(std::vector<float>(32, 0.25f), 10);
+static DenseDataset scann_test_dataset() {   // scann.rs:438-448
+    std::vector<std::vector<float>> v(100, std::vector<float>(16));
+    for (int i = 0; i < 100; ++i)
+        for (int j = 0; j < 16; ++j) v[i][j] = std::sin((float)i + (float)j * 0.1f);
+    return DenseDataset::from_vecs(v);
+}
+
+static void scann_facade_tests() {   // scann.rs:450-496 + the four search modes (:181-294)
+    auto bf = Scann::brute_force(scann_test_dataset());   // test_scann_brute_force
+    EXPECT(bf.search_mode() == SearchMode::BruteForce && bf.size() == 100);
+    EXPECT(bf.search(std::vector<float>(16, 0.5f), 10).size() == 10);
+    auto b = ScannBuilder().num_neighbors(5).distance_measure(DistanceMeasure::SquaredL2).brute_force()
+                 .build(scann_test_dataset());            // test_scann_builder
+    EXPECT(b.config().num_neighbors == 5 && b.distance_measure() == DistanceMeasure::SquaredL2);
+    auto br = bf.search_batched({std::vector<float>(16, 0.5f), std::vector<float>(16, 0.3f),
+                                 std::vector<float>(16, 0.7f)}, 5);   // test_scann_batched
+    EXPECT(br.size() == 3);
+    for (auto &r : br) EXPECT(r.size() == 5);
+    EXPECT(ScannBuilder().num_neighbors(3).brute_force().build(cube()).search({0, 0, 0}, 3).size() == 3);
+
+    const std::vector<float> q(32, 0.25f);
+    auto exact = Scann::brute_force(sin_dataset(400, 32)).search(q, 400);
+    // Partitioned: every partition searched == brute force over the same rows (same kernel maths)
+    auto part = Scann::partitioned(sin_dataset(400, 32), 8, 8);
+    EXPECT(part.search_mode() == SearchMode::Partitioned);
+    auto pr = part.search(q, 10);
+    EXPECT(pr.size() == 10);
+    sorted(pr);
+    for (size_t i = 0; i < pr.size(); ++i) EXPECT(pr[i].second == exact[i].second);
+    auto few = Scann::partitioned(sin_dataset(400, 32), 8, 2).search(q, 10);
+    EXPECT(few.size() == 10 && few[0].second >= exact[0].second);
+    sorted(few);
+    // DotProduct through the builder: distances are negated dots
+    auto dp = ScannBuilder().distance_measure(DistanceMeasure::DotProduct).tree(8, 8).build(sin_dataset(400, 32));
+    auto dexact = ScannBuilder().distance_measure(DistanceMeasure::DotProduct).brute_force().build(sin_dataset(400, 32));
+    auto d1 = dp.search(q, 5), d2 = dexact.search(q, 5);
+    for (size_t i = 0; i < 5; ++i) EXPECT(d1[i].second == d2[i].second);
+    // Hashed (256 buckets x num_blocks) and TreeAH, without and with the exact reordering
+    auto hashed = Scann::hashed(sin_dataset(400, 32), 8);
+    EXPECT(hashed.search_mode() == SearchMode::Hashed);
+    auto hr = hashed.search(q, 10);
+    EXPECT(hr.size() == 10);
+    sorted(hr);
+    auto t = ScannBuilder().num_neighbors(10).tree(8, 4).hash(8).build(sin_dataset(400, 32));
+    EXPECT(t.search_mode() == SearchMode::TreeAH);
+    auto r = t.search(q, 10);
     EXPECT(r.size() == 10);
     sorted(r);
+    auto tr = ScannBuilder().num_neighbors(10).tree(8, 4).hash(8).reorder(40).build(sin_dataset(400, 32));
+    auto rr = tr.search(q, 10);
+    EXPECT(rr.size() == 10);
+    sorted(rr);
+    {   // the reordering re-scores the SAME k rows exactly (scann.rs:199-209)
+        std::vector<uint32_t> a, c;
+        for (auto &p : r) a.push_back(p.first);
+        for (auto &p : rr) c.push_back(p.first);
+        std::sort(a.begin(), a.end());
+        std::sort(c.begin(), c.end());
+        EXPECT(a == c);
+        for (auto &p : rr) {
+            bool found = false;
+            for (auto &e : exact) if (e.first == p.first) { found = e.second == p.second; break; }
+            EXPECT(found);
+        }
+    }
+    auto tb = t.search_batched({q, q}, 10);
+    EXPECT(tb.size() == 2 && tb[0] == r && tb[1] == r);
     bool threw = false;
     try { ScannBuilder().build(DenseDataset()); } catch (const ScannError &e) { threw = e.code == ErrorCode::InvalidArgument; }
     EXPECT(threw);
@@ -140,7 +201,7 @@ int main() {
         brute_force_tests();
         hasher_tests();
         tree_x_hybrid_tests();
-        builder_tests();
+        scann_facade_tests();
     } catch (const ScannError &e) {
         std::printf("ScannError %d: %s\n", (int)e.code, e.what());
         return 2;

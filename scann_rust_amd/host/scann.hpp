@@ -168,6 +168,7 @@ struct IndexHandle {
     IndexHandle() = default;
     IndexHandle(const IndexHandle &) = delete;
     IndexHandle &operator=(const IndexHandle &) = delete;
+    IndexHandle(IndexHandle &&o) noexcept : h(o.h) { o.h = nullptr; }
     ~IndexHandle() { if (h) scann_hip_index_destroy(h); }
 };
 
@@ -237,6 +238,12 @@ inline std::vector<float> train_codebook(scann_hip_index *bf, size_t n, uint32_t
     }
     return cb;
 }
+
+// TreePartitioner::build (tree_partitioner.rs:48-98): flat k-means with seed 42 on the GPU, then the
+// CSR leaf lists (ascending datapoint index inside each leaf, :84-89).
+inline void build_partition(const DenseDataset &ds, size_t num_partitions, size_t iterations, int device,
+                            std::vector<float> &centers, std::vector<uint32_t> &leaf_off,
+                            std::vector<uint32_t> &leaf_ids);
 
 }  // namespace detail
 
@@ -411,24 +418,9 @@ public:
         if (dim % S != 0)
             throw ScannError::invalid_argument("Dimensionality " + std::to_string(dim) +
                                                " must be divisible by num_subspaces " + std::to_string(S));
-        // TreePartitioner::build: flat k-means, seed 42 (tree_partitioner.rs:48-98), on the GPU.
-        std::vector<uint32_t> assign;
-        {
-            detail::IndexHandle tmp;
-            check(scann_hip_bf_create(context(device_), ds.raw_data(), n, (uint32_t)dim, (uint32_t)st,
-                                      SCANN_HIP_SQUARED_L2, &tmp.h));
-            detail::kmeans_gpu(tmp.h, n, 0, dim, config_.num_partitions, config_.kmeans_iterations, 1e-5, 42,
-                               centers_, assign);
-        }
+        detail::build_partition(ds, config_.num_partitions, config_.kmeans_iterations, device_, centers_, leaf_off_,
+                                leaf_ids_);
         const uint32_t L = (uint32_t)(centers_.size() / dim);
-        leaf_off_.assign(L + 1, 0);
-        for (uint32_t a : assign) ++leaf_off_[a + 1];
-        for (uint32_t l = 0; l < L; ++l) leaf_off_[l + 1] += leaf_off_[l];
-        leaf_ids_.assign(n, 0);
-        {
-            std::vector<uint32_t> cur(leaf_off_.begin(), leaf_off_.end() - 1);
-            for (size_t i = 0; i < n; ++i) leaf_ids_[cur[assign[i]]++] = (uint32_t)i;   // ascending idx per leaf
-        }
         // residual rows in CSR order (mod.rs:177-189), codebook on residuals (:151-158)
         std::vector<float> rows(n * dim);
         std::vector<uint32_t> leaf_of_row(n);
@@ -514,62 +506,220 @@ private:
     detail::IndexHandle ix_;
 };
 
-// ---- Scann facade (scann.rs:35-56, 181-212, 364-426) ---------------------------------------------
+namespace detail {
+inline void build_partition(const DenseDataset &ds, size_t num_partitions, size_t iterations, int device,
+                            std::vector<float> &centers, std::vector<uint32_t> &leaf_off,
+                            std::vector<uint32_t> &leaf_ids) {
+    const size_t n = ds.size(), dim = ds.dimensionality();
+    std::vector<uint32_t> assign;
+    {
+        IndexHandle tmp;
+        check(scann_hip_bf_create(context(device), ds.raw_data(), n, (uint32_t)dim, ds.stride(), SCANN_HIP_SQUARED_L2,
+                                  &tmp.h));
+        kmeans_gpu(tmp.h, n, 0, dim, num_partitions, iterations, 1e-5, 42, centers, assign);
+    }
+    const uint32_t L = (uint32_t)(centers.size() / dim);
+    leaf_off.assign(L + 1, 0);
+    for (uint32_t a : assign) ++leaf_off[a + 1];
+    for (uint32_t l = 0; l < L; ++l) leaf_off[l + 1] += leaf_off[l];
+    leaf_ids.assign(n, 0);
+    std::vector<uint32_t> cur(leaf_off.begin(), leaf_off.end() - 1);
+    for (size_t i = 0; i < n; ++i) leaf_ids[cur[assign[i]]++] = (uint32_t)i;   // ascending idx per leaf
+}
+}  // namespace detail
+
+// ---- ScannConfig (config.rs:10-320: the fields the hot path reads) ------------------------------
+struct PartitioningConfig {          // config.rs:134-199
+    uint32_t num_partitions = 100, num_partitions_to_search = 10;
+};
+struct HashConfig {                  // config.rs:202-261
+    uint32_t num_buckets = 256, num_blocks = 16;
+};
+struct ExactReorderingConfig {       // config.rs:283-320
+    uint32_t num_candidates = 100;
+};
+struct ScannConfig {                 // config.rs:10-118
+    uint32_t num_neighbors = 10;
+    DistanceMeasure distance_measure = DistanceMeasure::SquaredL2;
+    bool brute_force = false;
+    bool has_partitioning = false, has_hash = false, has_exact_reordering = false;
+    PartitioningConfig partitioning;
+    HashConfig hash;
+    ExactReorderingConfig exact_reordering;
+    ScannConfig with_num_neighbors(uint32_t k) const { auto c = *this; c.num_neighbors = k; return c; }
+    ScannConfig with_distance_measure(DistanceMeasure m) const { auto c = *this; c.distance_measure = m; return c; }
+    ScannConfig with_brute_force() const {   // :63-68 clears the other two
+        auto c = *this; c.brute_force = true; c.has_partitioning = false; c.has_hash = false; return c;
+    }
+    ScannConfig with_partitioning(PartitioningConfig p) const { auto c = *this; c.partitioning = p; c.has_partitioning = true; return c; }
+    ScannConfig with_hash(HashConfig h) const { auto c = *this; c.hash = h; c.has_hash = true; return c; }
+    ScannConfig with_exact_reordering(ExactReorderingConfig r) const {
+        auto c = *this; c.exact_reordering = r; c.has_exact_reordering = true; return c;
+    }
+};
+
+enum class SearchMode { BruteForce, Partitioned, Hashed, TreeAH };   // scann.rs:17-28
+
+// ---- Scann facade (scann.rs:30-362) ------------------------------------------------------------
+// One GPU index per mode, all configurations of the same kernels (include/scann_hip.h):
+//   Partitioned  exact scan of the selected leaves' rows     search_partitioned  :213-252
+//   Hashed       AsymmetricHasher::search                    search_impl         :189-192
+//   TreeAH       one non-residual table per query, k best    search_tree_ah      :255-294
+// and the exact reordering of the k-truncated list with the configured measure (:199-209) runs
+// inside the same search call (pre_reorder_k = k, exact_reorder = 1).
 class Scann {
 public:
-    NNResultsVector search(const std::vector<float> &q, size_t k) const {
-        if (txh_) return txh_->search(q, k);
-        if (ah_) return reorder_ ? ah_->search_with_reordering(q, k, reorder_) : ah_->search(q, k);
-        return bf_->search(q, k);
+    explicit Scann(DenseDataset dataset, int device = 0) : Scann(std::move(dataset), ScannConfig(), device) {}
+    Scann(DenseDataset dataset, ScannConfig config, int device = 0) : config_(config), device_(device) {   // :63-103
+        if (dataset.is_empty()) throw ScannError::invalid_argument("Dataset cannot be empty");  // :64-66
+        dataset_ = std::make_shared<DenseDataset>(std::move(dataset));
+        bf_.reset(new BruteForceSearcher(dataset_, config_.distance_measure, device));
+        if (config_.brute_force) {
+            mode_ = SearchMode::BruteForce;
+        } else if (config_.has_partitioning && config_.has_hash) {
+            init_partitioning();
+            init_hashing();
+            mode_ = SearchMode::TreeAH;
+            create_index(true, true);
+        } else if (config_.has_partitioning) {
+            init_partitioning();
+            mode_ = SearchMode::Partitioned;
+            create_index(true, false);
+        } else if (config_.has_hash) {
+            init_hashing();
+            mode_ = SearchMode::Hashed;
+            create_index(false, true);
+        }
     }
+    static Scann brute_force(DenseDataset ds) { return Scann(std::move(ds), ScannConfig().with_brute_force()); }   // :106-109
+    static Scann partitioned(DenseDataset ds, uint32_t num_partitions, uint32_t partitions_to_search) {          // :112-124
+        PartitioningConfig p;
+        p.num_partitions = num_partitions;
+        p.num_partitions_to_search = partitions_to_search;
+        return Scann(std::move(ds), ScannConfig().with_partitioning(p));
+    }
+    static Scann hashed(DenseDataset ds, uint32_t num_blocks) {                                                  // :127-137
+        HashConfig h;
+        h.num_blocks = num_blocks;
+        return Scann(std::move(ds), ScannConfig().with_hash(h));
+    }
+
+    NNResultsVector search(const std::vector<float> &q, size_t k) const {      // :175-212
+        return search_batched({q}, k)[0];
+    }
+    // :297-303 maps search over the queries; here the whole batch is one GPU call
     std::vector<NNResultsVector> search_batched(const std::vector<std::vector<float>> &qs, size_t k) const {
-        if (txh_) return txh_->search_batched(qs, k);
-        if (ah_ && !reorder_) return ah_->search_batched(qs, k);
-        if (ah_) { std::vector<NNResultsVector> r; for (auto &q : qs) r.push_back(search(q, k)); return r; }
-        return bf_->search_batched(qs, k);
+        if (qs.empty()) return {};
+        // the reordering of a brute-force result re-scores it with the same kernel: a no-op
+        if (mode_ == SearchMode::BruteForce) return bf_->search_batched(qs, k);
+        uint32_t d;
+        auto flat = detail::flatten(qs, &d);
+        scann_hip_search_opts o;
+        scann_hip_search_opts_default(&o);
+        o.pre_reorder_k = (uint32_t)k;
+        const bool reorder = config_.has_exact_reordering && config_.exact_reordering.num_candidates > k;   // :199-201
+        o.exact_reorder = (reorder && mode_ != SearchMode::Partitioned) ? 1 : 0;
+        if (mode_ != SearchMode::Hashed) o.partitions_to_search = config_.partitioning.num_partitions_to_search;
+        return detail::run_search(ix_.h, flat.data(), (uint32_t)qs.size(), d, d, (uint32_t)k, &o);
     }
-    size_t size() const { return n_; }
+    SearchMode search_mode() const { return mode_; }
+    size_t size() const { return dataset_->size(); }
+    uint64_t dimensionality() const { return dataset_->dimensionality(); }
+    DistanceMeasure distance_measure() const { return config_.distance_measure; }
+    const ScannConfig &config() const { return config_; }
+    size_t dataset_size() const { return size(); }
 
 private:
-    friend class ScannBuilder;
+    void init_partitioning() {   // :140-150 -> TreePartitioner::build (tree_partitioner.rs:48-98)
+        detail::build_partition(*dataset_, config_.partitioning.num_partitions, 100, device_, centers_, leaf_off_,
+                                leaf_ids_);
+    }
+    void init_hashing() {        // :153-165 -> AsymmetricHasher::build (hasher.rs:109-134)
+        const DenseDataset &ds = *dataset_;
+        const uint32_t S = config_.hash.num_blocks, K = config_.hash.num_buckets, dim = (uint32_t)ds.dimensionality();
+        AsymmetricHasherConfig hc(K, S);
+        detail::IndexHandle tmp;
+        check(scann_hip_bf_create(context(device_), ds.raw_data(), ds.size(), dim, ds.stride(), SCANN_HIP_SQUARED_L2,
+                                  &tmp.h));
+        codebook_ = detail::train_codebook(tmp.h, ds.size(), dim, S, K, hc.seed, hc.training_iterations,
+                                           hc.convergence_threshold);
+        codes_.assign(ds.size() * S, 0);
+        check(scann_hip_encode(context(device_), codebook_.data(), S, K, dim / S, ds.raw_data(), ds.size(),
+                               ds.stride(), nullptr, nullptr, codes_.data()));
+    }
+    void create_index(bool tree, bool hash) {
+        const DenseDataset &ds = *dataset_;
+        const size_t n = ds.size();
+        scann_hip_txh_desc d{};
+        d.data = ds.raw_data();
+        d.n_rows = n;
+        d.dim = (uint32_t)ds.dimensionality();
+        d.stride = ds.stride();
+        d.n_local = n;
+        d.distance_measure = (int)config_.distance_measure;
+        d.partitions_to_search = tree ? config_.partitioning.num_partitions_to_search : 1;
+        d.pre_reorder_multiplier = 1.0f;
+        std::vector<uint8_t> csr_codes;
+        if (tree) {
+            d.centers = centers_.data();
+            d.num_partitions = (uint32_t)(leaf_off_.size() - 1);
+            d.leaf_offsets = leaf_off_.data();
+            d.leaf_ids = leaf_ids_.data();
+        }
+        if (hash) {
+            const uint32_t S = config_.hash.num_blocks;
+            d.codebook = codebook_.data();
+            d.num_subspaces = S;
+            d.num_codes = config_.hash.num_buckets;
+            d.dims_per_subspace = d.dim / S;
+            d.codes = codes_.data();
+            if (tree) {   // encoded_database()[idx] (scann.rs:283) laid out in CSR row order
+                csr_codes.resize(n * S);
+                for (size_t r = 0; r < n; ++r)
+                    std::memcpy(&csr_codes[r * S], &codes_[(size_t)leaf_ids_[r] * S], S);
+                d.codes = csr_codes.data();
+            }
+        }
+        check(scann_hip_txh_create(context(device_), &d, &ix_.h));
+    }
+
+    ScannConfig config_;
+    int device_;
+    SearchMode mode_ = SearchMode::BruteForce;
+    std::shared_ptr<DenseDataset> dataset_;
     std::unique_ptr<BruteForceSearcher> bf_;
-    std::unique_ptr<AsymmetricHasher> ah_;
-    std::unique_ptr<TreeXHybridSearcher> txh_;
-    size_t reorder_ = 0, n_ = 0;
+    std::vector<float> centers_, codebook_;
+    std::vector<uint32_t> leaf_off_, leaf_ids_;
+    std::vector<uint8_t> codes_;
+    detail::IndexHandle ix_;
 };
 
 class ScannBuilder {   // scann.rs:364-426
 public:
-    ScannBuilder &num_neighbors(size_t k) { k_ = k; return *this; }
-    ScannBuilder &distance_measure(DistanceMeasure m) { measure_ = m; return *this; }
-    ScannBuilder &brute_force() { brute_ = true; return *this; }
-    ScannBuilder &tree(size_t num_partitions, size_t to_search) { L_ = num_partitions; P_ = to_search; return *this; }
-    ScannBuilder &hash(size_t num_blocks) { blocks_ = num_blocks; return *this; }
-    ScannBuilder &reorder(size_t n) { reorder_ = n; return *this; }
-    Scann build(DenseDataset dataset) {
-        if (dataset.is_empty()) throw ScannError::invalid_argument("Dataset cannot be empty");  // scann.rs:66-68
-        Scann s;
-        s.n_ = dataset.size();
-        if (brute_ || (!L_ && !blocks_)) {
-            s.bf_.reset(new BruteForceSearcher(std::move(dataset), measure_));
-        } else if (L_) {
-            TreeXHybridConfig c(L_, P_);
-            c.hash_config = AsymmetricHasherConfig(16, blocks_ ? blocks_ : 8);
-            if (reorder_) c.pre_reorder_multiplier = (float)reorder_ / (float)std::max<size_t>(1, k_);
-            s.txh_.reset(new TreeXHybridSearcher(c));
-            s.txh_->build(std::move(dataset));
-        } else {
-            s.ah_.reset(new AsymmetricHasher(AsymmetricHasherConfig(16, blocks_)));
-            s.ah_->build(std::move(dataset));
-            s.reorder_ = reorder_;
-        }
-        return s;
+    ScannBuilder &num_neighbors(uint32_t k) { config_.num_neighbors = k; return *this; }
+    ScannBuilder &distance_measure(DistanceMeasure m) { config_.distance_measure = m; return *this; }
+    ScannBuilder &brute_force() { config_ = config_.with_brute_force(); return *this; }
+    ScannBuilder &tree(uint32_t num_partitions, uint32_t partitions_to_search) {
+        config_.partitioning.num_partitions = num_partitions;
+        config_.partitioning.num_partitions_to_search = partitions_to_search;
+        config_.has_partitioning = true;
+        return *this;
     }
+    ScannBuilder &hash(uint32_t num_blocks) {
+        config_.hash = HashConfig();
+        config_.hash.num_blocks = num_blocks;
+        config_.has_hash = true;
+        return *this;
+    }
+    ScannBuilder &reorder(uint32_t num_candidates) {
+        config_.exact_reordering.num_candidates = num_candidates;
+        config_.has_exact_reordering = true;
+        return *this;
+    }
+    Scann build(DenseDataset dataset) const { return Scann(std::move(dataset), config_); }
 
 private:
-    size_t k_ = 10, L_ = 0, P_ = 0, blocks_ = 0, reorder_ = 0;
-    bool brute_ = false;
-    DistanceMeasure measure_ = DistanceMeasure::SquaredL2;
+    ScannConfig config_;
 };
 
 }  // namespace scann
