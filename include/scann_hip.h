@@ -255,6 +255,40 @@ int scann_hip_txh_pack_blocks_device(scann_hip_ctx *ctx, uint32_t world, uint32_
 int scann_hip_assign_leaves(const uint32_t *leaf_sizes, uint32_t num_partitions,
                             uint32_t world, uint32_t *out_owner);
 
+/* ---- index files ---------------------------------------------------------
+ * The reference keeps indexes in memory only (no save/load: SURVEY section 5); its arrays are the
+ * DenseDataset buffer (data_format/dataset.rs:46-61), TreePartitioner.centers and the partition
+ * lists (partitioning/partitioner.rs:132-142, tree_x_hybrid/mod.rs:81-90), the Codebook and the
+ * per-point codes.  One little-endian container holds exactly the fields of scann_hip_txh_desc /
+ * the arguments of scann_hip_bf_create, so the GPU library, the CPU oracle (numpy reader:
+ * scann_rust_amd/index_file.py) and the golden fixtures share it:
+ *
+ *   [0, 256)   header   "SCANNIDX", version 1, kind (0 brute force, 1 tree / hasher index), the
+ *                        scalar descriptor fields, section count, file size
+ *   [256, ...) table    64 bytes per section: name[24], dtype (0 f32, 1 u32, 2 u8), offset, bytes
+ *   sections   "data" "centers" "leaf_offsets" "leaf_ids" "leaf_sizes_global" "codebook" "codes",
+ *              each starting on a 4096-byte boundary (absent arrays have no section)
+ *
+ * write: host arrays -> file.  load: the file is mmap'ed (never read into a second host copy), the
+ * mapping pinned for DMA when the driver allows it (SCANN_HIP_LOAD_PIN=0 skips that), and the
+ * arrays uploaded by the same code as scann_hip_*_create.  Errors: missing file -> NotFound; bad
+ * magic / version -> InvalidArgument; truncated or inconsistent file -> DataLoss. */
+typedef struct {
+    uint32_t version;
+    uint32_t kind;                 /* 0 = brute force, 1 = tree / hasher index */
+    uint64_t n_rows, n_local, file_bytes;
+    uint32_t dim, stride, num_partitions, num_subspaces, num_codes, dims_per_subspace;
+    int32_t distance_measure, data_is_csr_order, codes_packed4, use_residuals;
+    uint32_t partitions_to_search;
+    float pre_reorder_multiplier;
+    int32_t has_data;              /* exact re-ordering possible */
+} scann_hip_file_info;
+int scann_hip_txh_write_file(const char *path, const scann_hip_txh_desc *desc);
+int scann_hip_bf_write_file(const char *path, const float *data, uint64_t n, uint32_t dim,
+                            uint32_t stride, int measure);
+int scann_hip_index_file_info(const char *path, scann_hip_file_info *out_info);
+int scann_hip_index_load_file(scann_hip_ctx *ctx, const char *path, scann_hip_index **out_index);
+
 /* ---- building blocks exposed for parity tests / callers ---------------------- */
 /* TreePartitioner::partition for a batch (tree_partitioner.rs:196-229). */
 int scann_hip_txh_partition(scann_hip_index *index, const float *queries, uint32_t nq,

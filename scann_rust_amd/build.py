@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libscann_hip.so")
-SOURCES = ["api.hip", "txh.hip", "bf.hip"]
+SOURCES = ["api.hip", "txh.hip", "bf.hip", "index_file.hip"]
 HEADERS = ["common.h", "txh.h", "bf.h", os.path.join("..", "..", "include", "scann_hip.h")]
 # -ffp-contract=off: the reference never contracts a*b+c (Rust); FMA is used only via
 # explicit fmaf()/MFMA where the reference uses _mm256_fmadd_ps.

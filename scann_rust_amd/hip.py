@@ -35,6 +35,8 @@ EXPORTS = [
     "scann_hip_kmeans_init_pp", "scann_hip_kmeans_lloyd", "scann_hip_txh_pack_blocks_device", "scann_hip_index_size", "scann_hip_index_dimensionality",
     "scann_hip_index_destroy", "scann_hip_index_enable_timing",
     "scann_hip_index_last_kernel_ms",
+    "scann_hip_txh_write_file", "scann_hip_bf_write_file", "scann_hip_index_file_info",
+    "scann_hip_index_load_file",
 ]
 
 
@@ -66,6 +68,18 @@ class TxhDesc(C.Structure):
         ("codes", u8p), ("codes_packed4", C.c_int32), ("use_residuals", C.c_int32),
         ("partitions_to_search", C.c_uint32), ("pre_reorder_multiplier", C.c_float),
         ("distance_measure", C.c_int32),
+    ]
+
+
+class FileInfo(C.Structure):
+    _fields_ = [
+        ("version", C.c_uint32), ("kind", C.c_uint32),
+        ("n_rows", C.c_uint64), ("n_local", C.c_uint64), ("file_bytes", C.c_uint64),
+        ("dim", C.c_uint32), ("stride", C.c_uint32), ("num_partitions", C.c_uint32),
+        ("num_subspaces", C.c_uint32), ("num_codes", C.c_uint32), ("dims_per_subspace", C.c_uint32),
+        ("distance_measure", C.c_int32), ("data_is_csr_order", C.c_int32), ("codes_packed4", C.c_int32),
+        ("use_residuals", C.c_int32), ("partitions_to_search", C.c_uint32),
+        ("pre_reorder_multiplier", C.c_float), ("has_data", C.c_int32),
     ]
 
 
@@ -102,6 +116,10 @@ def load():
     L.scann_hip_bf_create.argtypes = [vp, f32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int,
                                       C.POINTER(vp)]
     L.scann_hip_txh_create.argtypes = [vp, C.POINTER(TxhDesc), C.POINTER(vp)]
+    L.scann_hip_txh_write_file.argtypes = [C.c_char_p, C.POINTER(TxhDesc)]
+    L.scann_hip_bf_write_file.argtypes = [C.c_char_p, f32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
+    L.scann_hip_index_file_info.argtypes = [C.c_char_p, C.POINTER(FileInfo)]
+    L.scann_hip_index_load_file.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
     L.scann_hip_search_opts_default.argtypes = [C.POINTER(SearchOpts)]
     L.scann_hip_search_opts_default.restype = None
     L.scann_hip_search_batched.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -268,6 +286,45 @@ def txh_create(*, data, n_rows, dim, stride, centers, leaf_offsets, leaf_ids, co
                pre_reorder_multiplier=3.0, leaf_sizes_global=None, data_is_csr_order=False,
                distance_measure=SQUARED_L2, device=0):
     """codebook=None and codes=None: SearchMode::Partitioned (exact scan of the selected leaves)."""
+    d, keep = _txh_desc(data=data, n_rows=n_rows, dim=dim, stride=stride, centers=centers,
+                        leaf_offsets=leaf_offsets, leaf_ids=leaf_ids, codebook=codebook, codes=codes,
+                        codes_packed4=codes_packed4, use_residuals=use_residuals,
+                        partitions_to_search=partitions_to_search,
+                        pre_reorder_multiplier=pre_reorder_multiplier, leaf_sizes_global=leaf_sizes_global,
+                        data_is_csr_order=data_is_csr_order, distance_measure=distance_measure)
+    h = vp()
+    check(load().scann_hip_txh_create(context(device), C.byref(d), C.byref(h)))
+    return Index(h)
+
+
+def txh_write_file(path, *, device=None, **kw):
+    """Write the index the same keyword arguments would create (no GPU needed)."""
+    d, keep = _txh_desc(**kw)
+    check(load().scann_hip_txh_write_file(os.fsencode(path), C.byref(d)))
+
+
+def bf_write_file(path, data, n, dim, stride, measure):
+    d = f32(data)
+    check(load().scann_hip_bf_write_file(os.fsencode(path), ptr(d, f32p) if n else None, n, dim, stride, measure))
+
+
+def index_file_info(path):
+    info = FileInfo()
+    check(load().scann_hip_index_file_info(os.fsencode(path), C.byref(info)))
+    return {name: getattr(info, name) for name, _ in FileInfo._fields_}
+
+
+def load_file(path, device=0):
+    """mmap the index file and upload it (scann_hip_index_load_file)."""
+    h = vp()
+    check(load().scann_hip_index_load_file(context(device), os.fsencode(path), C.byref(h)))
+    return Index(h)
+
+
+def _txh_desc(*, data, n_rows, dim, stride, centers, leaf_offsets, leaf_ids, codebook, codes,
+              codes_packed4=False, use_residuals=True, partitions_to_search=10,
+              pre_reorder_multiplier=3.0, leaf_sizes_global=None, data_is_csr_order=False,
+              distance_measure=SQUARED_L2):
     d = TxhDesc()
     keep = []
 
@@ -305,9 +362,7 @@ def txh_create(*, data, n_rows, dim, stride, centers, leaf_offsets, leaf_ids, co
     d.use_residuals = 1 if use_residuals else 0
     d.partitions_to_search = partitions_to_search
     d.pre_reorder_multiplier = pre_reorder_multiplier
-    h = vp()
-    check(load().scann_hip_txh_create(context(device), C.byref(d), C.byref(h)))
-    return Index(h)
+    return d, keep
 
 
 def txh_partition(index, queries, num_partitions, q_dim=None):

@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <string>
+#include <unistd.h>
 
 #include "scann.hpp"
 
@@ -111,6 +113,18 @@ static void tree_x_hybrid_tests() {
     auto tr = s.search_with_filter(q, 10, &two);
     EXPECT(tr.size() <= 2);
     for (auto &p : tr) EXPECT(p.first == 7 || p.first == 11);
+    {   // index file round trip: the loaded searcher answers exactly like the built one
+        const std::string path = "/tmp/scann_host_test_" + std::to_string((long)getpid()) + ".scannidx";
+        s.save(path);
+        auto loaded = TreeXHybridSearcher::load(path);
+        EXPECT(loaded.num_partitions() == 10 && loaded.num_datapoints() == 500 && loaded.dimensionality() == 32);
+        EXPECT(loaded.search(q, 10) == r);
+        EXPECT(loaded.search_with_filter(q, 10, &allow) == fr);
+        std::remove(path.c_str());
+        bool missing = false;
+        try { TreeXHybridSearcher::load(path); } catch (const ScannError &e) { missing = e.code == ErrorCode::NotFound; }
+        EXPECT(missing);
+    }
     // TreeXHybridConfig::default(): 100 partitions, search 10, 256 codes x 8 subspaces (mod.rs:37-48)
     TreeXHybridSearcher dflt{TreeXHybridConfig()};
     dflt.build(sin_dataset(3000, 32));

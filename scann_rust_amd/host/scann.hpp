@@ -413,7 +413,7 @@ public:
         if (dataset.is_empty()) throw ScannError::invalid_argument("Cannot build from empty dataset");
         dataset_ = std::make_shared<DenseDataset>(std::move(dataset));
         const DenseDataset &ds = *dataset_;
-        const size_t n = ds.size(), dim = ds.dimensionality(), st = ds.stride();
+        const size_t n = ds.size(), dim = ds.dimensionality();
         const uint32_t S = (uint32_t)config_.hash_config.num_subspaces, K = (uint32_t)config_.hash_config.num_codes;
         if (dim % S != 0)
             throw ScannError::invalid_argument("Dimensionality " + std::to_string(dim) +
@@ -442,24 +442,9 @@ public:
         codes_.assign(n * S, 0);
         check(scann_hip_encode(context(device_), codebook_.data(), S, K, (uint32_t)dim / S, rows.data(), n,
                                (uint32_t)dim, nullptr, nullptr, codes_.data()));
-        scann_hip_txh_desc d{};
-        d.data = ds.raw_data();
-        d.n_rows = n;
-        d.dim = (uint32_t)dim;
-        d.stride = (uint32_t)st;
-        d.centers = centers_.data();
-        d.num_partitions = L;
-        d.leaf_offsets = leaf_off_.data();
-        d.leaf_ids = leaf_ids_.data();
-        d.n_local = n;
-        d.codebook = codebook_.data();
-        d.num_subspaces = S;
-        d.num_codes = K;
-        d.dims_per_subspace = (uint32_t)dim / S;
-        d.codes = codes_.data();
-        d.use_residuals = config_.use_residuals ? 1 : 0;
-        d.partitions_to_search = (uint32_t)config_.partitions_to_search;
-        d.pre_reorder_multiplier = config_.pre_reorder_multiplier;
+        n_ = n;
+        dim_ = dim;
+        const scann_hip_txh_desc d = desc();
         if (ix_.h) { scann_hip_index_destroy(ix_.h); ix_.h = nullptr; }
         check(scann_hip_txh_create(context(device_), &d, &ix_.h));
     }
@@ -490,19 +475,68 @@ public:
         auto flat = detail::flatten(queries, &d);
         return detail::run_search(ix_.h, flat.data(), (uint32_t)queries.size(), d, d, (uint32_t)k, nullptr);
     }
-    size_t num_partitions() const { return leaf_off_.empty() ? 0 : leaf_off_.size() - 1; }
-    size_t num_datapoints() const { return dataset_ ? dataset_->size() : 0; }
+    size_t num_partitions() const { return L_ ? L_ : (leaf_off_.empty() ? 0 : leaf_off_.size() - 1); }
+    size_t num_datapoints() const { return n_; }
     size_t dataset_size() const { return num_datapoints(); }
-    uint64_t dimensionality() const { return dataset_ ? dataset_->dimensionality() : 0; }
+    uint64_t dimensionality() const { return dim_; }
     const TreeXHybridConfig &config() const { return config_; }
 
+    // Index files (include/scann_hip.h "index files"; the reference has no save/load): the built
+    // index as one SCANNIDX container, and a searcher over a file that is mmap'ed and uploaded
+    // without a second host copy.
+    void save(const std::string &path) const {
+        if (!ix_.h || !dataset_) throw ScannError::failed_precondition("Partitioner not built");
+        const scann_hip_txh_desc d = desc();
+        check(scann_hip_txh_write_file(path.c_str(), &d));
+    }
+    static TreeXHybridSearcher load(const std::string &path, int device = 0) {
+        scann_hip_file_info info;
+        check(scann_hip_index_file_info(path.c_str(), &info));
+        if (info.kind != 1 || info.num_partitions == 0 || info.num_subspaces == 0)
+            throw ScannError::invalid_argument(path + " does not hold a Tree-X-Hybrid index");
+        TreeXHybridConfig c(info.num_partitions, info.partitions_to_search);
+        c.hash_config = AsymmetricHasherConfig(info.num_codes, info.num_subspaces);
+        c.use_residuals = info.use_residuals != 0;
+        c.pre_reorder_multiplier = info.pre_reorder_multiplier;
+        TreeXHybridSearcher s(c, device);
+        check(scann_hip_index_load_file(context(device), path.c_str(), &s.ix_.h));
+        s.n_ = info.n_rows;
+        s.dim_ = info.dim;
+        s.L_ = info.num_partitions;
+        return s;
+    }
+
 private:
+    scann_hip_txh_desc desc() const {
+        const DenseDataset &ds = *dataset_;
+        const uint32_t S = (uint32_t)config_.hash_config.num_subspaces;
+        scann_hip_txh_desc d{};
+        d.data = ds.raw_data();
+        d.n_rows = ds.size();
+        d.dim = (uint32_t)ds.dimensionality();
+        d.stride = ds.stride();
+        d.centers = centers_.data();
+        d.num_partitions = (uint32_t)(leaf_off_.size() - 1);
+        d.leaf_offsets = leaf_off_.data();
+        d.leaf_ids = leaf_ids_.data();
+        d.n_local = ds.size();
+        d.codebook = codebook_.data();
+        d.num_subspaces = S;
+        d.num_codes = (uint32_t)config_.hash_config.num_codes;
+        d.dims_per_subspace = d.dim / S;
+        d.codes = codes_.data();
+        d.use_residuals = config_.use_residuals ? 1 : 0;
+        d.partitions_to_search = (uint32_t)config_.partitions_to_search;
+        d.pre_reorder_multiplier = config_.pre_reorder_multiplier;
+        return d;
+    }
     TreeXHybridConfig config_;
     int device_;
     std::shared_ptr<DenseDataset> dataset_;
     std::vector<float> centers_, codebook_;
     std::vector<uint32_t> leaf_off_, leaf_ids_;
     std::vector<uint8_t> codes_;
+    size_t n_ = 0, dim_ = 0, L_ = 0;
     detail::IndexHandle ix_;
 };
 
