@@ -1277,8 +1277,8 @@ struct SelectArgs {
     uint32_t *out_count;
 };
 
-// In-place stable compaction of list[0..cnt) keeping keys <= T, by one block.
-__device__ static uint32_t block_compact_le(uint64_t *list, uint32_t cnt, uint64_t T,
+// Stable compaction of list[0..cnt) keeping keys <= T into dst (dst == list: in place), by one block.
+__device__ static uint32_t block_compact_le(const uint64_t *list, uint64_t *dst, uint32_t cnt, uint64_t T,
                                             uint32_t *s_wave, uint32_t *s_base) {
     const uint32_t tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, nw = nt >> 6;
     if (tid == 0) *s_base = 0;
@@ -1297,7 +1297,7 @@ __device__ static uint32_t block_compact_le(uint64_t *list, uint32_t cnt, uint64
         __syncthreads();
         uint32_t off = *s_base;
         for (uint32_t w = 0; w < wave; ++w) off += s_wave[w];
-        if (keep) list[off + wpre] = key;   // off + wpre <= i: never overtakes unread data
+        if (keep) dst[off + wpre] = key;   // off + wpre <= i: never overtakes unread data
         __syncthreads();
         if (tid == 0) {
             uint32_t t = 0;
@@ -1343,23 +1343,21 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
     }
     uint64_t *list = a.cand + (size_t)q * a.cap;
 
-    while (cnt > sort_cap) {  // thin with a sampled bound until the list fits in LDS
-        const uint32_t stride = (cnt + sort_cap - 1) / sort_cap;
-        const uint32_t ns = (cnt + stride - 1) / stride;
-        uint32_t n2 = 1;
-        while (n2 < ns) n2 <<= 1;
-        for (uint32_t i = tid; i < n2; i += nt)
-            skeys[i] = (i < ns) ? list[(size_t)i * stride] : SCANN_KEY_MAX;
-        __syncthreads();
-        bitonic_sort_lds(skeys, n2);
-        const uint64_t T = (ns >= m) ? skeys[m - 1] : SCANN_KEY_MAX;
-        __syncthreads();
-        const uint32_t nc = block_compact_le(list, cnt, T, s_wave, s_basep);
-        __syncthreads();
-        if (nc >= cnt) break;  // no progress (cannot happen for m <= kMaxPreReorderK)
-        cnt = nc;
-    }
+    uint32_t *hist = reinterpret_cast<uint32_t *>(s_basep + 4);
+    uint64_t *slist = reinterpret_cast<uint64_t *>(hist + cfg.bins);
+    uint64_t *sred = slist + cfg.list;
+    bool in_lds = false;   // skeys[0..cnt) already holds the candidates
     if (cnt > sort_cap) {
+        // More candidates than LDS holds (no-threshold retry, dense lists of the exact leaf scan):
+        // rank-select the m-th smallest key straight from the global list, then keep the keys <= it
+        // (keys are unique, so exactly m remain; m <= kMaxPreReorderK <= sort_cap).
+        const uint64_t T = block_select<uint64_t>(list, cnt, m, cfg, hist, slist, sred);
+        __syncthreads();
+        cnt = block_compact_le(list, skeys, cnt, T, s_wave, s_basep);
+        __syncthreads();
+        in_lds = true;
+    }
+    if (cnt > sort_cap) {   // cannot happen: m <= sort_cap
         select_fail(a, q, (uint32_t)SCANN_HIP_RESOURCE_EXHAUSTED);
         return;
     }
@@ -1407,11 +1405,9 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
     if (a.unsorted) {
         // Selection without a sort: the m-th smallest key by histogram select, keep keys <= it.
         // The final stage orders by (exact, merge key), which equals (exact, approx rank).
-        for (uint32_t i = tid; i < cnt; i += nt) skeys[i] = list[i];
+        if (!in_lds)
+            for (uint32_t i = tid; i < cnt; i += nt) skeys[i] = list[i];
         __syncthreads();
-        uint32_t *hist = reinterpret_cast<uint32_t *>(s_basep + 4);
-        uint64_t *slist = reinterpret_cast<uint64_t *>(hist + cfg.bins);
-        uint64_t *sred = slist + cfg.list;
         const uint64_t T = cnt > m ? block_select<uint64_t>(skeys, cnt, m, cfg, hist, slist, sred) : SCANN_KEY_MAX;
         __syncthreads();
         uint32_t *s_slot = reinterpret_cast<uint32_t *>(sred);   // output cursor
@@ -1436,9 +1432,18 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
         return;
     }
 
+    if (!in_lds)
+        for (uint32_t i = tid; i < cnt; i += nt) skeys[i] = list[i];
+    __syncthreads();
+    if (cnt > 2 * m && cnt > 256) {   // sort only the m best: select the m-th key, compact in place
+        const uint64_t T = block_select<uint64_t>(skeys, cnt, m, cfg, hist, slist, sred);
+        __syncthreads();
+        cnt = block_compact_le(skeys, skeys, cnt, T, s_wave, s_basep);
+        __syncthreads();
+    }
     uint32_t n2 = 1;
     while (n2 < cnt) n2 <<= 1;
-    for (uint32_t i = tid; i < n2; i += nt) skeys[i] = (i < cnt) ? list[i] : SCANN_KEY_MAX;
+    for (uint32_t i = cnt + tid; i < n2; i += nt) skeys[i] = SCANN_KEY_MAX;
     __syncthreads();
     bitonic_sort_lds(skeys, n2);
 
