@@ -1119,8 +1119,14 @@ __global__ __launch_bounds__(kSelectThreads) void threshold_select_kernel(
 // dense key list [vbase[P]], from which select_rerank_kernel takes the k smallest keys.
 // =====================================================================================
 constexpr uint32_t kExactRows = 256;   // rows per tile chunk (one per thread)
-constexpr uint32_t kExactQuads = 8;    // quads per tile
+constexpr uint32_t kExactQuadsMax = 16; // quads per tile: all of them staged in LDS once per tile
 constexpr int kExactQT = 8;            // queries per pass over the row
+// quads per tile for this dimensionality: the tile's queries must fit 48 KB of LDS
+static inline uint32_t exact_quads_per_tile(uint32_t dim) {
+    const uint32_t dimp = (dim + 3u) & ~3u;
+    uint32_t q = (48u * 1024u) / (dimp * 4u) / 8u * 2u;   // whole passes of 8 queries, in quads
+    return q < 2u ? 2u : (q > kExactQuadsMax ? kExactQuadsMax : q);
+}
 
 struct ExactScanArgs {
     const uint32_t *pair_off, *tile_off, *pair_q, *pair_vbase;
@@ -1129,6 +1135,7 @@ struct ExactScanArgs {
     uint32_t q_stride;
     uint64_t *cand;
     uint32_t cap;
+    uint32_t qpt;   // quads per tile (exact_quads_per_tile)
 };
 
 __global__ void stream_counts_kernel(uint32_t nq, uint32_t P, const uint32_t *__restrict__ vbase,
@@ -1140,8 +1147,8 @@ __global__ void stream_counts_kernel(uint32_t nq, uint32_t P, const uint32_t *__
 template <int MEASURE>
 __global__ __launch_bounds__(256) void leaf_exact_scan_kernel(TxhIndexDev ix, ExactScanArgs a) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    extern __shared__ __attribute__((aligned(16))) float qs[];   // [kExactQT][dimp]
-    __shared__ uint32_t s_pq[kExactQT], s_vb[kExactQT], tile_sh;
+    extern __shared__ __attribute__((aligned(16))) float qs_all[];   // [4 * a.qpt][dimp]: the tile's queries
+    __shared__ uint32_t s_pq_all[kExactQuadsMax * 4], s_vb_all[kExactQuadsMax * 4], tile_sh;
     const uint32_t tid = threadIdx.x;
     const uint32_t dim = ix.dim, dimp = (dim + 3u) & ~3u, chunks = dim >> 3;
     const uint32_t total_tiles = a.counters[CNT_TOTAL_TILES];
@@ -1165,58 +1172,86 @@ __global__ __launch_bounds__(256) void leaf_exact_scan_kernel(TxhIndexDev ix, Ex
         const uint32_t chunk = local % nchunks, qg = local / nchunks;
         const uint32_t slot0 = uniform_load(a.pair_off + leaf);
         const uint32_t slot_end = uniform_load(a.pair_off + leaf + 1);
-        const uint32_t s_begin = slot0 + qg * kExactQuads * 4u;
-        const uint32_t s_stop = min(s_begin + kExactQuads * 4u, slot_end);
+        const uint32_t s_begin = slot0 + qg * a.qpt * 4u;
+        const uint32_t s_stop = min(s_begin + a.qpt * 4u, slot_end);
         const uint32_t j = chunk * kExactRows + tid;
         const bool valid = j < size;
         const uint32_t csr = lb + (valid ? j : 0u);
         const float *row = ix.rows + (size_t)(ix.rows_csr ? csr : ix.leaf_ids[csr]) * ix.stride;
 
-        for (uint32_t sg = s_begin; sg < s_stop; sg += kExactQT) {
-            __syncthreads();
-            if (tid < kExactQT) {
-                const uint32_t sl = sg + tid;
-                s_pq[tid] = sl < s_stop ? a.pair_q[sl] : kInvalid;
-                s_vb[tid] = sl < s_stop ? a.pair_vbase[sl] : 0u;
-            }
-            for (uint32_t i = tid; i < kExactQT * dimp; i += 256) {
-                const uint32_t qi = i / dimp, jj = i - qi * dimp;
-                const uint32_t sl = sg + qi;
-                const uint32_t pq = sl < s_stop ? a.pair_q[sl] : kInvalid;
-                qs[i] = (pq != kInvalid && jj < dim) ? a.queries[(size_t)pq * a.q_stride + jj] : 0.0f;
-            }
-            __syncthreads();
+        // stage every query of the tile once (the passes below then run without a barrier)
+        const uint32_t nslots = s_stop - s_begin, nslots8 = (nslots + 7u) & ~7u;
+        if (tid < nslots8) {
+            const uint32_t sl = s_begin + tid;
+            s_pq_all[tid] = sl < s_stop ? a.pair_q[sl] : kInvalid;
+            s_vb_all[tid] = sl < s_stop ? a.pair_vbase[sl] : 0u;
+        }
+        for (uint32_t i = tid; i < nslots8 * dimp; i += 256) {
+            const uint32_t qi = i / dimp, jj = i - qi * dimp;
+            const uint32_t sl = s_begin + qi;
+            const uint32_t pq = sl < s_stop ? a.pair_q[sl] : kInvalid;
+            qs_all[i] = (pq != kInvalid && jj < dim) ? a.queries[(size_t)pq * a.q_stride + jj] : 0.0f;
+        }
+        __syncthreads();
+
+        for (uint32_t sg = 0; sg < nslots; sg += kExactQT) {
+            const float *qs = qs_all + sg * dimp;
+            const uint32_t *s_pq = s_pq_all + sg, *s_vb = s_vb_all + sg;
             f32x2 accv[kExactQT][4];
 #pragma unroll
             for (int qi = 0; qi < kExactQT; ++qi)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) accv[qi][u] = f32x2{0.0f, 0.0f};
-            for (uint32_t c = 0; c < chunks; ++c) {
-                f32x2 x[4];
-                if (vec) {
-                    const float4 xa = *reinterpret_cast<const float4 *>(row + 8 * c);
-                    const float4 xb = *reinterpret_cast<const float4 *>(row + 8 * c + 4);
-                    x[0] = f32x2{xa.x, xa.y}; x[1] = f32x2{xa.z, xa.w};
-                    x[2] = f32x2{xb.x, xb.y}; x[3] = f32x2{xb.z, xb.w};
-                } else {
+            // the row streams through registers four 8-dim chunks at a time, the next group in
+            // flight while this one computes (a chunk-at-a-time loop exposed one global-load latency
+            // per 8 dims)
+            constexpr int G = 4;
+            float4 xa[G], xb[G], na[G], nb[G];
+            auto load_group = [&](uint32_t c0, float4 *pa, float4 *pb) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) x[u] = f32x2{row[8 * c + 2 * u], row[8 * c + 2 * u + 1]};
-                }
-#pragma unroll
-                for (int qi = 0; qi < kExactQT; ++qi) {
-                    const float4 qa = *reinterpret_cast<const float4 *>(qs + qi * dimp + 8 * c);
-                    const float4 qb = *reinterpret_cast<const float4 *>(qs + qi * dimp + 8 * c + 4);
-                    const f32x2 qv[4] = {f32x2{qa.x, qa.y}, f32x2{qa.z, qa.w}, f32x2{qb.x, qb.y},
-                                         f32x2{qb.z, qb.w}};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (MEASURE == SCANN_HIP_DOT_PRODUCT) {
-                            accv[qi][u] = __builtin_elementwise_fma(qv[u], x[u], accv[qi][u]);
+                for (int g = 0; g < G; ++g) {
+                    const uint32_t c = c0 + g;
+                    if (c < chunks) {
+                        if (vec) {
+                            pa[g] = *reinterpret_cast<const float4 *>(row + 8 * c);
+                            pb[g] = *reinterpret_cast<const float4 *>(row + 8 * c + 4);
                         } else {
-                            const f32x2 d = qv[u] - x[u];
-                            accv[qi][u] = __builtin_elementwise_fma(d, d, accv[qi][u]);
+                            pa[g] = make_float4(row[8 * c], row[8 * c + 1], row[8 * c + 2], row[8 * c + 3]);
+                            pb[g] = make_float4(row[8 * c + 4], row[8 * c + 5], row[8 * c + 6], row[8 * c + 7]);
                         }
                     }
+                }
+            };
+            load_group(0, xa, xb);
+            for (uint32_t c0 = 0; c0 < chunks; c0 += G) {
+                if (c0 + G < chunks) load_group(c0 + G, na, nb);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const uint32_t c = c0 + g;
+                    if (c >= chunks) break;
+                    const f32x2 x[4] = {f32x2{xa[g].x, xa[g].y}, f32x2{xa[g].z, xa[g].w}, f32x2{xb[g].x, xb[g].y},
+                                        f32x2{xb[g].z, xb[g].w}};
+#pragma unroll
+                    for (int qi = 0; qi < kExactQT; ++qi) {
+                        const float4 qa = *reinterpret_cast<const float4 *>(qs + qi * dimp + 8 * c);
+                        const float4 qb = *reinterpret_cast<const float4 *>(qs + qi * dimp + 8 * c + 4);
+                        const f32x2 qv[4] = {f32x2{qa.x, qa.y}, f32x2{qa.z, qa.w}, f32x2{qb.x, qb.y},
+                                             f32x2{qb.z, qb.w}};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (MEASURE == SCANN_HIP_DOT_PRODUCT) {
+                                accv[qi][u] = __builtin_elementwise_fma(qv[u], x[u], accv[qi][u]);
+                            } else {
+                                const f32x2 d = qv[u] - x[u];
+                                accv[qi][u] = __builtin_elementwise_fma(d, d, accv[qi][u]);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    xa[g] = na[g];
+                    xb[g] = nb[g];
                 }
             }
 #pragma unroll
@@ -2047,7 +2082,8 @@ static int launch_exact_scan(const TxhIndexDev &ix, const TxhWork &w, hipStream_
     ExactScanArgs a;
     a.pair_off = w.pair_off; a.tile_off = w.tile_off; a.pair_q = w.pair_q; a.pair_vbase = w.pair_vbase;
     a.counters = w.counters; a.queries = w.queries; a.q_stride = w.q_stride; a.cand = w.cand; a.cap = w.cap;
-    const size_t lds = (size_t)kExactQT * ((ix.dim + 3u) & ~3u) * sizeof(float);
+    a.qpt = exact_quads_per_tile(ix.dim);
+    const size_t lds = (size_t)a.qpt * 4 * ((ix.dim + 3u) & ~3u) * sizeof(float);
     if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
     const dim3 grid((uint32_t)cus * 8u), block(256);
     switch (ix.measure) {
@@ -2088,7 +2124,7 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
     hipLaunchKernelGGL(worklist_scan_kernel, dim3(1), dim3(1024), 0, st, ix.L, w.leaf_cnt,
                        ix.leaf_off,
                        ix.exact_scan ? kExactRows : w.resident ? kResThreads * kScanPPT : scan_tile_points(ix),
-                       ix.exact_scan ? kExactQuads : w.resident ? kResQuads : w.qpt,
+                       ix.exact_scan ? exact_quads_per_tile(ix.dim) : w.resident ? kResQuads : w.qpt,
                        (w.resident && !ix.exact_scan) ? w.res_cl : 1u, scan_tile_points(ix), w.st,
                        w.sqpt, w.pair_off, w.tile_off,
                        w.stile_off, w.counters);
