@@ -161,6 +161,140 @@ __global__ __launch_bounds__(256) void bf_generic_kernel(BfIndexDev ix, BfPass p
 }
 
 // =====================================================================================
+// Streaming kernel for SMALL batches (a handful of queries: the single-query search of
+// BruteForceSearcher::search): the pass is one read of the database, so it must run at HBM
+// speed.  A row-per-lane global read (bf_generic_kernel) touches 64 cache lines per instruction;
+// here each WAVE stages 64 rows x 32 dims through its own LDS slice with fully coalesced 16-byte
+// loads (8 lanes per 128-byte row segment), the next slice's loads already in flight, and every
+// lane then reads ITS row back (pitch 36 floats: conflict-free ds_read_b128).  No workgroup
+// barrier in the loop: a wave's LDS operations execute in order.  Arithmetic as bf_generic_kernel.
+// =====================================================================================
+constexpr int kStQT = 8;              // queries per database pass
+constexpr uint32_t kStDims = 32;      // dims per staged slice
+constexpr uint32_t kStLd = kStDims + 4;
+
+template <int MEASURE>
+__global__ __launch_bounds__(256) void bf_stream_kernel(BfIndexDev ix, BfPass p) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) float qs[];   // [kStQT][dimp] | [4 waves][64][kStLd]
+    const uint32_t dim = ix.dim, dimp = (dim + 3u) & ~3u, chunks = dim >> 3, cdim = chunks * 8;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t q0 = blockIdx.y * kStQT;
+    for (uint32_t i = tid; i < kStQT * dimp; i += 256) {
+        const uint32_t qi = i / dimp, j = i - qi * dimp;
+        qs[i] = (q0 + qi < p.nq && j < dim) ? p.queries[(size_t)(q0 + qi) * p.q_stride + j] : 0.0f;
+    }
+    __syncthreads();
+    float *xw = qs + kStQT * dimp + wave * 64 * kStLd;
+    const uint32_t ngroups = (p.nrows + 63u) / 64u;
+    const uint32_t part = lane & 7u, rsub = lane >> 3;   // staging: 8 lanes per row segment, 8 rows per load
+    for (uint32_t g = blockIdx.x * 4u + wave; g < ngroups; g += gridDim.x * 4u) {
+        const uint32_t vrow0 = g * 64u;
+        // this lane's 8 staging pieces: row rsub + 8 i, 16 bytes at float offset part * 4 of the slice
+        const float *src[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            src[i] = ix.rows + (size_t)min(vrow0 + rsub + 8u * i, p.nrows - 1u) * p.row_mult * ix.stride;
+        float4 s0, s1, s2, s3, s4, s5, s6, s7;
+        // lanes past a short last slice re-read its last piece (never stored)
+#define SCANN_ST_FETCH(d0_)                                                                  \
+    do {                                                                                       \
+        const uint32_t o_ = (d0_) + min(part * 4u, min(kStDims, cdim - (d0_)) - 4u);           \
+        s0 = *reinterpret_cast<const float4 *>(src[0] + o_);                                   \
+        s1 = *reinterpret_cast<const float4 *>(src[1] + o_);                                   \
+        s2 = *reinterpret_cast<const float4 *>(src[2] + o_);                                   \
+        s3 = *reinterpret_cast<const float4 *>(src[3] + o_);                                   \
+        s4 = *reinterpret_cast<const float4 *>(src[4] + o_);                                   \
+        s5 = *reinterpret_cast<const float4 *>(src[5] + o_);                                   \
+        s6 = *reinterpret_cast<const float4 *>(src[6] + o_);                                   \
+        s7 = *reinterpret_cast<const float4 *>(src[7] + o_);                                   \
+    } while (0)
+#define SCANN_ST_COMMIT(d0_)                                                                 \
+    do {                                                                                       \
+        if (part * 4u < min(kStDims, cdim - (d0_))) {                                          \
+            float *dst_ = xw + rsub * kStLd + part * 4u;                                       \
+            *reinterpret_cast<float4 *>(dst_ + 0 * 8 * kStLd) = s0;                            \
+            *reinterpret_cast<float4 *>(dst_ + 1 * 8 * kStLd) = s1;                            \
+            *reinterpret_cast<float4 *>(dst_ + 2 * 8 * kStLd) = s2;                            \
+            *reinterpret_cast<float4 *>(dst_ + 3 * 8 * kStLd) = s3;                            \
+            *reinterpret_cast<float4 *>(dst_ + 4 * 8 * kStLd) = s4;                            \
+            *reinterpret_cast<float4 *>(dst_ + 5 * 8 * kStLd) = s5;                            \
+            *reinterpret_cast<float4 *>(dst_ + 6 * 8 * kStLd) = s6;                            \
+            *reinterpret_cast<float4 *>(dst_ + 7 * 8 * kStLd) = s7;                            \
+        }                                                                                      \
+    } while (0)
+        f32x2 accv[kStQT][4];
+#pragma unroll
+        for (int qi = 0; qi < kStQT; ++qi)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accv[qi][u] = f32x2{0.0f, 0.0f};
+        if (cdim) SCANN_ST_FETCH(0u);
+        for (uint32_t d0 = 0; d0 < cdim; d0 += kStDims) {
+            const uint32_t nd = min(kStDims, cdim - d0);
+            SCANN_ST_COMMIT(d0);
+            if (d0 + kStDims < cdim) SCANN_ST_FETCH(d0 + kStDims);   // in flight during the compute
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float *xr = xw + lane * kStLd;
+            for (uint32_t c = 0; c < nd; c += 8) {
+                const float4 xa = *reinterpret_cast<const float4 *>(xr + c);
+                const float4 xb = *reinterpret_cast<const float4 *>(xr + c + 4);
+                const f32x2 x[4] = {f32x2{xa.x, xa.y}, f32x2{xa.z, xa.w}, f32x2{xb.x, xb.y}, f32x2{xb.z, xb.w}};
+#pragma unroll
+                for (int qi = 0; qi < kStQT; ++qi) {
+                    const float4 qa = *reinterpret_cast<const float4 *>(qs + qi * dimp + d0 + c);
+                    const float4 qb = *reinterpret_cast<const float4 *>(qs + qi * dimp + d0 + c + 4);
+                    const f32x2 qv[4] = {f32x2{qa.x, qa.y}, f32x2{qa.z, qa.w}, f32x2{qb.x, qb.y},
+                                         f32x2{qb.z, qb.w}};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (MEASURE == SCANN_HIP_DOT_PRODUCT) {
+                            accv[qi][u] = __builtin_elementwise_fma(qv[u], x[u], accv[qi][u]);
+                        } else {
+                            const f32x2 d = qv[u] - x[u];
+                            accv[qi][u] = __builtin_elementwise_fma(d, d, accv[qi][u]);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                     // reads done before the next commit
+        }
+        const uint32_t vrow = vrow0 + lane;
+        if (vrow < p.nrows) {
+            const float *row = ix.rows + (size_t)vrow * p.row_mult * ix.stride;
+#pragma unroll
+            for (int qi = 0; qi < kStQT; ++qi) {
+                if (q0 + qi >= p.nq) continue;
+                const f32x2 s01 = accv[qi][0] + accv[qi][2], s23 = accv[qi][1] + accv[qi][3];
+                float r = (s01.x + s01.y) + (s23.x + s23.y);   // hsum tree, x86.rs:31-44
+                for (uint32_t j = cdim; j < dim; ++j) {         // scalar tail, not fused
+                    const float qv = qs[qi * dimp + j];
+                    if (MEASURE == SCANN_HIP_DOT_PRODUCT) {
+                        r = r + qv * row[j];
+                    } else {
+                        const float d = qv - row[j];
+                        r = r + d * d;
+                    }
+                }
+                float dist = r;
+                if (MEASURE == SCANN_HIP_DOT_PRODUCT) dist = -r;
+                if (MEASURE == SCANN_HIP_L2) dist = sqrtf(r);
+                uint64_t T = 0;
+                float Tf = 0.0f;
+                if (p.filter) {
+                    T = p.thr[q0 + qi];
+                    Tf = bf_thr_float(T);
+                }
+                bf_emit(p, q0 + qi, vrow, dist, Tf, T);
+            }
+        }
+    }
+#undef SCANN_ST_FETCH
+#undef SCANN_ST_COMMIT
+}
+
+// =====================================================================================
 // SquaredL2 / L2 kernel with one QUERY per lane (dim = 8 * DC <= 128).  (q - x)^2 cannot go
 // through MFMA bit-exactly, so this is the VALU roofline: a lane keeps its whole query in
 // registers (DC * 4 packed pairs), a block of 4 waves (256 queries) shares 32-row tiles of
@@ -1018,10 +1152,21 @@ static bool vq_eligible(const BfIndexDev &ix, const BfPass &p) {
     return p.nq >= 128;
 }
 
+// streaming kernel: a few queries (one database pass per 8), 16-byte-loadable rows
+static bool stream_eligible(const BfIndexDev &ix, const BfPass &p) {
+    if ((ix.stride & 3u) || (reinterpret_cast<uintptr_t>(ix.rows) & 15u) || ix.dim < 8) return false;
+    static const uint32_t max_q = [] {
+        const char *e = std::getenv("SCANN_HIP_BF_STREAM_MAX_QUERIES");
+        return e ? (uint32_t)std::max(0, std::atoi(e)) : 16u;
+    }();
+    return p.nq <= max_q;
+}
+
 // name of the kernel launch_pass picks for a batch of nq queries (timing reports)
 const char *bf_pass_kernel_name(const BfIndexDev &ix, uint32_t nq) {
     BfPass p{};
     p.nq = nq;
+    if (stream_eligible(ix, p)) return "bf_stream_kernel";
     if (mfma_eligible(ix)) return "bf_mfma_dot_kernel";
     if (vq_eligible(ix, p)) return "bf_vq_kernel";
     return "bf_generic_kernel";
@@ -1029,6 +1174,30 @@ const char *bf_pass_kernel_name(const BfIndexDev &ix, uint32_t nq) {
 
 static int launch_pass(const BfIndexDev &ix, const BfPass &p, hipStream_t st) {
     if (p.nq == 0 || p.nrows == 0) return SCANN_HIP_OK;
+    if (stream_eligible(ix, p)) {
+        const uint32_t dimp = (ix.dim + 3u) & ~3u;
+        const size_t lds = ((size_t)kStQT * dimp + 4u * 64u * kStLd) * sizeof(float);
+        const uint32_t ny = ceil_div_u32(p.nq, kStQT);
+        const uint32_t ngroups = ceil_div_u32(p.nrows, 64);
+        const uint32_t nx = std::max(1u, std::min(ceil_div_u32(ngroups, 4), 4u * (uint32_t)num_cus()));
+        dim3 grid(nx, ny);
+        switch (ix.measure) {
+            case SCANN_HIP_SQUARED_L2:
+                SCANN_TRY(set_dyn_lds(bf_stream_kernel<SCANN_HIP_SQUARED_L2>, lds));
+                hipLaunchKernelGGL(bf_stream_kernel<SCANN_HIP_SQUARED_L2>, grid, dim3(256), lds, st, ix, p);
+                break;
+            case SCANN_HIP_L2:
+                SCANN_TRY(set_dyn_lds(bf_stream_kernel<SCANN_HIP_L2>, lds));
+                hipLaunchKernelGGL(bf_stream_kernel<SCANN_HIP_L2>, grid, dim3(256), lds, st, ix, p);
+                break;
+            default:
+                SCANN_TRY(set_dyn_lds(bf_stream_kernel<SCANN_HIP_DOT_PRODUCT>, lds));
+                hipLaunchKernelGGL(bf_stream_kernel<SCANN_HIP_DOT_PRODUCT>, grid, dim3(256), lds, st, ix, p);
+                break;
+        }
+        LAUNCH_CHECK();
+        return SCANN_HIP_OK;
+    }
     if (mfma_eligible(ix)) {
         switch (ix.dim / 16) {
             case 2: return launch_mfma<2>(ix, p, st);

@@ -883,3 +883,27 @@ def test_scann_partitioned_mode_errors():
     with pytest.raises(hip.ScannError) as e:
         index.search_batched(np.zeros((1, 8), np.float32), 5)
     assert e.value.code == hip.INVALID_ARGUMENT
+
+
+# ---- small-batch brute force: bf_stream_kernel (a few queries, one coalesced database pass) -------
+@pytest.mark.parametrize("measure", [hip.SQUARED_L2, hip.L2, hip.DOT_PRODUCT])
+@pytest.mark.parametrize("n,dim", [(3000, 128), (70, 64), (5000, 100), (1000, 33), (4097, 8), (2500, 24),
+                                   (900, 200)])
+def test_bf_small_batch_stream_kernel(measure, n, dim):
+    """1..16 queries take the streaming kernel: all-pairs distances bitwise (ragged dims: slices of
+    8/16/24 dims and scalar tails; row counts that are not multiples of 64) and exact top-k."""
+    rows = synth.uniform_f32(n, dim, 42)
+    data, stride = orc.to_strided(rows)
+    index = hip.bf_create(data, n, dim, stride, measure)
+    for nq in (1, 5, 8, 9, 16):
+        q = synth.uniform_f32(nq, dim, 100 + nq)
+        got = hip.bf_distances(index, q)
+        for i in range(nq):
+            assert np.array_equal(bits(got[i]), bits(orc.one_to_many(q[i], data, stride, n, measure))), (nq, i)
+        k = min(10, n)
+        idx, dist, cnt = index.search_batched(q, k)
+        oi, od, oc = orc.bf_search_batched(data, n, dim, stride, measure, q, k)
+        assert np.array_equal(cnt, oc)
+        for i in range(nq):
+            H.assert_topk_equal_up_to_ties(idx[i, :cnt[i]], dist[i, :cnt[i]], oi[i, :cnt[i]], od[i, :cnt[i]],
+                                           what="stream nq=%d q%d" % (nq, i))
