@@ -10,13 +10,20 @@ search_with_reordering (exact f32 re-rank of the pre_reorder_k best approximate
 candidates).  A "step" is one search_batched call over one batch of `--batch` queries
 already resident in HBM; value = queries/s of the whole job.
 
-One process per GPU.  N > 1 (launched by torch.distributed.run): the database is sharded
-across ranks (row ranges = leaves of a flat partition), every rank scans its shard for
-all queries, ONE RCCL all_to_all per step sends each peer the (merge key, index, exact distance)
-triples of the queries that peer merges (xGMI is point-to-point: 1/world of the all_gather volume
-per link), each rank merges its batch/world queries and the k result rows are all_gathered
-(strong scaling: total work fixed).  Steps are software-pipelined: a step's exchange overlaps
-the next step's local stage.
+One process per GPU.  N > 1 (launched by torch.distributed.run), two layouts:
+
+  --multi-gpu replica (default): the index of this configuration (1M x 128: 0.53 GB) fits one GPU
+    many times over, so the data-parallel unit is the QUERY -- the reference's own parallelism
+    (search_batched = one rayon task per query, tree_x_hybrid/mod.rs:404-408).  Every rank holds
+    the full index and searches its own batch of `--batch` queries per step; no data-path
+    collective.  Weak scaling: per-GPU work fixed, value = N * batch * steps / max-over-ranks time.
+  --multi-gpu shard: for indexes that do not fit (BASELINE configs[4]).  The database is sharded
+    across ranks (leaves; row ranges = leaves of a flat partition for the hasher), every rank scans
+    its shard for all queries, ONE RCCL all_to_all per step sends each peer the (merge key, index,
+    exact distance) triples of the queries that peer merges (xGMI is point-to-point: 1/world of
+    the all_gather volume per link), each rank merges its batch/world queries and the k result
+    rows are all_gathered (strong scaling: total work fixed).  Steps are software-pipelined: a
+    step's exchange overlaps the next step's local stage.
 
 The CPU oracle is used here ONLY as (a) the checker of a few result rows and (b) the
 cpu_baseline leg; the timed path is libscann_hip.so through its C ABI.
@@ -66,6 +73,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-recall", action="store_true")
     # rehearsal knobs (not used by the driver): gloo collectives / all ranks on one device
+    p.add_argument("--multi-gpu", default="replica", choices=["replica", "shard"],
+                   help="N > 1: query-parallel replicas of the index (default) or a leaf-sharded index "
+                        "with one RCCL all_to_all per step")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     p.add_argument("--single-device", action="store_true")
     p.add_argument("--bf-exact", action="store_true",
@@ -192,7 +202,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    nproc = world                       # processes (= GPUs) of the job
+    replica = nproc > 1 and args.multi_gpu == "replica"
+    if replica:
+        world = 1                       # shards of the index: every rank holds all of it
+    srank = 0 if replica else rank      # this rank's shard
+    if nproc > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)   # RCCL over xGMI
@@ -233,11 +248,11 @@ def main():
 
     # ---------------- data (synthetic, reference-harness shape: U[0,1), seeds 42/123) ----
     t0 = time.time()
-    lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+    lo, hi = (n * srank) // world, (n * (srank + 1)) // world
     n_loc = hi - lo
     txh_state = None
     if args.workload == "txh":
-        txh_state = build_txh(args, torch, dist, hip, synth, trainer, device, local_rank, rank, world,
+        txh_state = build_txh(args, torch, dist, hip, synth, trainer, device, local_rank, srank, world,
                               stride)
         rows = None
         queries_all = txh_state["queries"]
@@ -251,6 +266,8 @@ def main():
         rows, _ = synth.clustered_f32(n, dim, 7, n_clusters=1000)
         qsrc, _ = synth.clustered_f32(max(Q * 4, args.eval_queries), dim, 8, n_clusters=1000)
         queries_all = qsrc
+    if replica and rank:                # every replica searches its own queries
+        queries_all = np.roll(queries_all, -rank * Q, axis=0)
     if rows is not None:
         data = np.zeros((n_loc, stride), np.float32)
         data[:, :dim] = rows
@@ -305,7 +322,7 @@ def main():
                 sizes = np.array([(n * (g + 1)) // world - (n * g) // world for g in range(world)],
                                  np.uint32)
                 off = np.zeros(world + 1, np.uint32)
-                off[rank + 1:] = n_loc
+                off[srank + 1:] = n_loc
                 index = hip.txh_create(
                     data=data, n_rows=n_loc, dim=dim, stride=stride,
                     centers=np.zeros((world, dim), np.float32), leaf_offsets=off,
@@ -437,7 +454,7 @@ def main():
         if device_status_aborted():
             continue
         index.enable_timing(True)
-        if world > 1:
+        if nproc > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -445,7 +462,7 @@ def main():
             step(i)
         flush_steps()
         torch.cuda.synchronize()
-        if world > 1:
+        if nproc > 1:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -453,6 +470,10 @@ def main():
         index.enable_timing(False)
         if device_status_aborted():
             continue
+        if replica:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0].item())
         if world > 1:
             t = torch.tensor([elapsed, float(mstatus.item())], dtype=torch.float64,
                              device=device if args.backend == "nccl" else "cpu")
@@ -465,7 +486,7 @@ def main():
             if t[1].item() != 0:
                 raise SystemExit("merge reported status %d" % int(t[1].item()))
         break
-    qps = Q * args.steps / elapsed
+    qps = Q * args.steps * (nproc if replica else 1) / elapsed
     if world > 1:   # result rows of the last step, gathered from the ranks that merged them
         ra = res_alls[last_res[0]].cpu().numpy()
         rb_ = (Q // world) * k * 4
@@ -523,7 +544,7 @@ def main():
 
     # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N = 1) -------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and nproc == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle as orc
         threads = orc.max_threads()
         nq0 = min(threads, queries_all.shape[0])
@@ -588,11 +609,12 @@ def main():
                 pass
         line = {
             "metric": "QPS @ recall10@10 + achieved HBM GB/s, 1M x 128 f32",
-            "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "value": qps, "unit": "queries/s", "n_gpus": nproc, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong",
+            "higher_is_better": True, "scaling": "weak" if (replica or nproc == 1) else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name, "n": n, "dim": dim, "k": k, "batch": Q,
+                       "global_batch": Q * (nproc if replica else 1),
                        "pre_reorder_k": m if args.workload != "bf_dot" else None,
                        "pre_reorder_k_per_rank": m_local if world > 1 else None,
                        "distribution": args.dist if args.workload != "txh" else "clustered (1000 Gaussians)",
@@ -601,11 +623,14 @@ def main():
                        "recall10@10": recall,
                        "oracle_check": checked,
                        "parallelism": "1 process/GPU, leaf(row-range)-sharded x%d + RCCL all_to_all of candidates"
-                                      % world if world > 1 else "single GPU"},
+                                      % world if world > 1 else
+                                      ("1 process/GPU, %d query-parallel replicas of the index (no data-path "
+                                       "collective); --multi-gpu shard = leaf-sharded index + RCCL all_to_all"
+                                       % nproc) if replica else "single GPU"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if nproc > 1:
         dist.destroy_process_group()
 
 
