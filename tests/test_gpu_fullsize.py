@@ -147,3 +147,41 @@ def test_txh_1m_gpu_build_and_oracle():
                           ci[i, :cc[i]], cd[i, :cc[i]], what="q%d" % i)
     a, b, _ = index.search_batched(q[:7], k, o)      # batch-split invariance
     assert np.array_equal(b.view(np.uint32), dist[:7].view(np.uint32))
+
+
+@pytest.mark.parametrize("measure", [hip.SQUARED_L2, hip.DOT_PRODUCT])
+def test_scann_partitioned_1m_all_leaves_equals_brute_force(big, measure):
+    """SearchMode::Partitioned at full size: with every leaf searched the scanned stream is the whole
+    database, so the rows must equal brute force over the same data -- the same distances bit for bit
+    (same single-pair arithmetic), the same indices up to distance ties; a subset of the leaves can
+    only be worse.  Also checks the loader on a 0.5 GB index file."""
+    L = 64
+    bf = hip.bf_create(big["data"], N, DIM, big["stride"], measure)
+    sq = bf if measure == hip.SQUARED_L2 else hip.bf_create(big["data"], N, DIM, big["stride"], hip.SQUARED_L2)
+    centers, assign = hip.kmeans_lloyd(sq, hip.kmeans_init_pp(sq, L, seed=42), max_iterations=3)[:2]
+    order = np.argsort(assign, kind="stable").astype(np.uint32)
+    off = np.zeros(L + 1, np.uint32)
+    off[1:] = np.cumsum(np.bincount(assign, minlength=L))
+    kw = dict(data=big["data"], n_rows=N, dim=DIM, stride=big["stride"], centers=centers, leaf_offsets=off,
+              leaf_ids=order, codebook=None, codes=None, partitions_to_search=L, distance_measure=measure)
+    index = hip.txh_create(**kw)
+    q = big["q"][:6]
+    idx, dist, cnt = index.search_batched(q, K)
+    bi, bd, bc = bf.search_batched(q, K)
+    assert np.all(cnt == K) and np.all(bc == K)
+    assert np.array_equal(dist.view(np.uint32), bd.view(np.uint32))
+    for i in range(q.shape[0]):
+        H.assert_topk_equal_up_to_ties(idx[i], dist[i], bi[i], bd[i], what="partitioned(all leaves) q%d" % i)
+    o = hip.default_opts()
+    o.partitions_to_search = 8
+    idx8, dist8, cnt8 = index.search_batched(q, K, o)
+    assert np.all(dist8 >= dist) and np.all(np.diff(dist8, axis=1) >= 0)
+    if measure == hip.SQUARED_L2:     # index file round trip at full size
+        import os
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            p = os.path.join(d, "part.scannidx")
+            hip.txh_write_file(p, **kw)
+            loaded = hip.load_file(p)
+            li, ld, lc = loaded.search_batched(q, K)
+            assert np.array_equal(li, idx) and np.array_equal(ld.view(np.uint32), dist.view(np.uint32))
