@@ -22,7 +22,9 @@
  *    out_count (the reference returns shorter Vecs: brute_force/searcher.rs:91,
  *    tree_x_hybrid/mod.rs:360-363).  Unused slots: idx 0xFFFFFFFF, dist +inf.
  *  - any thread may call search functions concurrently on one handle (Searcher:
- *    Send + Sync, searcher.rs:148); create/destroy need external synchronisation.
+ *    Send + Sync, searcher.rs:148): host-side searches draw a stream + workspace from a small
+ *    per-handle pool (SCANN_HIP_SEARCH_SLOTS, default 4) and run side by side; the *_device
+ *    entry points share the primary slot.  create/destroy need external synchronisation.
  */
 #ifndef SCANN_HIP_H
 #define SCANN_HIP_H

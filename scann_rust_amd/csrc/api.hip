@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -40,10 +41,21 @@ struct TxhWorkspace {
         sbase, pair_sbase, stile_off, samp;
 };
 
+// An extra stream + workspaces: host-side searches of concurrent caller threads (Searcher: Send +
+// Sync, tests/stress_tests.rs:256-297) run side by side instead of queueing on one mutex.
+struct SearchSlot {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    TxhWorkspace ws;
+    BfWorkspace bfw;
+};
+
 struct scann_hip_index {
     scann_hip_ctx *ctx = nullptr;
     int kind = 0;
-    std::mutex mu;  // serialises searches on one handle (callers may be concurrent)
+    std::mutex mu;  // the primary slot (stream, ws, bfw below): device entry points and timing use it
+    std::mutex slots_mu;
+    std::vector<std::unique_ptr<SearchSlot>> slots;   // created on demand, at most max_slots() - 1
     hipStream_t stream = nullptr;
     // ring of HIP event pairs bracketing the dominant kernel of each search launch
     static constexpr int kEvRing = 64;
@@ -143,6 +155,11 @@ void scann_hip_index_destroy(scann_hip_index *ix) {
         if (ix->evs[i][1]) (void)hipEventDestroy(ix->evs[i][1]);
     }
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    for (auto &sl : ix->slots)
+        if (sl->stream) {
+            (void)hipStreamSynchronize(sl->stream);
+            (void)hipStreamDestroy(sl->stream);
+        }
     delete ix;
 }
 
@@ -449,10 +466,9 @@ static int resolve_params(const scann_hip_index *ix, uint32_t k, const scann_hip
     return SCANN_HIP_OK;
 }
 
-static int ensure_txh_workspace(scann_hip_index *ix, uint32_t nq, const TxhCallParams &p,
+static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t nq, const TxhCallParams &p,
                                 bool own_queries, uint32_t q_stride, bool own_outputs,
                                 TxhWork *w) {
-    TxhWorkspace &s = ix->ws;
     const TxhIndexDev &t = ix->tx;
     const uint32_t L = t.L, P = p.P, m = std::max(1u, p.m), k = std::max(1u, p.k);
     const uint32_t max_slots = nq * P + 3 * L + 4;
@@ -588,10 +604,71 @@ static void fill_empty(uint32_t nq, uint32_t k, uint32_t *out_idx, float *out_di
         if (out_count) out_count[i] = 0;
 }
 
+// A search slot for a host-side call: the primary one if it is free, else a free extra slot (created
+// up to SCANN_HIP_SEARCH_SLOTS, default 4, streams + workspaces in total), else wait for the primary.
+struct SlotLock {
+    std::unique_lock<std::mutex> lock;
+    hipStream_t stream = nullptr;
+    TxhWorkspace *ws = nullptr;
+    BfWorkspace *bfw = nullptr;
+    bool primary = false;
+};
+
+static uint32_t max_slots() {
+    static const uint32_t v = [] {
+        const char *e = std::getenv("SCANN_HIP_SEARCH_SLOTS");
+        return (uint32_t)std::max(1, std::min(64, e ? std::atoi(e) : 4));
+    }();
+    return v;
+}
+
+static int acquire_slot(scann_hip_index *ix, SlotLock *out) {
+    std::unique_lock<std::mutex> lk(ix->mu, std::try_to_lock);
+    if (!lk.owns_lock()) {
+        SearchSlot *slot = nullptr;
+        {
+            std::lock_guard<std::mutex> g(ix->slots_mu);
+            for (auto &sl : ix->slots) {
+                std::unique_lock<std::mutex> l2(sl->mu, std::try_to_lock);
+                if (l2.owns_lock()) {
+                    slot = sl.get();
+                    out->lock = std::move(l2);
+                    break;
+                }
+            }
+            if (!slot && ix->slots.size() + 1 < max_slots()) {
+                std::unique_ptr<SearchSlot> ns(new SearchSlot());
+                SCANN_TRY(set_device(ix->ctx));
+                SCANN_HIP_CHECK(hipStreamCreateWithFlags(&ns->stream, hipStreamNonBlocking));
+                out->lock = std::unique_lock<std::mutex>(ns->mu);
+                slot = ns.get();
+                ix->slots.push_back(std::move(ns));
+            }
+        }
+        if (slot) {
+            out->stream = slot->stream;
+            out->ws = &slot->ws;
+            out->bfw = &slot->bfw;
+            out->primary = false;
+            return SCANN_HIP_OK;
+        }
+        lk.lock();   // every slot busy: queue on the primary
+    }
+    out->lock = std::move(lk);
+    out->stream = ix->stream;
+    out->ws = &ix->ws;
+    out->bfw = &ix->bfw;
+    out->primary = true;
+    return SCANN_HIP_OK;
+}
+
 static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t nq,
                            uint32_t q_stride, uint32_t k, const scann_hip_search_opts *opts,
                            uint32_t *out_idx, float *out_dist, uint32_t *out_count) {
-    std::lock_guard<std::mutex> lock(ix->mu);
+    SlotLock sl;
+    SCANN_TRY(acquire_slot(ix, &sl));
+    TxhWorkspace &ws = *sl.ws;
+    const hipStream_t stream = sl.stream;
     SCANN_TRY(set_device(ix->ctx));
     for (int attempt = 0; attempt < 2; ++attempt) {
         TxhCallParams p;
@@ -602,50 +679,50 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
             return SCANN_HIP_OK;
         }
         TxhWork w;
-        SCANN_TRY(ensure_txh_workspace(ix, nq, p, true, q_stride, true, &w));
+        SCANN_TRY(ensure_txh_workspace(ix, ws, nq, p, true, q_stride, true, &w));
         w.need_sorted_cands = (opts && (opts->cand_idx || opts->cand_dist)) ? 1 : 0;
         if (opts && opts->allow_bitmap) {   // search_with_filter(Some(allow-list))
             const size_t words = (size_t)((opts->allow_bitmap_bits + 63) / 64);
-            SCANN_TRY(ix->ws.allow.ensure(words * 8));
-            SCANN_HIP_CHECK(hipMemcpyAsync(ix->ws.allow.p, opts->allow_bitmap, words * 8,
-                                           hipMemcpyHostToDevice, ix->stream));
-            w.allow = ix->ws.allow.as<uint64_t>();
+            SCANN_TRY(ws.allow.ensure(words * 8));
+            SCANN_HIP_CHECK(hipMemcpyAsync(ws.allow.p, opts->allow_bitmap, words * 8,
+                                           hipMemcpyHostToDevice, stream));
+            w.allow = ws.allow.as<uint64_t>();
             w.allow_bits = opts->allow_bitmap_bits;
         }
-        SCANN_HIP_CHECK(hipMemcpyAsync(ix->ws.queries.p, queries, (size_t)nq * q_stride * 4,
-                                       hipMemcpyHostToDevice, ix->stream));
-        ix->next_events();
-        SCANN_TRY(txh_launch_search(ix->tx, w, false, ix->stream, ix->ev0,
-                                    ix->ev1));
-        ix->timing_valid = ix->timing;
-        ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
+        SCANN_HIP_CHECK(hipMemcpyAsync(ws.queries.p, queries, (size_t)nq * q_stride * 4,
+                                       hipMemcpyHostToDevice, stream));
+        if (sl.primary) ix->next_events();   // kernel timing follows the primary slot only
+        SCANN_TRY(txh_launch_search(ix->tx, w, false, stream, sl.primary ? ix->ev0 : nullptr,
+                                    sl.primary ? ix->ev1 : nullptr));
+        if (sl.primary) ix->timing_valid = ix->timing;
+        if (sl.primary) ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
         uint32_t counters[CNT_N];
         SCANN_HIP_CHECK(hipMemcpyAsync(counters, w.counters, sizeof(counters), hipMemcpyDeviceToHost,
-                                       ix->stream));
+                                       stream));
         SCANN_HIP_CHECK(hipMemcpyAsync(out_idx, w.out_idx, (size_t)nq * k * 4, hipMemcpyDeviceToHost,
-                                       ix->stream));
+                                       stream));
         SCANN_HIP_CHECK(hipMemcpyAsync(out_dist, w.out_dist, (size_t)nq * k * 4,
-                                       hipMemcpyDeviceToHost, ix->stream));
+                                       hipMemcpyDeviceToHost, stream));
         SCANN_HIP_CHECK(hipMemcpyAsync(out_count, w.out_count, (size_t)nq * 4, hipMemcpyDeviceToHost,
-                                       ix->stream));
+                                       stream));
         if (opts) {
             if (opts->tokens)
                 SCANN_HIP_CHECK(hipMemcpyAsync(opts->tokens, w.tokens, (size_t)nq * p.P * 4,
-                                               hipMemcpyDeviceToHost, ix->stream));
+                                               hipMemcpyDeviceToHost, stream));
             if (opts->token_dists)
                 SCANN_HIP_CHECK(hipMemcpyAsync(opts->token_dists, w.token_dists, (size_t)nq * p.P * 4,
-                                               hipMemcpyDeviceToHost, ix->stream));
+                                               hipMemcpyDeviceToHost, stream));
             if (opts->cand_idx)
                 SCANN_HIP_CHECK(hipMemcpyAsync(opts->cand_idx, w.cand_idx, (size_t)nq * p.m * 4,
-                                               hipMemcpyDeviceToHost, ix->stream));
+                                               hipMemcpyDeviceToHost, stream));
             if (opts->cand_dist)
                 SCANN_HIP_CHECK(hipMemcpyAsync(opts->cand_dist, w.cand_dist, (size_t)nq * p.m * 4,
-                                               hipMemcpyDeviceToHost, ix->stream));
+                                               hipMemcpyDeviceToHost, stream));
             if (opts->cand_count)
                 SCANN_HIP_CHECK(hipMemcpyAsync(opts->cand_count, w.cand_count, (size_t)nq * 4,
-                                               hipMemcpyDeviceToHost, ix->stream));
+                                               hipMemcpyDeviceToHost, stream));
         }
-        SCANN_HIP_CHECK(hipStreamSynchronize(ix->stream));
+        SCANN_HIP_CHECK(hipStreamSynchronize(stream));
         if (counters[CNT_STATUS] == SCANN_HIP_OK) return SCANN_HIP_OK;
         if ((counters[CNT_STATUS] != SCANN_HIP_RESOURCE_EXHAUSTED &&
              counters[CNT_STATUS] != SCANN_HIP_ABORTED) || attempt == 1)
@@ -678,14 +755,18 @@ int scann_hip_search_batched(scann_hip_index *ix, const float *queries, uint32_t
             fill_empty(nq, 0, nullptr, nullptr, out_count);
             return SCANN_HIP_OK;
         }
-        std::lock_guard<std::mutex> lock(ix->mu);
+        SlotLock sl;
+        SCANN_TRY(acquire_slot(ix, &sl));
         SCANN_TRY(set_device(ix->ctx));
-        ix->next_events();
-        int s = bf_search_host(ix->bf, ix->bfw, queries, nq, q_stride, k, opts && opts->bf_exact, out_idx,
-                               out_dist, out_count, ix->stream, ix->ev0, ix->ev1);
-        ix->timing_valid = ix->timing && s == SCANN_HIP_OK;
-        ix->timed_kernel = (!(opts && opts->bf_exact) && bf_shortlist_eligible(ix->bf, nq, k))
-                               ? "bf_bf16_kernel" : bf_pass_kernel_name(ix->bf, nq);
+        if (sl.primary) ix->next_events();
+        int s = bf_search_host(ix->bf, *sl.bfw, queries, nq, q_stride, k, opts && opts->bf_exact, out_idx,
+                               out_dist, out_count, sl.stream, sl.primary ? ix->ev0 : nullptr,
+                               sl.primary ? ix->ev1 : nullptr);
+        if (sl.primary) {
+            ix->timing_valid = ix->timing && s == SCANN_HIP_OK;
+            ix->timed_kernel = (!(opts && opts->bf_exact) && bf_shortlist_eligible(ix->bf, nq, k))
+                                   ? "bf_bf16_kernel" : bf_pass_kernel_name(ix->bf, nq);
+        }
         return s;
     }
     if (q_dim != ix->tx.dim)  // tree_x_hybrid/mod.rs:251-253, hashes/hasher.rs:167-171
@@ -707,7 +788,7 @@ int scann_hip_index_reserve(scann_hip_index *ix, uint32_t max_nq, uint32_t max_k
     TxhCallParams p;
     SCANN_TRY(resolve_params(ix, max_k, opts, false, &p));
     TxhWork w;
-    return ensure_txh_workspace(ix, max_nq, p, false, 0, false, &w);
+    return ensure_txh_workspace(ix, ix->ws, max_nq, p, false, 0, false, &w);
 }
 
 int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries, uint32_t nq,
@@ -734,7 +815,7 @@ int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries,
     SCANN_TRY(resolve_params(ix, k, opts, false, &p));
     if (p.m == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "pre-reorder candidate count is 0");
     TxhWork w;
-    SCANN_TRY(ensure_txh_workspace(ix, nq, p, false, q_stride, false, &w));
+    SCANN_TRY(ensure_txh_workspace(ix, ix->ws, nq, p, false, q_stride, false, &w));
     w.queries = d_queries;
     w.out_idx = d_out_idx;
     w.out_dist = d_out_dist;
@@ -785,7 +866,7 @@ int scann_hip_txh_search_local_device(scann_hip_index *ix, const float *d_querie
     if (!p.exact_reorder) return fail(SCANN_HIP_INVALID_ARGUMENT, "local stage needs exact_reorder");
     if (p.m == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "pre-reorder candidate count is 0");
     TxhWork w;
-    SCANN_TRY(ensure_txh_workspace(ix, nq, p, false, q_stride, false, &w));
+    SCANN_TRY(ensure_txh_workspace(ix, ix->ws, nq, p, false, q_stride, false, &w));
     w.queries = d_queries;
     w.cand_key = d_keys;
     w.cand_idx = d_idx;
@@ -864,7 +945,7 @@ int scann_hip_txh_partition(scann_hip_index *ix, const float *queries, uint32_t 
     TxhCallParams p;
     SCANN_TRY(resolve_params(ix, 1, &o, false, &p));
     TxhWork w;
-    SCANN_TRY(ensure_txh_workspace(ix, nq, p, true, q_stride, true, &w));
+    SCANN_TRY(ensure_txh_workspace(ix, ix->ws, nq, p, true, q_stride, true, &w));
     SCANN_HIP_CHECK(hipMemcpyAsync(ix->ws.queries.p, queries, (size_t)nq * q_stride * 4,
                                    hipMemcpyHostToDevice, ix->stream));
     SCANN_TRY(txh_launch_partition_only(ix->tx, w, ix->stream));

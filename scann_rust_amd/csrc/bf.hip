@@ -1103,10 +1103,14 @@ __global__ __launch_bounds__(kBfSelectThreads) void bf_select_kernel(
 
 template <typename F>
 static int set_dyn_lds(F kernel, size_t bytes) {
+    // Always the same value (the CU's 160 KB), never the launch's own size: threads searching
+    // different indexes set this attribute concurrently, and a smaller value written by one of
+    // them must not undercut another's launch.
+    constexpr size_t kMaxLds = 160 * 1024;
+    if (bytes > kMaxLds) return fail(SCANN_HIP_RESOURCE_EXHAUSTED, "kernel needs more than 160 KB of LDS");
     if (bytes > 64 * 1024)
         SCANN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)bytes));
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
     return SCANN_HIP_OK;
 }
 

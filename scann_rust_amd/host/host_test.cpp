@@ -4,6 +4,9 @@
 //   hashes/hasher.rs:322-380
 //   tree_x_hybrid/mod.rs:436-468
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <string>
@@ -210,12 +213,57 @@ static void scann_facade_tests() {   // scann.rs:450-496 + the four search modes
     EXPECT(threw);
 }
 
+// tests/stress_tests.rs:256-297 (stress_test_concurrent_queries) and :300-323 (high-dimensional)
+static void stress_tests() {
+    std::vector<std::vector<float>> v(5000, std::vector<float>(32));
+    uint64_t st = 42;
+    for (auto &r : v)
+        for (auto &x : r) x = (float)(detail::splitmix(st) >> 40) * (1.0f / 16777216.0f);
+    const Scann scann = Scann::brute_force(DenseDataset::from_vecs(v));
+    auto run = [&](int threads) {
+        std::vector<std::thread> pool;
+        std::atomic<int> bad{0};
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int t = 0; t < threads; ++t)
+            pool.emplace_back([&, t]() {
+                uint64_t s2 = 100 + (uint64_t)t;
+                std::vector<float> q(32);
+                for (int i = 0; i < 50; ++i) {
+                    for (auto &x : q) x = (float)(detail::splitmix(s2) >> 40) * (1.0f / 16777216.0f);
+                    auto r = scann.search(q, 10);
+                    if (r.size() != 10) ++bad;
+                    for (size_t j = 1; j < r.size(); ++j)
+                        if (r[j].second < r[j - 1].second) ++bad;
+                }
+            });
+        for (auto &th : pool) th.join();
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        EXPECT(bad.load() == 0);
+        return threads * 50 / sec;
+    };
+    run(1);   // warm-up (workspaces of the first slot)
+    const double q1 = run(1), q4 = run(4);
+    run(4);
+    std::printf("concurrent queries: 1 thread %.0f QPS, 4 threads %.0f QPS\n", q1, q4);
+
+    std::vector<std::vector<float>> hd(1000, std::vector<float>(512));
+    for (auto &r : hd)
+        for (auto &x : r) x = (float)(detail::splitmix(st) >> 40) * (1.0f / 16777216.0f);
+    BruteForceSearcher hs(DenseDataset::from_vecs(hd), DistanceMeasure::SquaredL2);
+    for (int i = 0; i < 20; ++i) {
+        auto r = hs.search(hd[(size_t)i * 7], 10);
+        EXPECT(r.size() == 10 && r[0].first == (uint32_t)(i * 7) && r[0].second == 0.0f);
+        sorted(r);
+    }
+}
+
 int main() {
     try {
         brute_force_tests();
         hasher_tests();
         tree_x_hybrid_tests();
         scann_facade_tests();
+        stress_tests();
     } catch (const ScannError &e) {
         std::printf("ScannError %d: %s\n", (int)e.code, e.what());
         return 2;

@@ -327,6 +327,41 @@ def test_concurrent_queries():
     assert not errs, errs
 
 
+@pytest.mark.parametrize("kind", ["txh", "bf_dot", "bf_l2", "partitioned"])
+def test_concurrent_queries_use_separate_slots(kind):
+    """8 caller threads on one handle: concurrent host-side searches run on separate search slots
+    (stream + workspace each) and must return exactly what the same calls return one at a time,
+    for single queries and for batches of different sizes."""
+    rows, data, stride, ix, oix, kw = H.make_txh_case(5000, 64, 12, 8, seed=14, P=3, kmeans_iters=2,
+                                                      pq_iters=2)
+    if kind == "txh":
+        index = hip.txh_create(**kw)
+    elif kind == "partitioned":
+        index = hip.txh_create(**dict(kw, codebook=None, codes=None))
+    else:
+        index = hip.bf_create(data, 5000, 64, stride, hip.DOT_PRODUCT if kind == "bf_dot" else hip.L2)
+    q = synth.uniform_f32(240, 64, 77)
+    jobs = [(i, i + 1) for i in range(0, 96)] + [(96 + 9 * j, 96 + 9 * j + 9) for j in range(16)]
+    want = [index.search_batched(q[a:b], 10) for a, b in jobs]
+    errs = []
+
+    def worker(t):
+        try:
+            for rep in range(3):
+                for j in range(t, len(jobs), 8):
+                    a, b = jobs[j]
+                    idx, dist, cnt = index.search_batched(q[a:b], 10)
+                    assert np.array_equal(cnt, want[j][2]) and np.array_equal(idx, want[j][0])
+                    assert np.array_equal(bits(dist), bits(want[j][1]))
+        except Exception as ex:  # noqa
+            errs.append(ex)
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[:2]
+
+
 # ---- multi-GPU stages on one GPU: two leaf shards -> local stage x2 -> merge ------------------------------
 @pytest.mark.parametrize("world,k,m", [(2, 10, 60), (3, 10, 60), (2, 100, 400)])
 def test_sharded_local_plus_merge_equals_single_index(world, k, m):
@@ -888,7 +923,7 @@ def test_scann_partitioned_mode_errors():
 # ---- small-batch brute force: bf_stream_kernel (a few queries, one coalesced database pass) -------
 @pytest.mark.parametrize("measure", [hip.SQUARED_L2, hip.L2, hip.DOT_PRODUCT])
 @pytest.mark.parametrize("n,dim", [(3000, 128), (70, 64), (5000, 100), (1000, 33), (4097, 8), (2500, 24),
-                                   (900, 200)])
+                                   (900, 200), (1000, 512)])   # 1000 x 512: stress_tests.rs:300-323
 def test_bf_small_batch_stream_kernel(measure, n, dim):
     """1..16 queries take the streaming kernel: all-pairs distances bitwise (ragged dims: slices of
     8/16/24 dims and scalar tails; row counts that are not multiples of 64) and exact top-k."""
