@@ -707,6 +707,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kB16Waves = 4;      // waves per block: 8 x 32 = 256 queries share a stage
 constexpr int kB16Sub = 1;        // 32-row sub-tiles per stage (one barrier per 64 rows)
 
+constexpr uint32_t kB16Stage = 64;   // survivors staged per wave and iteration (one per lane at the flush)
+
+// s_waitcnt vmcnt(2 * pairs): all but the wave's `pairs` youngest (hi, lo) DMA instruction pairs have
+// completed.  pairs is wave-uniform; the immediate must be a constant.
+__device__ __forceinline__ void wait_all_but_pairs(uint32_t pairs) {
+    switch (pairs) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+}
+
 template <int TS, int MEASURE>
 __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev ix, BfPass p,
                                                                     const uint16_t *__restrict__ qb,
@@ -719,16 +733,27 @@ __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev i
     constexpr int RT = 32 * kB16Sub;                                   // rows per stage
     constexpr int TILE_B = RT * DIM * 2;                               // bytes of one (hi or lo) stage
     constexpr int NI = TILE_B / 1024;                                  // 1 KiB wave-instructions per stage
-    constexpr int NBUF = 2;
+    constexpr int NBUF = 3;                                            // stages in flight: this + the next two
     constexpr int STAGE_B = 2 * TILE_B + 256;                          // hi | lo | RT norms (<= 64)
     constexpr int MYI = (NI + kB16Waves - 1) / kB16Waves;              // DMA instruction pairs per wave
     static_assert(RT <= 64, "one 4-byte DMA instruction carries the stage's norms");
-    extern __shared__ __attribute__((aligned(16))) unsigned char xsb[];   // [NBUF][STAGE_B]
+    static_assert(MYI <= 4, "wait_all_but_pairs covers up to 4 pairs");
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsb[];   // [NBUF][STAGE_B] | survivor stages
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t h = lane >> 5, li = lane & 31u;
     const uint32_t bid = blockIdx.x, xcd = bid & 7u, slot = bid >> 3;
     const uint32_t x = xcd + 8u * (slot / ny), y = slot % ny;
     const uint32_t ntiles = (p.nrows + RT - 1u) / RT;
+    // Survivors of the filter are staged per wave in LDS and appended to the global candidate lists
+    // one iteration later: the returning atomic that reserves a list slot is issued BEFORE the next
+    // stage's MFMAs and its result is consumed after them.  (Emitting in place put one atomic round
+    // trip, ~1-2 us, into nearly every iteration: about one survivor per 32 x 32 wave tile.)
+    uint64_t *wkey = reinterpret_cast<uint64_t *>(xsb + (size_t)NBUF * STAGE_B) + wave * kB16Stage;
+    uint32_t *wq = reinterpret_cast<uint32_t *>(xsb + (size_t)NBUF * STAGE_B + (size_t)kB16Waves * kB16Stage * 8) +
+                   wave * kB16Stage;
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(xsb + (size_t)NBUF * STAGE_B + (size_t)kB16Waves * kB16Stage * 12) +
+                     wave;
+    if (lane == 0) *wcnt = 0;
     const uint32_t q = y * (kB16Waves * 32u) + wave * 32u + li;
     const uint32_t qc = min(q, p.nq - 1u);
     bf16x8 qf[TS], ql[TS];
@@ -755,6 +780,10 @@ __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev i
         lane_row[i] = r;
         lane_col[i] = 8u * (pos ^ (r & SW));
     }
+    uint32_t my_pairs = 0;                                             // DMA pairs this wave issues per stage
+#pragma unroll
+    for (int i = 0; i < MYI; ++i) my_pairs += (wave + (uint32_t)kB16Waves * i < (uint32_t)NI) ? 1u : 0u;
+    my_pairs = __builtin_amdgcn_readfirstlane(my_pairs);
     const size_t row_pitch = (size_t)p.row_mult * DIM;                 // elements between virtual rows
     auto dma_tile = [&](uint32_t tile, uint32_t buf) {
         unsigned char *stage = xsb + (size_t)buf * STAGE_B;
@@ -793,15 +822,34 @@ __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev i
     if (tile >= ntiles) return;   // uniform per block
     dma_tile(tile, 0);
     stage_norms(tile, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tile + nx < ntiles) {     // second stage in flight; only the first must have landed
+        dma_tile(tile + nx, 1);
+        stage_norms(tile + nx, 1);
+        if (MEASURE == SCANN_HIP_DOT_PRODUCT) wait_all_but_pairs(my_pairs);
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
     const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
                          0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const uint32_t sw = li & SW;
     for (uint32_t it = 0; tile < ntiles; tile += nx, ++it) {
-        const uint32_t buf = it % NBUF;
-        const bool more = tile + nx < ntiles;
-        if (more) dma_tile(tile + nx, buf ^ 1u);          // in flight during this stage's MFMAs
+        const uint32_t buf = it % NBUF, buf2 = (it + 2u) % NBUF;
+        const bool more = tile + 2u * nx < ntiles;        // a stage two tiles ahead to fetch
+        // previous iteration's survivors: one lane each reserves a slot now, stores after the MFMAs
+        const uint32_t nst = min(*wcnt, kB16Stage);
+        uint64_t fkey = 0;
+        uint32_t fq = 0, fpos = 0;
+        if (lane < nst) {
+            fkey = wkey[lane];
+            fq = wq[lane];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) *wcnt = 0;
+        if (lane < nst) fpos = atomicAdd(&p.cand_cnt[fq], 1u);
+        if (more) dma_tile(tile + 2u * nx, buf2);         // lands during this and the next stage's MFMAs
         const unsigned char *stage = xsb + (size_t)buf * STAGE_B;
 #pragma unroll
         for (int sub = 0; sub < kB16Sub; ++sub) {
@@ -837,7 +885,19 @@ __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev i
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const uint32_t vrow = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (qvalid && vrow < p.nrows) bf_emit(p, q, vrow, sc[r], Tf, T);
+                        if (qvalid && vrow < p.nrows && sc[r] <= Tf) {
+                            const uint64_t key = make_key(sc[r], vrow * p.row_mult);
+                            if (key <= T) {
+                                const uint32_t sl = atomicAdd(wcnt, 1u);   // LDS
+                                if (sl < kB16Stage) {
+                                    wkey[sl] = key;
+                                    wq[sl] = q;
+                                } else {                                   // stage full: direct append
+                                    const uint32_t pos = atomicAdd(&p.cand_cnt[q], 1u);
+                                    if (pos < p.cap) p.cand[(size_t)q * p.cap + pos] = key;
+                                }
+                            }
+                        }
                     }
                 }
             } else {
@@ -848,9 +908,24 @@ __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev i
                 }
             }
         }
-        if (more) stage_norms(tile + nx, buf ^ 1u);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage's DMA has landed
+        if (lane < nst && fpos < p.cap) p.cand[(size_t)fq * p.cap + fpos] = fkey;
+        if (more) stage_norms(tile + 2u * nx, buf2);
+        // The NEXT stage must have landed; the one just issued may stay in flight.  vmcnt counts in
+        // issue order, and at least this wave's DMA instructions of this iteration are younger than
+        // the next stage's (the survivor atomic / store, when issued, only make the wait stricter).
+        if (more && MEASURE == SCANN_HIP_DOT_PRODUCT) wait_all_but_pairs(my_pairs);
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    }
+    // the last iteration's survivors
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nst = min(*wcnt, kB16Stage);
+    if (lane < nst) {
+        const uint64_t fkey = wkey[lane];
+        const uint32_t fq = wq[lane];
+        const uint32_t fpos = atomicAdd(&p.cand_cnt[fq], 1u);
+        if (fpos < p.cap) p.cand[(size_t)fq * p.cap + fpos] = fkey;
     }
 }
 
@@ -913,7 +988,7 @@ __global__ __launch_bounds__(256) void bf_rerank_kernel(BfIndexDev ix, const flo
 template <int MEASURE>
 __global__ __launch_bounds__(64) void bf_shortlist_final_kernel(
     uint32_t n, uint32_t k, uint32_t kp, float max_norm, float dot_err, const float *__restrict__ qn2,
-    const uint32_t *__restrict__ sl_idx, const float *__restrict__ sl_approx,
+    const uint64_t *__restrict__ thr, const uint32_t *__restrict__ sl_idx, const float *__restrict__ sl_approx,
     const uint32_t *__restrict__ sl_cnt, const float *__restrict__ sl_exact,
     uint32_t *__restrict__ counters, uint32_t *__restrict__ fail_flag, uint32_t *__restrict__ out_idx,
     float *__restrict__ out_dist, uint32_t *__restrict__ out_count) {
@@ -941,9 +1016,11 @@ __global__ __launch_bounds__(64) void bf_shortlist_final_kernel(
     if (tid == 0) {
         out_count[q] = nout;
         bool ok = nsel >= n;                         // everything was re-scored
-        if (!ok && nout == k && nsel == kp) {
-            // every row outside the shortlist scores >= the shortlist's largest bf16 score
-            const float floor_b = sl_approx[(size_t)q * kp + kp - 1];
+        if (!ok && nout == k) {
+            // every row outside the shortlist scores >= the shortlist's largest bf16 score; a
+            // shortlist shorter than kp holds EVERY row that passed the filter, so the rest score
+            // >= the filter's bound
+            const float floor_b = nsel == kp ? sl_approx[(size_t)q * kp + kp - 1] : bf_thr_float(thr[q]);
             const float dk = ordered_to_f32((uint32_t)(skeys[k - 1] >> 32));   // k-th exact (squared for L2)
             const float qn = sqrtf(qn2[q]);
             float E;
@@ -1404,7 +1481,8 @@ static int launch_bf16(const BfIndexDev &ix, const BfPass &p, const uint16_t *qb
     uint32_t want = std::max<uint32_t>(1, (2u * (uint32_t)num_cus()) / ny);
     want = std::min(want, ntiles);
     const uint32_t nx = 8u * ceil_div_u32(want, 8);
-    const size_t lds = (size_t)2 * (2 * 32 * kB16Sub * (TS * 16) * 2 + 256);   // two (hi | lo | norms) stages
+    const size_t lds = (size_t)3 * (2 * 32 * kB16Sub * (TS * 16) * 2 + 256) +   // three (hi | lo | norms) stages
+                       (size_t)kB16Waves * kB16Stage * 12 + kB16Waves * 4;     // + per-wave survivor stages
     if (ix.measure == SCANN_HIP_DOT_PRODUCT) {
         SCANN_TRY(set_dyn_lds((bf_bf16_kernel<TS, SCANN_HIP_DOT_PRODUCT>), lds));
         hipLaunchKernelGGL((bf_bf16_kernel<TS, SCANN_HIP_DOT_PRODUCT>), dim3(nx * ny), dim3(kB16Waves * 64), lds, st,
@@ -1469,8 +1547,28 @@ static int enqueue_shortlist_search(const BfIndexDev &ix, BfWorkspace &w, uint32
     const SelCfg tcfg = sel_cfg(ns);
     const size_t lds_thr = (size_t)next_pow2_u32(ns) * 8 + (size_t)tcfg.bins * 4 + (size_t)tcfg.list * 8 + 48 * 8;
     SCANN_TRY(set_dyn_lds(bf_threshold_kernel, lds_thr));
+    // Sample rank of the filter bound.  The kp-th smallest sample score is a certain bound of the
+    // kp-th smallest score overall but lets ~kp * rs rows through; the j-th smallest with
+    // P(Poisson(kp / rs) >= j) <= 1e-6 -- the chance that j of the overall best kp fell into the
+    // 1-in-rs sample -- lets ~j * rs through.  Should it cut deeper, the shortlist is merely shorter
+    // than kp and the final kernel proves the result against the bound itself (or flags the query).
+    uint32_t jthr = kp;
+    {
+        static const double tail = [] {
+            const char *e = std::getenv("SCANN_HIP_BF_SHORTLIST_TAIL");
+            const double v = e ? std::atof(e) : 1e-6;
+            return v > 0.0 && v < 1.0 ? v : 1e-6;
+        }();
+        const double lam = (double)kp / (double)rs;
+        double term = std::exp(-lam), cdf = term;   // P(X <= 0)
+        for (uint32_t j = 1; j < kp; ++j) {         // smallest j with P(X >= j) = 1 - P(X <= j-1) <= 1e-6
+            if (1.0 - cdf <= tail) { jthr = j; break; }
+            term *= lam / (double)j;
+            cdf += term;
+        }
+    }
     hipLaunchKernelGGL(bf_threshold_kernel, dim3(nq), dim3(kBfSelectThreads), lds_thr, st, w.sample.as<float>(),
-                       ns, rs, kp, 0, w.thr.as<uint64_t>(), (uint32_t *)nullptr, (float *)nullptr,
+                       ns, rs, jthr, 0, w.thr.as<uint64_t>(), (uint32_t *)nullptr, (float *)nullptr,
                        (uint32_t *)nullptr);
     LAUNCH_CHECK();
     // 2. bf16 scores of every row, filtered by that bound
@@ -1504,7 +1602,7 @@ static int enqueue_shortlist_search(const BfIndexDev &ix, BfWorkspace &w, uint32
                            q_stride, kp, w.sl_idx.as<uint32_t>(), w.sl_cnt.as<uint32_t>(), w.sl_exact.as<float>());
         LAUNCH_CHECK();
         hipLaunchKernelGGL(bf_shortlist_final_kernel<SCANN_HIP_DOT_PRODUCT>, dim3(nq), dim3(64), 0, st, n, k, kp,
-                           ix.max_norm, shortlist_dot_err(ix.dim), w.q_n2.as<float>(), w.sl_idx.as<uint32_t>(), w.sl_approx.as<float>(),
+                           ix.max_norm, shortlist_dot_err(ix.dim), w.q_n2.as<float>(), w.thr.as<uint64_t>(), w.sl_idx.as<uint32_t>(), w.sl_approx.as<float>(),
                            w.sl_cnt.as<uint32_t>(), w.sl_exact.as<float>(), w.counters.as<uint32_t>(),
                            w.sl_fail.as<uint32_t>(), d_out_idx, d_out_dist, d_out_count);
     } else {
@@ -1513,12 +1611,12 @@ static int enqueue_shortlist_search(const BfIndexDev &ix, BfWorkspace &w, uint32
         LAUNCH_CHECK();
         if (ix.measure == SCANN_HIP_L2)
             hipLaunchKernelGGL(bf_shortlist_final_kernel<SCANN_HIP_L2>, dim3(nq), dim3(64), 0, st, n, k, kp,
-                               ix.max_norm, shortlist_dot_err(ix.dim), w.q_n2.as<float>(), w.sl_idx.as<uint32_t>(), w.sl_approx.as<float>(),
+                               ix.max_norm, shortlist_dot_err(ix.dim), w.q_n2.as<float>(), w.thr.as<uint64_t>(), w.sl_idx.as<uint32_t>(), w.sl_approx.as<float>(),
                                w.sl_cnt.as<uint32_t>(), w.sl_exact.as<float>(), w.counters.as<uint32_t>(),
                                w.sl_fail.as<uint32_t>(), d_out_idx, d_out_dist, d_out_count);
         else
             hipLaunchKernelGGL(bf_shortlist_final_kernel<SCANN_HIP_SQUARED_L2>, dim3(nq), dim3(64), 0, st, n, k, kp,
-                               ix.max_norm, shortlist_dot_err(ix.dim), w.q_n2.as<float>(), w.sl_idx.as<uint32_t>(), w.sl_approx.as<float>(),
+                               ix.max_norm, shortlist_dot_err(ix.dim), w.q_n2.as<float>(), w.thr.as<uint64_t>(), w.sl_idx.as<uint32_t>(), w.sl_approx.as<float>(),
                                w.sl_cnt.as<uint32_t>(), w.sl_exact.as<float>(), w.counters.as<uint32_t>(),
                                w.sl_fail.as<uint32_t>(), d_out_idx, d_out_dist, d_out_count);
     }
