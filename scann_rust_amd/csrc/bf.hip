@@ -707,7 +707,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kB16Waves = 4;      // waves per block: 8 x 32 = 256 queries share a stage
 constexpr int kB16Sub = 1;        // 32-row sub-tiles per stage (one barrier per 64 rows)
 
-constexpr uint32_t kB16Stage = 64;   // survivors staged per wave and iteration (one per lane at the flush)
 
 // s_waitcnt vmcnt(2 * pairs): all but the wave's `pairs` youngest (hi, lo) DMA instruction pairs have
 // completed.  pairs is wave-uniform; the immediate must be a constant.
@@ -744,16 +743,12 @@ __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev i
     const uint32_t bid = blockIdx.x, xcd = bid & 7u, slot = bid >> 3;
     const uint32_t x = xcd + 8u * (slot / ny), y = slot % ny;
     const uint32_t ntiles = (p.nrows + RT - 1u) / RT;
-    // Survivors of the filter are staged per wave in LDS and appended to the global candidate lists
-    // one iteration later: the returning atomic that reserves a list slot is issued BEFORE the next
-    // stage's MFMAs and its result is consumed after them.  (Emitting in place put one atomic round
-    // trip, ~1-2 us, into nearly every iteration: about one survivor per 32 x 32 wave tile.)
-    uint64_t *wkey = reinterpret_cast<uint64_t *>(xsb + (size_t)NBUF * STAGE_B) + wave * kB16Stage;
-    uint32_t *wq = reinterpret_cast<uint32_t *>(xsb + (size_t)NBUF * STAGE_B + (size_t)kB16Waves * kB16Stage * 8) +
-                   wave * kB16Stage;
-    uint32_t *wcnt = reinterpret_cast<uint32_t *>(xsb + (size_t)NBUF * STAGE_B + (size_t)kB16Waves * kB16Stage * 12) +
-                     wave;
-    if (lane == 0) *wcnt = 0;
+    // A survivor of the filter is held in a register of its lane and appended to the global
+    // candidate list two iterations later: the returning atomic that reserves the list slot is
+    // issued at the top of the next iteration, BEFORE that iteration's DMA, and its result is
+    // consumed one iteration after that.  Emitting in place put an atomic round trip (~1-2 us)
+    // into nearly every iteration; staging through LDS made the compiler wait for ALL outstanding
+    // LDS-DMA before each staging write (it cannot prove that the DMA's LDS writes do not alias).
     const uint32_t q = y * (kB16Waves * 32u) + wave * 32u + li;
     const uint32_t qc = min(q, p.nq - 1u);
     bf16x8 qf[TS], ql[TS];
@@ -834,21 +829,20 @@ __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev i
     const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
                          0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const uint32_t sw = li & SW;
+    bool phas = false, fhas = false;       // this lane's survivor found / slot reservation in flight
+    uint64_t pkey = 0, fkey = 0;
+    uint32_t fpos = 0;
     for (uint32_t it = 0; tile < ntiles; tile += nx, ++it) {
         const uint32_t buf = it % NBUF, buf2 = (it + 2u) % NBUF;
         const bool more = tile + 2u * nx < ntiles;        // a stage two tiles ahead to fetch
-        // previous iteration's survivors: one lane each reserves a slot now, stores after the MFMAs
-        const uint32_t nst = min(*wcnt, kB16Stage);
-        uint64_t fkey = 0;
-        uint32_t fq = 0, fpos = 0;
-        if (lane < nst) {
-            fkey = wkey[lane];
-            fq = wq[lane];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) *wcnt = 0;
-        if (lane < nst) fpos = atomicAdd(&p.cand_cnt[fq], 1u);
+        // Survivors travel two iterations behind: the one found in iteration i-1 gets its list slot
+        // reserved now, the one reserved in iteration i-1 is stored now -- both before this
+        // iteration's DMA, so the counted wait at the end never waits for the DMA itself.
+        if (fhas && fpos < p.cap) p.cand[(size_t)q * p.cap + fpos] = fkey;
+        fhas = phas;
+        fkey = pkey;
+        phas = false;
+        if (fhas) fpos = atomicAdd(&p.cand_cnt[q], 1u);
         if (more) dma_tile(tile + 2u * nx, buf2);         // lands during this and the next stage's MFMAs
         const unsigned char *stage = xsb + (size_t)buf * STAGE_B;
 #pragma unroll
@@ -858,14 +852,22 @@ __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev i
             const float *nrm = reinterpret_cast<const float *>(stage + 2 * TILE_B) + 32 * sub;
             f32x16 acc = zero;
             const unsigned char *xrow = stage + (size_t)(32 * sub + li) * DIM * 2;
+            // every A fragment of the stage is requested before the first MFMA (the compiler's own
+            // schedule kept two fragment registers and waited for LDS once per k-step: the MFMA
+            // pipe idled through eight LDS round trips per stage)
+            bf16x8 a[TS], al[TS];
 #pragma unroll
             for (int t = 0; t < TS; ++t) {
                 const uint32_t c0 = 2u * t + h;
-                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(xrow + 16u * (c0 ^ sw));
-                const bf16x8 al = *reinterpret_cast<const bf16x8 *>(xrow + TILE_B + 16u * (c0 ^ sw));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[t], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qf[t], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ql[t], acc, 0, 0, 0);
+                a[t] = *reinterpret_cast<const bf16x8 *>(xrow + 16u * (c0 ^ sw));
+                al[t] = *reinterpret_cast<const bf16x8 *>(xrow + TILE_B + 16u * (c0 ^ sw));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TS; ++t) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], qf[t], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], qf[t], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], ql[t], acc, 0, 0, 0);
             }
             float sc[16];
 #pragma unroll
@@ -888,11 +890,10 @@ __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev i
                         if (qvalid && vrow < p.nrows && sc[r] <= Tf) {
                             const uint64_t key = make_key(sc[r], vrow * p.row_mult);
                             if (key <= T) {
-                                const uint32_t sl = atomicAdd(wcnt, 1u);   // LDS
-                                if (sl < kB16Stage) {
-                                    wkey[sl] = key;
-                                    wq[sl] = q;
-                                } else {                                   // stage full: direct append
+                                if (!phas) {
+                                    pkey = key;
+                                    phas = true;
+                                } else {                                   // a second survivor of this lane
                                     const uint32_t pos = atomicAdd(&p.cand_cnt[q], 1u);
                                     if (pos < p.cap) p.cand[(size_t)q * p.cap + pos] = key;
                                 }
@@ -908,7 +909,6 @@ __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev i
                 }
             }
         }
-        if (lane < nst && fpos < p.cap) p.cand[(size_t)fq * p.cap + fpos] = fkey;
         if (more) stage_norms(tile + 2u * nx, buf2);
         // The NEXT stage must have landed; the one just issued may stay in flight.  vmcnt counts in
         // issue order, and at least this wave's DMA instructions of this iteration are younger than
@@ -917,15 +917,11 @@ __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev i
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    // the last iteration's survivors
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t nst = min(*wcnt, kB16Stage);
-    if (lane < nst) {
-        const uint64_t fkey = wkey[lane];
-        const uint32_t fq = wq[lane];
-        const uint32_t fpos = atomicAdd(&p.cand_cnt[fq], 1u);
-        if (fpos < p.cap) p.cand[(size_t)fq * p.cap + fpos] = fkey;
+    // drain: the slot reserved in the last iteration, then the survivor found in it
+    if (fhas && fpos < p.cap) p.cand[(size_t)q * p.cap + fpos] = fkey;
+    if (phas) {
+        const uint32_t pos = atomicAdd(&p.cand_cnt[q], 1u);
+        if (pos < p.cap) p.cand[(size_t)q * p.cap + pos] = pkey;
     }
 }
 
@@ -1478,11 +1474,11 @@ static int launch_bf16(const BfIndexDev &ix, const BfPass &p, const uint16_t *qb
                        const float *qn2, hipStream_t st) {
     const uint32_t ny = ceil_div_u32(p.nq, kB16Waves * 32);
     const uint32_t ntiles = ceil_div_u32(p.nrows, 32 * kB16Sub);
-    uint32_t want = std::max<uint32_t>(1, (2u * (uint32_t)num_cus()) / ny);
+    uint32_t want = std::max<uint32_t>(1, ((8u / kB16Waves) * (uint32_t)num_cus()) / ny);   // 8 waves per CU
     want = std::min(want, ntiles);
     const uint32_t nx = 8u * ceil_div_u32(want, 8);
     const size_t lds = (size_t)3 * (2 * 32 * kB16Sub * (TS * 16) * 2 + 256) +   // three (hi | lo | norms) stages
-                       (size_t)kB16Waves * kB16Stage * 12 + kB16Waves * 4;     // + per-wave survivor stages
+                       16;
     if (ix.measure == SCANN_HIP_DOT_PRODUCT) {
         SCANN_TRY(set_dyn_lds((bf_bf16_kernel<TS, SCANN_HIP_DOT_PRODUCT>), lds));
         hipLaunchKernelGGL((bf_bf16_kernel<TS, SCANN_HIP_DOT_PRODUCT>), dim3(nx * ny), dim3(kB16Waves * 64), lds, st,
