@@ -1153,6 +1153,7 @@ __global__ __launch_bounds__(256) void leaf_exact_scan_kernel(TxhIndexDev ix, Ex
     const uint32_t dim = ix.dim, dimp = (dim + 3u) & ~3u, chunks = dim >> 3;
     const uint32_t total_tiles = a.counters[CNT_TOTAL_TILES];
     const bool vec = ((ix.stride & 3u) == 0) && ((reinterpret_cast<uintptr_t>(ix.rows) & 15u) == 0);
+    const bool qvec = ((a.q_stride & 3u) == 0) && ((reinterpret_cast<uintptr_t>(a.queries) & 15u) == 0);
     for (;;) {
         __syncthreads();   // the previous tile's LDS reads are done
         if (tid == 0) tile_sh = grab_tile(a.counters + CNT_XQ, total_tiles);
@@ -1186,11 +1187,40 @@ __global__ __launch_bounds__(256) void leaf_exact_scan_kernel(TxhIndexDev ix, Ex
             s_pq_all[tid] = sl < s_stop ? a.pair_q[sl] : kInvalid;
             s_vb_all[tid] = sl < s_stop ? a.pair_vbase[sl] : 0u;
         }
-        for (uint32_t i = tid; i < nslots8 * dimp; i += 256) {
-            const uint32_t qi = i / dimp, jj = i - qi * dimp;
-            const uint32_t sl = s_begin + qi;
-            const uint32_t pq = sl < s_stop ? a.pair_q[sl] : kInvalid;
-            qs_all[i] = (pq != kInvalid && jj < dim) ? a.queries[(size_t)pq * a.q_stride + jj] : 0.0f;
+        __syncthreads();   // s_pq_all visible
+        if (qvec) {
+            // 16-byte copies, four independent loads in flight per thread (an element-at-a-time loop
+            // serialised two dependent global loads per element: ~50 us per tile)
+            const uint32_t dim4 = dimp >> 2, total4 = nslots8 * dim4;
+            for (uint32_t i0 = 0; i0 < total4; i0 += 1024u) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t i = i0 + 256u * u + tid;
+                    v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (i < total4) {
+                        const uint32_t qi = i / dim4, j4 = (i - qi * dim4) * 4u;
+                        const uint32_t pq = s_pq_all[qi];
+                        if (pq != kInvalid) {
+                            v[u] = *reinterpret_cast<const float4 *>(a.queries + (size_t)pq * a.q_stride + j4);
+                            if (j4 + 1 >= dim) v[u].y = 0.0f;   // padding of the last piece
+                            if (j4 + 2 >= dim) v[u].z = 0.0f;
+                            if (j4 + 3 >= dim) v[u].w = 0.0f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t i = i0 + 256u * u + tid;
+                    if (i < total4) reinterpret_cast<float4 *>(qs_all)[i] = v[u];
+                }
+            }
+        } else {
+            for (uint32_t i = tid; i < nslots8 * dimp; i += 256) {
+                const uint32_t qi = i / dimp, jj = i - qi * dimp;
+                const uint32_t pq = s_pq_all[qi];
+                qs_all[i] = (pq != kInvalid && jj < dim) ? a.queries[(size_t)pq * a.q_stride + jj] : 0.0f;
+            }
         }
         __syncthreads();
 
