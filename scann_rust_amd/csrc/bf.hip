@@ -705,6 +705,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 //   A[i = lane & 31][k = 8h + j] = X[row i][16t + 8h + j], B[k][n = lane & 31] = Q[n][16t + 8h + j].
 // Score = -dot (DotProduct) or |q|^2 + |x|^2 - 2 dot (SquaredL2 / L2: squared domain).
 constexpr int kB16Waves = 4;      // waves per block: 8 x 32 = 256 queries share a stage
+#ifndef SCANN_B16_OCC
+#define SCANN_B16_OCC 3
+#endif
+#ifndef SCANN_B16_RING
+#define SCANN_B16_RING 2
+#endif
+constexpr int kB16Occ = SCANN_B16_OCC;     // workgroups per CU = waves per SIMD (TS <= 8)
+constexpr int kB16Ring = SCANN_B16_RING;   // LDS stages per workgroup
 constexpr int kB16Sub = 1;        // 32-row sub-tiles per stage (one barrier per 64 rows)
 
 
@@ -721,7 +729,7 @@ __device__ __forceinline__ void wait_all_but_pairs(uint32_t pairs) {
 }
 
 template <int TS, int MEASURE>
-__global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev ix, BfPass p,
+__global__ __launch_bounds__(kB16Waves * 64, (TS <= 8 ? kB16Occ : 2)) void bf_bf16_kernel(BfIndexDev ix, BfPass p,
                                                                     const uint16_t *__restrict__ qb,
                                                                     const uint16_t *__restrict__ qbl,
                                                                     const float *__restrict__ qn2, uint32_t nx,
@@ -732,7 +740,8 @@ __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev i
     constexpr int RT = 32 * kB16Sub;                                   // rows per stage
     constexpr int TILE_B = RT * DIM * 2;                               // bytes of one (hi or lo) stage
     constexpr int NI = TILE_B / 1024;                                  // 1 KiB wave-instructions per stage
-    constexpr int NBUF = 3;                                            // stages in flight: this + the next two
+    constexpr int NBUF = kB16Ring;                                     // stages: this one + DIST in flight
+    constexpr uint32_t DIST = NBUF - 1;
     constexpr int STAGE_B = 2 * TILE_B + 256;                          // hi | lo | RT norms (<= 64)
     constexpr int MYI = (NI + kB16Waves - 1) / kB16Waves;              // DMA instruction pairs per wave
     static_assert(RT <= 64, "one 4-byte DMA instruction carries the stage's norms");
@@ -817,7 +826,7 @@ __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev i
     if (tile >= ntiles) return;   // uniform per block
     dma_tile(tile, 0);
     stage_norms(tile, 0);
-    if (tile + nx < ntiles) {     // second stage in flight; only the first must have landed
+    if (DIST == 2 && tile + nx < ntiles) {   // second stage in flight; only the first must have landed
         dma_tile(tile + nx, 1);
         stage_norms(tile + nx, 1);
         if (MEASURE == SCANN_HIP_DOT_PRODUCT) wait_all_but_pairs(my_pairs);
@@ -833,8 +842,8 @@ __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev i
     uint64_t pkey = 0, fkey = 0;
     uint32_t fpos = 0;
     for (uint32_t it = 0; tile < ntiles; tile += nx, ++it) {
-        const uint32_t buf = it % NBUF, buf2 = (it + 2u) % NBUF;
-        const bool more = tile + 2u * nx < ntiles;        // a stage two tiles ahead to fetch
+        const uint32_t buf = it % NBUF, buf2 = (it + DIST) % NBUF;
+        const bool more = tile + DIST * nx < ntiles;      // a stage DIST tiles ahead to fetch
         // Survivors travel two iterations behind: the one found in iteration i-1 gets its list slot
         // reserved now, the one reserved in iteration i-1 is stored now -- both before this
         // iteration's DMA, so the counted wait at the end never waits for the DMA itself.
@@ -843,7 +852,7 @@ __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev i
         fkey = pkey;
         phas = false;
         if (fhas) fpos = atomicAdd(&p.cand_cnt[q], 1u);
-        if (more) dma_tile(tile + 2u * nx, buf2);         // lands during this and the next stage's MFMAs
+        if (more) dma_tile(tile + DIST * nx, buf2);       // lands during the MFMAs of the stages before it
         const unsigned char *stage = xsb + (size_t)buf * STAGE_B;
 #pragma unroll
         for (int sub = 0; sub < kB16Sub; ++sub) {
@@ -852,22 +861,14 @@ __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev i
             const float *nrm = reinterpret_cast<const float *>(stage + 2 * TILE_B) + 32 * sub;
             f32x16 acc = zero;
             const unsigned char *xrow = stage + (size_t)(32 * sub + li) * DIM * 2;
-            // every A fragment of the stage is requested before the first MFMA (the compiler's own
-            // schedule kept two fragment registers and waited for LDS once per k-step: the MFMA
-            // pipe idled through eight LDS round trips per stage)
-            bf16x8 a[TS], al[TS];
 #pragma unroll
             for (int t = 0; t < TS; ++t) {
                 const uint32_t c0 = 2u * t + h;
-                a[t] = *reinterpret_cast<const bf16x8 *>(xrow + 16u * (c0 ^ sw));
-                al[t] = *reinterpret_cast<const bf16x8 *>(xrow + TILE_B + 16u * (c0 ^ sw));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < TS; ++t) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], qf[t], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], qf[t], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], ql[t], acc, 0, 0, 0);
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(xrow + 16u * (c0 ^ sw));
+                const bf16x8 al = *reinterpret_cast<const bf16x8 *>(xrow + TILE_B + 16u * (c0 ^ sw));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[t], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qf[t], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ql[t], acc, 0, 0, 0);
             }
             float sc[16];
 #pragma unroll
@@ -909,11 +910,11 @@ __global__ __launch_bounds__(kB16Waves * 64, 2) void bf_bf16_kernel(BfIndexDev i
                 }
             }
         }
-        if (more) stage_norms(tile + 2u * nx, buf2);
+        if (more) stage_norms(tile + DIST * nx, buf2);
         // The NEXT stage must have landed; the one just issued may stay in flight.  vmcnt counts in
         // issue order, and at least this wave's DMA instructions of this iteration are younger than
         // the next stage's (the survivor atomic / store, when issued, only make the wait stricter).
-        if (more && MEASURE == SCANN_HIP_DOT_PRODUCT) wait_all_but_pairs(my_pairs);
+        if (DIST == 2 && more && MEASURE == SCANN_HIP_DOT_PRODUCT) wait_all_but_pairs(my_pairs);
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -1474,10 +1475,10 @@ static int launch_bf16(const BfIndexDev &ix, const BfPass &p, const uint16_t *qb
                        const float *qn2, hipStream_t st) {
     const uint32_t ny = ceil_div_u32(p.nq, kB16Waves * 32);
     const uint32_t ntiles = ceil_div_u32(p.nrows, 32 * kB16Sub);
-    uint32_t want = std::max<uint32_t>(1, ((8u / kB16Waves) * (uint32_t)num_cus()) / ny);   // 8 waves per CU
+    uint32_t want = std::max<uint32_t>(1, ((uint32_t)(TS <= 8 ? kB16Occ : 2) * (uint32_t)num_cus()) / ny);
     want = std::min(want, ntiles);
     const uint32_t nx = 8u * ceil_div_u32(want, 8);
-    const size_t lds = (size_t)3 * (2 * 32 * kB16Sub * (TS * 16) * 2 + 256) +   // three (hi | lo | norms) stages
+    const size_t lds = (size_t)kB16Ring * (2 * 32 * kB16Sub * (TS * 16) * 2 + 256) +   // (hi | lo | norms) stages
                        16;
     if (ix.measure == SCANN_HIP_DOT_PRODUCT) {
         SCANN_TRY(set_dyn_lds((bf_bf16_kernel<TS, SCANN_HIP_DOT_PRODUCT>), lds));
