@@ -498,7 +498,7 @@ def main():
     # ---------------- recall10@10 (bin/ann_benchmark.rs:427-471 semantics) ------------------
     recall = None
     checked = None
-    if not args.no_recall and world == 1 and args.workload != "bf_dot":
+    if not args.no_recall and world == 1 and rank == 0 and args.workload != "bf_dot":
         ne = min(args.eval_queries, queries_all.shape[0])
         qe = np.ascontiguousarray(queries_all[:ne])
         gi, gd, gc = index.search_batched(qe, k, opts)
