@@ -1551,11 +1551,11 @@ static int enqueue_shortlist_search(const BfIndexDev &ix, BfWorkspace &w, uint32
     // than kp and the final kernel proves the result against the bound itself (or flags the query).
     uint32_t jthr = kp;
     {
-        static const double tail = [] {
-            const char *e = std::getenv("SCANN_HIP_BF_SHORTLIST_TAIL");
-            const double v = e ? std::atof(e) : 1e-6;
-            return v > 0.0 && v < 1.0 ? v : 1e-6;
-        }();
+        double tail = 1e-6;   // read per call: tests force the short-shortlist paths through it
+        if (const char *e = std::getenv("SCANN_HIP_BF_SHORTLIST_TAIL")) {
+            const double v = std::atof(e);
+            if (v > 0.0 && v < 1.0) tail = v;
+        }
         const double lam = (double)kp / (double)rs;
         double term = std::exp(-lam), cdf = term;   // P(X <= 0)
         for (uint32_t j = 1; j < kp; ++j) {         // smallest j with P(X >= j) = 1 - P(X <= j-1) <= 1e-6

@@ -942,3 +942,22 @@ def test_bf_small_batch_stream_kernel(measure, n, dim):
         for i in range(nq):
             H.assert_topk_equal_up_to_ties(idx[i, :cnt[i]], dist[i, :cnt[i]], oi[i, :cnt[i]], od[i, :cnt[i]],
                                            what="stream nq=%d q%d" % (nq, i))
+
+
+@pytest.mark.parametrize("tail", ["0.9", "0.3", "1e-2"])
+@pytest.mark.parametrize("measure", [hip.DOT_PRODUCT, hip.SQUARED_L2])
+def test_bf_shortlist_aggressive_filter_bound_stays_exact(monkeypatch, force_shortlist, tail, measure):
+    """A filter bound cut far too deep (tail probability 0.9: the best sample score) leaves shortlists
+    shorter than kp, some shorter than k.  The former are proven against the bound itself, the latter
+    are flagged and redone by the exact kernels: the rows returned by the host entry stay exact."""
+    monkeypatch.setenv("SCANN_HIP_BF_SHORTLIST_TAIL", tail)
+    n, dim, k, nq = 70000, 64, 10, 96
+    rows = synth.uniform_f32(n, dim, 42)
+    data, stride = orc.to_strided(rows)
+    index = hip.bf_create(data, n, dim, stride, measure)
+    q = synth.uniform_f32(nq, dim, 123)
+    idx, dist, cnt = index.search_batched(q, k)
+    oi, od, oc = orc.bf_search_batched(data, n, dim, stride, measure, q, k)
+    assert np.array_equal(cnt, oc)
+    for i in range(nq):
+        H.assert_topk_equal_up_to_ties(idx[i], dist[i], oi[i], od[i], what="tail %s q%d" % (tail, i))
