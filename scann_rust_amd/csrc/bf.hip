@@ -2003,6 +2003,33 @@ __global__ __launch_bounds__(256) void km_update_kernel(BfIndexDev ix, const flo
             centers[(size_t)c * dim + j] = ix.rows[(uint64_t)(c % ix.n) * ix.stride + j];
         return;
     }
+    if (dim <= 64) {
+        // Narrow rows (the per-subspace codebooks: 4..16 dims, 16..256 clusters): wave 0 runs the
+        // chains while waves 1-3 stage the NEXT tile, so the chain never waits for a staging phase
+        // (with one buffer the 4 summing threads idled through every copy: 2.1 ms per call at 62 k
+        // members).
+        const uint32_t half = kKmTileFloats / 2, tm = half / dim;   // members per half-tile
+        auto stage = [&](uint32_t m0, uint32_t buf, uint32_t t0, uint32_t nt) {
+            const uint32_t nm = min(tm, e - m0);
+            for (uint32_t f = t0; f < nm * dim; f += nt) s_x[buf * half + f] = grows[(uint64_t)m0 * dim + f];
+        };
+        stage(b, 0, tid, blockDim.x);
+        __syncthreads();
+        double sum = 0.0;
+        uint32_t buf = 0;
+        for (uint32_t m0 = b; m0 < e; m0 += tm, buf ^= 1u) {
+            const uint32_t nm = min(tm, e - m0);
+            if (tid >= 64) {
+                if (m0 + tm < e) stage(m0 + tm, buf ^ 1u, tid - 64, blockDim.x - 64);
+            } else if (tid < dim) {
+                const float *sx = s_x + buf * half;
+                for (uint32_t mm = 0; mm < nm; ++mm) sum += (double)sx[mm * dim + tid];
+            }
+            __syncthreads();
+        }
+        if (tid < dim) centers[(size_t)c * dim + tid] = (float)(sum / (double)(e - b));
+        return;
+    }
     // dimensions are processed in slabs of <= 256 (one chain per thread)
     for (uint32_t j0 = 0; j0 < dim; j0 += 256) {
         const uint32_t dw = min(256u, dim - j0);          // slab width
