@@ -765,6 +765,14 @@ __global__ __launch_bounds__(kB16Waves * 64, (TS <= 8 ? kB16Occ : 2)) void bf_bf
     for (int t = 0; t < TS; ++t) {
         qf[t] = *reinterpret_cast<const bf16x8 *>(qb + (size_t)qc * DIM + 16 * t + 8 * h);
         ql[t] = *reinterpret_cast<const bf16x8 *>(qbl + (size_t)qc * DIM + 16 * t + 8 * h);
+        if (MEASURE == SCANN_HIP_DOT_PRODUCT) {   // the score is -dot: negate the query once (sign bits:
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // exact), not every score
+            u32x4 a = __builtin_bit_cast(u32x4, qf[t]), b = __builtin_bit_cast(u32x4, ql[t]);
+            a ^= 0x80008000u;
+            b ^= 0x80008000u;
+            qf[t] = __builtin_bit_cast(bf16x8, a);
+            ql[t] = __builtin_bit_cast(bf16x8, b);
+        }
     }
     const float q2 = MEASURE == SCANN_HIP_DOT_PRODUCT ? 0.0f : qn2[qc];
     uint64_t T = 0;
@@ -874,7 +882,7 @@ __global__ __launch_bounds__(kB16Waves * 64, (TS <= 8 ? kB16Occ : 2)) void bf_bf
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (MEASURE == SCANN_HIP_DOT_PRODUCT) {
-                    sc[r] = -acc[r];
+                    sc[r] = acc[r];     // the query fragments carry the sign
                 } else {
                     sc[r] = (q2 + nrm[(r & 3) + 8 * (r >> 2) + 4 * h]) - 2.0f * acc[r];
                 }
