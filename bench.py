@@ -4,34 +4,32 @@
     python bench.py --gpus N --steps K --warmup W [--workload ah|bf_dot|txh] ...
 
 Metric (BASELINE.json): QPS @ recall10@10 + achieved HBM GB/s, 1M x 128 f32.
-Default workload `ah` = BASELINE.json configs[2]: AsymmetricHasher LUT16 (4-bit PQ,
-32 blocks x 16 centres) over 1M x 128 uniform U[0,1) vectors, k = 10, with
-search_with_reordering (exact f32 re-rank of the pre_reorder_k best approximate
-candidates).  A "step" is one search_batched call over one batch of `--batch` queries
-already resident in HBM; value = queries/s of the whole job.
 
-One process per GPU.  N > 1 (launched by torch.distributed.run), two layouts:
+N = 1 (default): workload `ah` = BASELINE.json configs[2]: AsymmetricHasher LUT16 (4-bit PQ, 32 blocks
+x 16 centres) over 1M x 128 uniform U[0,1) vectors, k = 10, search_with_reordering (exact f32 re-rank
+of the pre_reorder_k best approximate candidates).  A "step" is one search_batched call over one batch
+of `--batch` queries already resident in HBM; value = queries/s of the whole job.
 
-  --multi-gpu replica (default): the index of this configuration (1M x 128: 0.53 GB) fits one GPU
-    many times over, so the data-parallel unit is the QUERY -- the reference's own parallelism
-    (search_batched = one rayon task per query, tree_x_hybrid/mod.rs:404-408).  Every rank holds
-    the full index and searches its own batch of `--batch` queries per step; no data-path
-    collective.  Weak scaling: per-GPU work fixed, value = N * batch * steps / max-over-ranks time.
-  --multi-gpu shard: for indexes that do not fit (BASELINE configs[4]).  The database is sharded
-    across ranks (leaves; row ranges = leaves of a flat partition for the hasher), every rank scans
-    its shard for all queries, ONE RCCL all_to_all per step sends each peer the (merge key, index,
-    exact distance) triples of the queries that peer merges (xGMI is point-to-point: 1/world of
-    the all_gather volume per link), each rank merges its batch/world queries and the k result
-    rows are all_gathered (strong scaling: total work fixed).  Steps are software-pipelined: a
-    step's exchange overlaps the next step's local stage.
+N > 1 (one process per GPU, launched by torch.distributed.run): the north-star split --
+a leaf-sharded Tree-X-Hybrid index, ONE shard of the BASELINE configs[4] shape per GPU (12.5M x 96,
+S = 24, 1250 leaves per GPU: the index grows with N, at N = 8 it is the 100M x 96 / 10 000-leaf
+configuration), searched through the LIBRARY's own entry point scann_hip_txh_search_sharded_device:
+local stage -> one RCCL all-to-all of candidate blocks over xGMI -> merge -> all-gather of the k
+result rows, on the library's streams (csrc/comm.hip; no torch collective on the data path --
+torch.distributed/gloo carries only the rendezvous, the barriers and the max over ranks).  Every
+step searches the same `--batch` queries on all ranks; partitions_to_search is fixed, so the work of
+a step is fixed and split over the ranks ("strong").  `--multi-gpu replica` times N query-parallel
+copies of the N = 1 workload instead (reported as `secondary` by the default N > 1 run).
 
-The CPU oracle is used here ONLY as (a) the checker of a few result rows and (b) the
-cpu_baseline leg; the timed path is libscann_hip.so through its C ABI.
+The CPU oracle is used here ONLY as (a) the checker of a few result rows and (b) the cpu_baseline
+leg; the timed path is libscann_hip.so through its C ABI.
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -41,9 +39,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (no sparsity)
+# MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0          # HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+LDS_PEAK_GBPS = 157286.4        # ds_read_b128: 256 B/clk/CU x 256 CUs x 2.4 GHz
+LDS_MEASURED_GBPS = 150000.0    # "Aggregate with every CU streaming: ~150 TB/s for ds_read_b64/b128"
+F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # bf16 MFMA, dense (no sparsity)
+I8_MFMA_PEAK_TOPS = 5000.0      # i8 MFMA: 2x the bf16 rate per clock, dense
+
+METRIC = "QPS @ recall10@10 + achieved HBM GB/s, 1M x 128 f32"
 
 
 def log(*a):
@@ -54,138 +58,265 @@ def log(*a):
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="ah", choices=["ah", "bf_dot", "txh"])
-    p.add_argument("--num-points", dest="n", type=int, default=1_000_000)
-    p.add_argument("--dim", type=int, default=128)
-    p.add_argument("--subspaces", type=int, default=32)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--workload", default=None, choices=["ah", "bf_dot", "txh"],
+                   help="default: ah at N = 1, the leaf-sharded Tree-X-Hybrid at N > 1")
+    p.add_argument("--num-points", dest="n", type=int, default=None,
+                   help="points (per GPU when sharded); default 1M (ah, bf_dot, txh) / 12.5M per GPU (sharded)")
+    p.add_argument("--dim", type=int, default=None)
+    p.add_argument("--subspaces", type=int, default=None)
     p.add_argument("--num-codes", type=int, default=16,
                    help="codes per subspace: <= 16 = LUT16 (4-bit), <= 256 = byte codes")
     p.add_argument("--batch", type=int, default=1024)
     p.add_argument("--k", type=int, default=10)
-    p.add_argument("--pre-reorder-k", type=int, default=5000)
-    p.add_argument("--leaves", type=int, default=1000)
-    p.add_argument("--partitions-to-search", type=int, default=50)
+    p.add_argument("--pre-reorder-k", type=int, default=None)
+    p.add_argument("--leaves", type=int, default=None, help="k-means leaves (per GPU when sharded)")
+    p.add_argument("--partitions-to-search", type=int, default=None)
     p.add_argument("--dist", default="uniform", choices=["uniform", "clustered"])
     p.add_argument("--eval-queries", type=int, default=256)
-    p.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-recall", action="store_true")
-    # rehearsal knobs (not used by the driver): gloo collectives / all ranks on one device
-    p.add_argument("--multi-gpu", default="replica", choices=["replica", "shard"],
-                   help="N > 1: query-parallel replicas of the index (default) or a leaf-sharded index "
-                        "with one RCCL all_to_all per step")
-    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
-    p.add_argument("--single-device", action="store_true")
+    p.add_argument("--no-batch-sweep", action="store_true")
+    p.add_argument("--multi-gpu", default="shard", choices=["shard", "replica"],
+                   help="N > 1: the leaf-sharded index through the library's RCCL exchange (default), or "
+                        "query-parallel replicas of the N = 1 workload")
+    p.add_argument("--no-secondary", action="store_true", help="N > 1 shard: skip the replica measurement")
+    p.add_argument("--m-local", type=int, default=0, help="sharded: candidates sent per (rank, query); 0 = all m")
+    p.add_argument("--kmeans-iters", type=int, default=8)
     p.add_argument("--bf-exact", action="store_true",
                    help="bf_dot: exact f32-MFMA kernels only (no bf16 shortlist)")
-    return p.parse_args()
+    a = p.parse_args()
+    sharded = a.gpus > 1 and a.multi_gpu == "shard" and a.workload in (None, "txh")
+    a.sharded = sharded
+    if a.workload is None:
+        a.workload = "txh" if sharded else "ah"
+    if sharded:      # one shard of BASELINE configs[4] per GPU
+        a.n = a.n or 12_500_000
+        a.dim = a.dim or 96
+        a.subspaces = a.subspaces or 24
+        a.leaves = a.leaves or 1250
+        a.partitions_to_search = a.partitions_to_search or 10
+        a.pre_reorder_k = a.pre_reorder_k or 8192
+    else:
+        a.n = a.n or 1_000_000
+        a.dim = a.dim or 128
+        a.subspaces = a.subspaces or 32
+        a.leaves = a.leaves or 1000
+        a.partitions_to_search = a.partitions_to_search or 50
+        a.pre_reorder_k = a.pre_reorder_k or 5000
+    return a
 
 
 def dev_ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def build_txh(args, torch, dist, hip, synth, trainer, device, local_rank, rank, world, stride):
-    """Tree-X-Hybrid index on a clustered synthetic set (mixture of 1000 Gaussians, SURVEY.md
-    8d).  The data is generated with torch on the GPU (harness plumbing); rank 0 builds the index
-    with the library's GPU k-means and broadcasts it so every rank holds the identical index, then
-    keeps only its leaves."""
-    from scann_rust_amd import sharding
-    n, dim, S, L, Q, k = args.n, args.dim, args.subspaces, args.leaves, args.batch, args.k
+def lib_sha256(hip):
+    h = hashlib.sha256()
+    with open(hip.LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+# =====================================================================================================
+# index builders
+# =====================================================================================================
+def clustered_points(torch, device, seed, n, dim, n_clusters=1000, centre_seed=7):
+    """Mixture of 1000 Gaussians: centres from `centre_seed` (identical on every rank),
+    points from `seed`.  torch on the GPU = harness plumbing."""
+    gc = torch.Generator(device=device)
+    gc.manual_seed(centre_seed)
+    cen = torch.rand((n_clusters, dim), generator=gc, device=device)
     g = torch.Generator(device=device)
-    g.manual_seed(7)
-    cen = torch.rand((1000, dim), generator=g, device=device)
+    g.manual_seed(seed)
     sig = 0.1 * (1.0 / 6.0) ** 0.5
-    X = cen[torch.randint(0, 1000, (n,), generator=g, device=device)] + \
+    return cen[torch.randint(0, n_clusters, (n,), generator=g, device=device)] + \
         sig * torch.randn((n, dim), generator=g, device=device)
+
+
+def train_residual_codebook(torch, hip, res_sample, dim, S, stride, device_index):
+    ns = res_sample.shape[0]
+    rs = np.zeros((ns, stride), np.float32)
+    rs[:, :dim] = res_sample
+    rbf = hip.bf_create(rs, ns, dim, stride, hip.SQUARED_L2, device=device_index)
+    dsub = dim // S
+    cb = np.zeros((S, 16, dsub), np.float32)
+    for sidx in range(S):
+        c0 = hip.kmeans_init_pp(rbf, 16, seed=42 + sidx, col_offset=sidx * dsub, sub_dim=dsub)
+        cb[sidx] = hip.kmeans_lloyd(rbf, c0, max_iterations=25, col_offset=sidx * dsub)[0]
+    rbf.close()
+    return cb
+
+
+def build_txh_single(args, torch, hip, device, local_rank, stride):
+    """Tree-X-Hybrid index on the clustered set, built with the library's GPU k-means."""
+    n, dim, S, L, Q, k = args.n, args.dim, args.subspaces, args.leaves, args.batch, args.k
+    X = clustered_points(torch, device, 11, n, dim)
     nq = max(Q * 4, args.eval_queries)
-    Xq = cen[torch.randint(0, 1000, (nq,), generator=g, device=device)] + \
-        sig * torch.randn((nq, dim), generator=g, device=device)
-    C = torch.empty((L, dim), device=device)
-    assign = torch.empty((n,), dtype=torch.int64, device=device)
-    cb_t = torch.empty((S, 16, dim // S), device=device)
-    if rank == 0:
-        # index build with the library's own GPU k-means (KMeans::fit of trees/kmeans.rs: k-means++
-        # seeding + Lloyd, scann_hip_kmeans_*): partitioner on all rows, codebook on a residual sample
-        xs = np.zeros((n, stride), np.float32)
-        xs[:, :dim] = X.cpu().numpy()
-        bf = hip.bf_create(xs, n, dim, stride, hip.SQUARED_L2, device=local_rank)
-        c_np, a_np, _, _, it_done, _ = hip.kmeans_lloyd(bf, hip.kmeans_init_pp(bf, L, seed=42),
-                                                        max_iterations=25)
-        bf.close()
-        del xs
-        C.copy_(torch.from_numpy(c_np).to(device))
-        assign.copy_(torch.from_numpy(a_np.astype(np.int64)).to(device))
-        res = X - C[assign]
-        ns = min(n, 262144)
-        rs = np.zeros((ns, stride), np.float32)
-        rs[:, :dim] = res[torch.randperm(n, generator=g, device=device)[:ns]].cpu().numpy()
-        rbf = hip.bf_create(rs, ns, dim, stride, hip.SQUARED_L2, device=local_rank)
-        dsub = dim // S
-        cb_np = np.zeros((S, 16, dsub), np.float32)
-        for sidx in range(S):
-            c0 = hip.kmeans_init_pp(rbf, 16, seed=42 + sidx, col_offset=sidx * dsub, sub_dim=dsub)
-            cb_np[sidx] = hip.kmeans_lloyd(rbf, c0, max_iterations=25, col_offset=sidx * dsub)[0]
-        rbf.close()
-        cb_t.copy_(torch.from_numpy(cb_np).to(device))
-        log("partitioner k-means: %d Lloyd iterations" % it_done)
-    if world > 1:
-        if args.backend == "nccl":
-            for t in (C, assign, cb_t):
-                dist.broadcast(t, 0)
-        else:
-            for t in (C, assign, cb_t):
-                h = t.cpu()
-                dist.broadcast(h, 0)
-                t.copy_(h.to(device))
+    Xq = clustered_points(torch, device, 12, nq, dim)
+    xs = np.zeros((n, stride), np.float32)
+    xs[:, :dim] = X.cpu().numpy()
+    bf = hip.bf_create(xs, n, dim, stride, hip.SQUARED_L2, device=local_rank)
+    centers, a_np, sizes, _, it_done, _ = hip.kmeans_lloyd(bf, hip.kmeans_init_pp(bf, L, seed=42), max_iterations=25)
+    bf.close()
+    log("partitioner k-means: %d Lloyd iterations" % it_done)
+    assign = torch.from_numpy(a_np.astype(np.int64)).to(device)
     order = torch.argsort(assign, stable=True)
-    counts = torch.bincount(assign, minlength=L).cpu().numpy()
+    C = torch.from_numpy(centers).to(device)
+    g = torch.Generator(device=device)
+    g.manual_seed(5)
+    pick = torch.randperm(n, generator=g, device=device)[:min(n, 262144)]
+    codebook = train_residual_codebook(torch, hip, (X[pick] - C[assign[pick]]).cpu().numpy(), dim, S, stride,
+                                       local_rank)
     leaf_off = np.zeros(L + 1, np.uint32)
-    leaf_off[1:] = np.cumsum(counts)
-    sizes = counts.astype(np.uint32)
-    owner = sharding.assign_leaves(sizes, world)
-    mine = owner == rank
-    centers = C.cpu().numpy().astype(np.float32)
-    codebook = cb_t.cpu().numpy().astype(np.float32)
+    leaf_off[1:] = np.cumsum(sizes)
     order_np = order.cpu().numpy()
-    sel = np.concatenate([order_np[leaf_off[l]:leaf_off[l + 1]] for l in range(L) if mine[l]]
-                         or [np.zeros(0, np.int64)])
-    local_sizes = np.where(mine, sizes, 0).astype(np.uint32)
-    loc_off = np.zeros(L + 1, np.uint32)
-    loc_off[1:] = np.cumsum(local_sizes)
-    leaf_of_row = np.repeat(np.arange(L, dtype=np.uint32), local_sizes)
-    rows_csr = np.zeros((sel.size, stride), np.float32)
-    rows_csr[:, :dim] = X[torch.from_numpy(sel).to(device)].cpu().numpy()
-    codes = hip.encode(codebook, rows_csr, stride=stride, centers=centers, leaf_of_row=leaf_of_row,
-                       device=local_rank)
-    index = hip.txh_create(data=rows_csr, n_rows=sel.size, dim=dim, stride=stride, centers=centers,
-                           leaf_offsets=loc_off, leaf_ids=sel.astype(np.uint32),
-                           leaf_sizes_global=sizes, codebook=codebook, codes=codes, use_residuals=True,
-                           partitions_to_search=args.partitions_to_search,
+    rows_csr = np.zeros((n, stride), np.float32)
+    rows_csr[:, :dim] = X[order].cpu().numpy()
+    leaf_of_row = np.repeat(np.arange(L, dtype=np.uint32), sizes)
+    codes = hip.encode(codebook, rows_csr, stride=stride, centers=centers, leaf_of_row=leaf_of_row, device=local_rank)
+    index = hip.txh_create(data=rows_csr, n_rows=n, dim=dim, stride=stride, centers=centers, leaf_offsets=leaf_off,
+                           leaf_ids=order_np.astype(np.uint32), leaf_sizes_global=sizes, codebook=codebook,
+                           codes=codes, use_residuals=True, partitions_to_search=args.partitions_to_search,
                            pre_reorder_multiplier=float(args.pre_reorder_k) / k, data_is_csr_order=True,
                            device=local_rank)
     queries = Xq.cpu().numpy().astype(np.float32)
     tok, _, _ = hip.txh_partition(index, np.ascontiguousarray(queries[:Q]), args.partitions_to_search)
-    scanned_local = local_sizes[tok.astype(np.int64)].sum(1).mean()
-    state = dict(index=index, queries=queries, n_local=int(sel.size), data=rows_csr, codebook=codebook,
-                 codes=codes,
-                 scan_bytes_per_query=int(scanned_local * (S // 2) + args.partitions_to_search * S * 64))
-    full = None
-    if world == 1:
-        full = np.zeros((n, stride), np.float32)
-        full[:, :dim] = X.cpu().numpy()
-    state["full_data"] = full
+    scanned = float(sizes[tok.astype(np.int64)].sum(1).mean())
+    full = xs   # rows by datapoint index (the oracle's and the ground truth's view)
 
     def oracle_index(orc, m, kk):
-        return orc.TxhIndex(full, stride, dim, centers, leaf_off, order_np.astype(np.uint32), codebook,
-                            codes, use_residuals=True, partitions_to_search=args.partitions_to_search,
+        return orc.TxhIndex(full, stride, dim, centers, leaf_off, order_np.astype(np.uint32), codebook, codes,
+                            use_residuals=True, partitions_to_search=args.partitions_to_search,
                             pre_reorder_multiplier=float(m) / kk)
-    state["oracle_index"] = oracle_index
-    return state
+    return dict(index=index, queries=queries, data=full, codebook=codebook, codes=codes, scanned_points=scanned,
+                oracle_index=oracle_index)
 
 
+def build_txh_shard(args, torch, dist, hip, device, local_rank, rank, world, stride):
+    """One BASELINE configs[4]-shaped shard per rank.  Rank g draws its own n points of the common
+    mixture and trains its own `leaves` centroids on them (the library's GPU k-means); the global
+    partitioner is the concatenation of the ranks' centroid tables (leaf l belongs to rank
+    l // leaves), the PQ codebook is trained by rank 0 on its residuals and broadcast.  Centroids,
+    codebook and GLOBAL leaf sizes are replicated, so every rank selects the same leaves and forms
+    identical merge keys.  Datapoint index = rank * n + row in leaf order."""
+    n, dim, S, Lr, Q, k = args.n, args.dim, args.subspaces, args.leaves, args.batch, args.k
+    L = Lr * world
+    X = clustered_points(torch, device, 100 + rank, n, dim)
+    nq = max(Q * 4, args.eval_queries)
+    queries = clustered_points(torch, device, 12, nq, dim).cpu().numpy().astype(np.float32)   # same on all ranks
+    xs = np.zeros((n, stride), np.float32)
+    xs[:, :dim] = X.cpu().numpy()
+    bf = hip.bf_create(xs, n, dim, stride, hip.SQUARED_L2, device=local_rank)
+    c_loc, a_np, sizes_loc, _, it_done, _ = hip.kmeans_lloyd(bf, hip.kmeans_init_pp(bf, Lr, seed=42 + rank),
+                                                             max_iterations=args.kmeans_iters)
+    bf.close()
+    del xs
+    log("shard k-means: %d leaves, %d Lloyd iterations" % (Lr, it_done))
+    assign = torch.from_numpy(a_np.astype(np.int64)).to(device)
+    order = torch.argsort(assign, stable=True)
+    C_loc = torch.from_numpy(c_loc).to(device)
+    cb_t = torch.zeros((S, 16, dim // S))
+    if rank == 0:
+        g = torch.Generator(device=device)
+        g.manual_seed(5)
+        pick = torch.randperm(n, generator=g, device=device)[:min(n, 262144)]
+        cb_t = torch.from_numpy(train_residual_codebook(torch, hip, (X[pick] - C_loc[assign[pick]]).cpu().numpy(),
+                                                        dim, S, stride, local_rank))
+    cen_all = [torch.zeros((Lr, dim)) for _ in range(world)]
+    siz_all = [torch.zeros((Lr,), dtype=torch.int64) for _ in range(world)]
+    if world > 1:
+        dist.broadcast(cb_t, 0)
+        dist.all_gather(cen_all, torch.from_numpy(c_loc))
+        dist.all_gather(siz_all, torch.from_numpy(sizes_loc.astype(np.int64)))
+    else:
+        cen_all, siz_all = [torch.from_numpy(c_loc)], [torch.from_numpy(sizes_loc.astype(np.int64))]
+    codebook = cb_t.numpy().astype(np.float32)
+    centers = torch.cat(cen_all).numpy().astype(np.float32)                 # [L][dim], replicated
+    sizes_global = torch.cat(siz_all).numpy().astype(np.uint32)            # [L]
+    local_sizes = np.zeros(L, np.uint32)
+    local_sizes[rank * Lr:(rank + 1) * Lr] = sizes_loc
+    loc_off = np.zeros(L + 1, np.uint32)
+    loc_off[1:] = np.cumsum(local_sizes)
+    rows_csr = np.zeros((n, stride), np.float32)
+    rows_csr[:, :dim] = X[order].cpu().numpy()
+    del X
+    torch.cuda.empty_cache()
+    leaf_of_row = np.repeat(np.arange(L, dtype=np.uint32), local_sizes)
+    codes = hip.encode(codebook, rows_csr, stride=stride, centers=centers, leaf_of_row=leaf_of_row, device=local_rank)
+    ids = (np.arange(n, dtype=np.uint64) + np.uint64(rank) * np.uint64(n)).astype(np.uint32)
+    index = hip.txh_create(data=rows_csr, n_rows=n, dim=dim, stride=stride, centers=centers, leaf_offsets=loc_off,
+                           leaf_ids=ids, leaf_sizes_global=sizes_global, codebook=codebook, codes=codes,
+                           use_residuals=True, partitions_to_search=args.partitions_to_search,
+                           pre_reorder_multiplier=float(args.pre_reorder_k) / k, data_is_csr_order=True,
+                           device=local_rank)
+    tok, _, _ = hip.txh_partition(index, np.ascontiguousarray(queries[:Q]), args.partitions_to_search)
+    scanned_local = float(local_sizes[tok.astype(np.int64)].sum(1).mean())
+    scanned_global = float(sizes_global[tok.astype(np.int64)].sum(1).mean())
+    return dict(index=index, queries=queries, data=rows_csr, ids=ids, codebook=codebook, codes=codes,
+                scanned_points=scanned_local, scanned_points_global=scanned_global, L=L)
+
+
+# =====================================================================================================
+# roofline of the dominant kernel
+# =====================================================================================================
+def traffic_for(hip, workload, kernel_name):
+    """PMC-measured HBM bytes per launch from profiles/traffic.json -- only when the entry was recorded
+    for THIS kernel of THIS build of the library (keyed by kernel name + sha256 of libscann_hip.so by
+    tools/prof_refresh.sh); anything else would be a stale constant, so null."""
+    tr = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        ent = json.load(open(tr)).get(workload)
+        if isinstance(ent, dict) and ent.get("kernel") == kernel_name and ent.get("lib_sha256") == lib_sha256(hip):
+            return {"bytes": ent["bytes"], "source": ent.get("source")}
+    except Exception:
+        pass
+    return None
+
+
+def scan_roofline(hip, workload, kernel_name, kernel_ms, scanned_points, S, K, Q, k, pairs_per_query):
+    """LUT16 / byte-code ADC scan.  Binding resource of the batched scan = the LDS table gather: one
+    ds_read_b128 (16 B) per (point, subspace, quad of 4 queries), i.e. scanned_points * S * 4 B per
+    query (MI355X_MICROARCH.md section LDS: 256 B/clk/CU).  The SURVEY 8(d) HBM figure is reported
+    beside it as ALGORITHMIC bytes: the codes are read once per tile and shared by the whole batch, so
+    it is not physical traffic and is not a fraction of the HBM roof."""
+    code_bytes = S // 2 if K <= 16 else S
+    algo_bytes = scanned_points * code_bytes + pairs_per_query * S * (16 if K <= 16 else 256) * 4 + k * 8
+    lds_bytes = scanned_points * S * 4.0 * Q
+    t = kernel_ms * 1e-3
+    ach = lds_bytes / t / 1e9 if t else 0.0
+    roof = {"bound": "lds", "achieved": ach, "peak": LDS_PEAK_GBPS, "unit": "GB/s", "frac": ach / LDS_PEAK_GBPS,
+            "frac_of_measured_peak": ach / LDS_MEASURED_GBPS, "peak_measured": LDS_MEASURED_GBPS,
+            "traffic": None, "kernel": kernel_name, "kernel_ms": kernel_ms,
+            "algorithmic": "LDS gather: scanned points (%.0f) x S (%d) x 16 B per quad of 4 queries x %d queries "
+                           "per launch = %.4g B; peak = ds_read_b128 256 B/clk/CU x 256 CUs x 2.4 GHz"
+                           % (scanned_points, S, Q, lds_bytes)}
+    tr = traffic_for(hip, workload, kernel_name)
+    if tr:
+        roof["traffic"] = tr["bytes"]
+        roof["traffic_source"] = tr["source"]
+    algo = {"bytes_per_query": algo_bytes, "GBps": algo_bytes * Q / t / 1e9 if t else 0.0,
+            "x_hbm_peak": (algo_bytes * Q / t / 1e9 / HBM_PEAK_GBPS) if t else 0.0,
+            "note": "SURVEY 8(d) algorithmic bytes (scanned codes + LUTs + out) x queries / kernel time; the batch "
+                    "shares one read of the codes, so this may exceed the 8 TB/s HBM roof and is not a roofline "
+                    "fraction -- physical HBM bytes are `roofline.traffic`"}
+    return roof, algo
+
+
+# =====================================================================================================
 def main():
     args = parse()
     import torch
@@ -193,445 +324,386 @@ def main():
     from scann_rust_amd import hip, synth, trainer
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    nproc = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    if args.single_device:
-        local_rank = 0
+    if nproc != args.gpus and nproc == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    nproc = world                       # processes (= GPUs) of the job
-    replica = nproc > 1 and args.multi_gpu == "replica"
-    if replica:
-        world = 1                       # shards of the index: every rank holds all of it
-    srank = 0 if replica else rank      # this rank's shard
     if nproc > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)   # RCCL over xGMI
-        else:
-            dist.init_process_group("gloo")
-
-    def all_to_all_start(dst, src):
-        """Enqueue the exchange of this step's destination blocks (one block per peer: xGMI is
-        point-to-point, every rank sends each peer only the candidates of the queries that peer
-        merges).  NCCL/RCCL: asynchronous on the process group's own stream, so the next step's
-        local stage overlaps the transfer."""
-        if args.backend == "nccl":
-            return dist.all_to_all_single(dst.view(-1), src.view(-1), async_op=True)
-        h = torch.empty(src.numel(), dtype=src.dtype)            # rehearsal path: through host memory
-        dist.all_to_all_single(h, src.view(-1).cpu())
-        dst.view(-1).copy_(h.to(dst.device))
-        return None
-
-    def wait_for(work):
-        if work is not None:
-            work.wait()   # the current stream waits for the collective; the host does not block
-
-    def all_gather_start(dst, src):
-        if args.backend == "nccl":
-            return dist.all_gather_into_tensor(dst.view(-1), src.view(-1), async_op=True)
-        else:
-            parts = [torch.empty(src.numel(), dtype=src.dtype) for _ in range(world)]
-            dist.all_gather(parts, src.view(-1).cpu())
-            dst.view(-1).copy_(torch.cat(parts).to(dst.device))
-            return None
+        # control plane only (rendezvous, barriers, max over ranks, index broadcast): the data path's
+        # collectives are the library's own RCCL calls
+        dist.init_process_group("gloo")
+    sharded = args.sharded and nproc > 1
+    replica = nproc > 1 and not sharded
 
     L = hip.load()
     n, dim, S, K, k, Q = args.n, args.dim, args.subspaces, args.num_codes, args.k, args.batch
     m = args.pre_reorder_k
     stride = hip.compute_stride(dim)
-    stream = torch.cuda.current_stream().cuda_stream
-    sptr = ctypes.c_void_p(stream)
-
-    # ---------------- data (synthetic, reference-harness shape: U[0,1), seeds 42/123) ----
     t0 = time.time()
-    lo, hi = (n * srank) // world, (n * (srank + 1)) // world
-    n_loc = hi - lo
-    txh_state = None
-    if args.workload == "txh":
-        txh_state = build_txh(args, torch, dist, hip, synth, trainer, device, local_rank, srank, world,
-                              stride)
-        rows = None
-        queries_all = txh_state["queries"]
-        n_loc = txh_state["n_local"]
-    elif args.dist == "uniform":
-        rows = synth.uniform_f32(n_loc, dim, 42, row_offset=lo)
-        queries_all = synth.uniform_f32(max(Q * 4, args.eval_queries), dim, 123)
-    else:
-        if world > 1:
-            raise SystemExit("clustered data is single-GPU only in this round")
-        rows, _ = synth.clustered_f32(n, dim, 7, n_clusters=1000)
-        qsrc, _ = synth.clustered_f32(max(Q * 4, args.eval_queries), dim, 8, n_clusters=1000)
-        queries_all = qsrc
-    if replica and rank:                # every replica searches its own queries
-        queries_all = np.roll(queries_all, -rank * Q, axis=0)
-    if rows is not None:
-        data = np.zeros((n_loc, stride), np.float32)
-        data[:, :dim] = rows
-    else:
-        data = txh_state["data"]
-    log("data %.1fs (n_local=%d)" % (time.time() - t0, n_loc))
 
-    workload_name = {"ah": "AsymmetricHasher %s S=%d K=%d + exact re-rank"
-                           % ("LUT16" if K <= 16 else "byte codes", S, K),
-                     "bf_dot": "BruteForceSearcher.search_batched DotProduct (bf16-MFMA shortlist + exact f32 "
-                               "re-score, verified)" if not args.bf_exact else
-                               "BruteForceSearcher.search_batched DotProduct (f32 MFMA)",
-                     "txh": "Tree-X-Hybrid L=%d P=%d LUT16 S=%d + exact re-rank"
-                            % (args.leaves, args.partitions_to_search, S)}[args.workload]
-
-    opts = hip.default_opts()
-    index = None
-    algo_bytes_per_query = None
+    # ---------------- index ------------------------------------------------------------------------
+    st = None
+    data = codebook = codes = None
     flops_per_query = None
-    codebook = codes = None
-    t0 = time.time()
-    if args.workload == "txh":
-        index = txh_state["index"]
-        codebook, codes = txh_state["codebook"], txh_state["codes"]
-        algo_bytes_per_query = txh_state["scan_bytes_per_query"]
-        opts.partitions_to_search = args.partitions_to_search
-        opts.pre_reorder_k = m
-        opts.exact_reorder = 1
-    elif args.workload == "bf_dot":
-        if world > 1:
-            raise SystemExit("bf_dot is single-GPU only in this round")
-        index = hip.bf_create(data, n, dim, stride, hip.DOT_PRODUCT)
-        algo_bytes_per_query = n * dim * 4          # SURVEY.md 8d (per DB pass, B = batch)
-        flops_per_query = 2.0 * n * dim
+    comm = None
+    if sharded:
+        st = build_txh_shard(args, torch, dist, hip, device, local_rank, rank, nproc, stride)
+        index, queries_all = st["index"], st["queries"]
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(hip.Comm.unique_id()), dtype=torch.uint8).clone()
+        dist.broadcast(uid, 0)
+        comm = hip.Comm(uid.numpy().tobytes(), rank, nproc, device=local_rank)
+    elif args.workload == "txh":
+        st = build_txh_single(args, torch, hip, device, local_rank, stride)
+        index, queries_all, data, codebook, codes = st["index"], st["queries"], st["data"], st["codebook"], st["codes"]
     else:
-        # codebook: identical on every rank (trained on a deterministic global sample)
         if args.dist == "uniform":
-            sel = (synth.splitmix64(0xC0DE, 0, 65536) % np.uint64(n)).astype(np.int64)
-            sample = synth.uniform_rows(sel, dim, 42)
+            rows = synth.uniform_f32(n, dim, 42)
+            queries_all = synth.uniform_f32(max(Q * 4, args.eval_queries), dim, 123)
         else:
-            sample = rows[:: max(1, n // 65536)]
-        if args.workload == "ah":
+            rows, _ = synth.clustered_f32(n, dim, 7, n_clusters=1000)
+            queries_all, _ = synth.clustered_f32(max(Q * 4, args.eval_queries), dim, 8, n_clusters=1000)
+        data = np.zeros((n, stride), np.float32)
+        data[:, :dim] = rows
+        if args.workload == "bf_dot":
+            index = hip.bf_create(data, n, dim, stride, hip.DOT_PRODUCT, device=local_rank)
+            flops_per_query = 2.0 * n * dim
+        else:
+            sample = rows[:: max(1, n // 65536)] if args.dist != "uniform" else \
+                synth.uniform_rows((synth.splitmix64(0xC0DE, 0, 65536) % np.uint64(n)).astype(np.int64), dim, 42)
             codebook = trainer.train_codebook(sample, S, K, iters=25, seed=42, sample=1 << 30)
             codes = hip.encode(codebook, data, stride=stride, device=local_rank)
-            if world == 1:
-                index = hip.txh_create(data=data, n_rows=n, dim=dim, stride=stride, centers=None,
-                                       leaf_offsets=None, leaf_ids=None, codebook=codebook,
-                                       codes=codes, use_residuals=False, partitions_to_search=1,
-                                       pre_reorder_multiplier=float(m) / k, device=local_rank)
-            else:
-                # flat partition: leaf g = row range of rank g; all leaves searched
-                sizes = np.array([(n * (g + 1)) // world - (n * g) // world for g in range(world)],
-                                 np.uint32)
-                off = np.zeros(world + 1, np.uint32)
-                off[srank + 1:] = n_loc
-                index = hip.txh_create(
-                    data=data, n_rows=n_loc, dim=dim, stride=stride,
-                    centers=np.zeros((world, dim), np.float32), leaf_offsets=off,
-                    leaf_ids=np.arange(lo, hi, dtype=np.uint32), leaf_sizes_global=sizes,
-                    codebook=codebook, codes=codes, use_residuals=False,
-                    partitions_to_search=world, pre_reorder_multiplier=float(m) / k,
-                    data_is_csr_order=True, device=local_rank)
-            # SURVEY.md 8d: 16 002 128 B at N = 1; per launch a rank scans its n_loc points
-            code_bytes = S // 2 if K <= 16 else S
-            algo_bytes_per_query = n_loc * code_bytes + S * K * 4 + k * 8
+            index = hip.txh_create(data=data, n_rows=n, dim=dim, stride=stride, centers=None, leaf_offsets=None,
+                                   leaf_ids=None, codebook=codebook, codes=codes, use_residuals=False,
+                                   partitions_to_search=1, pre_reorder_multiplier=float(m) / k, device=local_rank)
+        del rows
+    if replica and rank:                # every replica searches its own queries
+        queries_all = np.roll(queries_all, -rank * Q, axis=0)
+    log("index built in %.1fs" % (time.time() - t0))
+
+    workload_name = {
+        "ah": "AsymmetricHasher %s S=%d K=%d + exact re-rank" % ("LUT16" if K <= 16 else "byte codes", S, K),
+        "bf_dot": "BruteForceSearcher.search_batched DotProduct (bf16-MFMA shortlist + exact f32 re-score, verified)"
+                  if not args.bf_exact else "BruteForceSearcher.search_batched DotProduct (f32 MFMA)",
+        "txh": "Tree-X-Hybrid L=%d P=%d LUT16 S=%d + exact re-rank"
+               % (args.leaves * (nproc if sharded else 1), args.partitions_to_search, S)}[args.workload]
+
+    opts = hip.default_opts()
+    if args.workload != "bf_dot":
         opts.pre_reorder_k = m
         opts.exact_reorder = 1
-    log("index %.1fs" % (time.time() - t0))
+    if args.workload == "txh":
+        opts.partitions_to_search = args.partitions_to_search
+    opts.bf_exact = 1 if args.bf_exact else 0
 
-    # ---------------- device buffers (inputs resident in HBM before the timed region) ----
+    # ---------------- device buffers (inputs resident in HBM before the timed region) ----------------
     nbatches = 4
-    qdev = [torch.from_numpy(np.ascontiguousarray(queries_all[i * Q:(i + 1) * Q])).to(device)
-            for i in range(nbatches)]
-    out_idx = torch.empty((Q, k), dtype=torch.int32, device=device)
-    out_dist = torch.empty((Q, k), dtype=torch.float32, device=device)
-    out_cnt = torch.empty((Q,), dtype=torch.int32, device=device)
-    # Sharded runs: a rank sends its m_local best candidates.  A random row-range shard holds
-    # Binomial(m, 1/world) of the global best m, so m_local = m/world + 6 sigma + 16 suffices;
-    # the merge kernel VERIFIES it (status Aborted -> the whole measurement is repeated with
-    # m_local = m, which is exact by construction).
-    m_local = m
-    if world > 1 and args.workload == "ah":
-        m_local = min(m, int(m / world + 6.0 * (m / world) ** 0.5 + 16))
-    elapsed = kernel_ms = 0.0
-    kernel_name = ""
-    bf_exact_retry = False
+    qdev = [torch.from_numpy(np.ascontiguousarray(queries_all[i * Q:(i + 1) * Q])).to(device) for i in range(nbatches)]
+    streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)]
+    outs = [(torch.empty((Q, k), dtype=torch.int32, device=device), torch.empty((Q, k), dtype=torch.float32, device=device),
+             torch.empty((Q,), dtype=torch.int32, device=device)) for _ in range(2)]
+    hip.check(L.scann_hip_index_reserve(index.h, Q, k, ctypes.byref(opts)))
 
-    def device_status_aborted():
-        """Brute force: a bf16-shortlist result that could not be proven exact -> repeat the whole
-        measurement on the exact kernels.  Any other failure raises."""
-        nonlocal bf_exact_retry
-        try:
-            hip.check(L.scann_hip_index_last_device_status(index.h, sptr))
-        except hip.ScannError as e:
-            if args.workload == "bf_dot" and e.code == 10 and not bf_exact_retry:
-                log("a bf16-shortlist result could not be verified; repeating with the exact kernels")
-                bf_exact_retry = True
-                return True
-            raise
-        return False
+    def step(i, qd=None, nq=Q):
+        qd = qdev[i % nbatches] if qd is None else qd
+        b = i & 1
+        oi, od, oc = outs[b]
+        sp = ctypes.c_void_p(streams[b if sharded else 0].cuda_stream)
+        if sharded:
+            # two caller streams alternate: step i's exchange (on the library's stream) overlaps
+            # step i+1's local stage (the library orders its own buffers with events)
+            hip.check(L.scann_hip_txh_search_sharded_device(index.h, comm.h, dev_ptr(qd), nq, dim, k,
+                                                            ctypes.byref(opts), args.m_local, dev_ptr(oi),
+                                                            dev_ptr(od), dev_ptr(oc), sp))
+        else:
+            hip.check(L.scann_hip_search_batched_device(index.h, dev_ptr(qd), nq, dim, k, ctypes.byref(opts),
+                                                        dev_ptr(oi), dev_ptr(od), dev_ptr(oc), sp))
 
-    while True:
-        lopts = hip.default_opts()
-        lopts.pre_reorder_k = m_local if world > 1 else opts.pre_reorder_k
-        lopts.exact_reorder = opts.exact_reorder
-        lopts.partitions_to_search = opts.partitions_to_search
-        if world > 1:
-            if Q % world:
-                raise SystemExit("--batch must be a multiple of the number of ranks")
-            from scann_rust_amd import sharding as _sh
-            Qr = Q // world
-            # local stage output (SoA, [Q][m_local]) -> destination blocks -> ONE all_to_all per
-            # step -> merge of this rank's Qr queries -> all_gather of the k result rows (tiny)
-            kb, ib = Q * m_local * 8, Q * m_local * 4
-            soa = torch.zeros((kb + 2 * ib + Q * 4,), dtype=torch.uint8, device=device)
-            ssec = [0, kb, kb + ib, kb + 2 * ib]
-            bk, bi, be, bc, block_bytes = _sh.block_layout(Q, m_local, world)
-            bsec = [bk, bi, be, bc]
-            # double-buffered: step i+1's local stage runs while step i's exchange is in flight
-            sends = [torch.zeros((world, block_bytes), dtype=torch.uint8, device=device) for _ in range(2)]
-            recvs = [torch.zeros((world, block_bytes), dtype=torch.uint8, device=device) for _ in range(2)]
-            rb = Qr * k * 4
-            res_locals = [torch.zeros((2 * rb + Qr * 4,), dtype=torch.uint8, device=device) for _ in range(2)]
-            res_alls = [torch.zeros((world, 2 * rb + Qr * 4), dtype=torch.uint8, device=device)
-                        for _ in range(2)]
-            res_work = [None, None]   # result gathers in flight (waited for one step later)
-            mstatus = torch.zeros((1,), dtype=torch.int32, device=device)
-            pending = []
-            last_res = [0]
+    def device_status():
+        if sharded:
+            comm.last_status()
+        hip.check(L.scann_hip_index_last_device_status(index.h, ctypes.c_void_p(streams[0].cuda_stream)))
 
-            def at(t, off):
-                return ctypes.c_void_p(t.data_ptr() + off)
-
-            def finish_step():
-                work, b = pending.pop(0)
-                wait_for(work)
-                rv, res_local = recvs[b], res_locals[b]
-                wait_for(res_work[b])          # the gather that last read res_locals[b]
-                hip.check(L.scann_hip_txh_merge_device(hip.context(local_rank), world, Qr, m_local, m,
-                                                       k, block_bytes, at(rv, bsec[0]), at(rv, bsec[1]),
-                                                       at(rv, bsec[2]), at(rv, bsec[3]), at(res_local, 0),
-                                                       at(res_local, rb), at(res_local, 2 * rb),
-                                                       dev_ptr(mstatus), sptr))
-                res_work[b] = all_gather_start(res_alls[b], res_local)
-                last_res[0] = b
-        hip.check(L.scann_hip_index_reserve(index.h, Q, k, ctypes.byref(lopts)))
-
-        def step(i):
-            qd = qdev[i % nbatches]
-            if world == 1:
-                hip.check(L.scann_hip_search_batched_device(index.h, dev_ptr(qd), Q, dim, k,
-                                                            ctypes.byref(lopts), dev_ptr(out_idx),
-                                                            dev_ptr(out_dist), dev_ptr(out_cnt), sptr))
-            else:
-                # software pipeline over steps: local stage(i) -> exchange(i) in flight ->
-                # [merge(i-1) + result gather]; the last merge is drained by flush_steps()
-                b = i & 1
-                hip.check(L.scann_hip_txh_search_local_device(index.h, dev_ptr(qd), Q, dim, k,
-                                                              ctypes.byref(lopts), at(soa, ssec[0]),
-                                                              at(soa, ssec[1]), at(soa, ssec[2]),
-                                                              at(soa, ssec[3]), sptr))
-                hip.check(L.scann_hip_txh_pack_blocks_device(hip.context(local_rank), world, Q, m_local,
-                                                             at(soa, ssec[0]), at(soa, ssec[1]),
-                                                             at(soa, ssec[2]), at(soa, ssec[3]),
-                                                             dev_ptr(sends[b]), block_bytes, sptr))
-                work = all_to_all_start(recvs[b], sends[b])
-                if pending:
-                    finish_step()
-                pending.append((work, b))
-
-        def flush_steps():
-            while world > 1 and pending:
-                finish_step()
-            if world > 1:
-                for wk in res_work:
-                    wait_for(wk)
-
-        # ---------------- warmup, then EXACTLY K timed steps -------------------------------
-        lopts.bf_exact = 1 if (args.bf_exact or bf_exact_retry) else 0
-        for i in range(args.warmup):
-            step(i)
-        flush_steps()
-        torch.cuda.synchronize()
-        if device_status_aborted():
-            continue
-        index.enable_timing(True)
+    def barrier():
         if nproc > 1:
             dist.barrier()
+
+    # ---------------- warmup, then EXACTLY K timed steps ---------------------------------------------
+    bf_retry = False
+    while True:
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        try:
+            device_status()
+        except hip.ScannError as e:
+            if args.workload == "bf_dot" and e.code == 10 and not bf_retry:
+                log("a bf16-shortlist result could not be verified; repeating with the exact kernels")
+                bf_retry, opts.bf_exact = True, 1
+                continue
+            if sharded and e.code == 10 and args.m_local:
+                log("m_local=%d was too short; repeating with m_local = m" % args.m_local)
+                args.m_local = 0
+                continue
+            raise
+        index.enable_timing(True)
+        barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(i)
-        flush_steps()
         torch.cuda.synchronize()
-        if nproc > 1:
-            dist.barrier()
+        barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         kernel_ms, kernel_name = index.last_kernel_ms()
         index.enable_timing(False)
-        if device_status_aborted():
-            continue
-        if replica:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t[0].item())
-        if world > 1:
-            t = torch.tensor([elapsed, float(mstatus.item())], dtype=torch.float64,
-                             device=device if args.backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t[0].item())
-            if t[1].item() != 0 and m_local < m:
-                log("a shard's m_local=%d list was too short; repeating with m_local=m" % m_local)
-                m_local = m
-                continue
-            if t[1].item() != 0:
-                raise SystemExit("merge reported status %d" % int(t[1].item()))
+        device_status()
         break
+    if nproc > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0].item())
     qps = Q * args.steps * (nproc if replica else 1) / elapsed
-    if world > 1:   # result rows of the last step, gathered from the ranks that merged them
-        ra = res_alls[last_res[0]].cpu().numpy()
-        rb_ = (Q // world) * k * 4
-        out_idx = torch.from_numpy(np.concatenate([ra[g, :rb_].view(np.int32).reshape(-1, k)
-                                                   for g in range(world)]))
-        out_dist = torch.from_numpy(np.concatenate([ra[g, rb_:2 * rb_].view(np.float32).reshape(-1, k)
-                                                    for g in range(world)]))
+    last_out = outs[(args.steps - 1) & 1]
+    last_q = queries_all[((args.steps - 1) % nbatches) * Q:][:Q]
 
-    # ---------------- recall10@10 (bin/ann_benchmark.rs:427-471 semantics) ------------------
-    recall = None
-    checked = None
-    if not args.no_recall and world == 1 and rank == 0 and args.workload != "bf_dot":
-        ne = min(args.eval_queries, queries_all.shape[0])
-        qe = np.ascontiguousarray(queries_all[:ne])
-        gi, gd, gc = index.search_batched(qe, k, opts)
-        bf = hip.bf_create(txh_state["full_data"] if txh_state else data, n, dim, stride,
-                           hip.SQUARED_L2, device=local_rank)
-        ti, td, tc = bf.search_batched(qe, k)
-        hits = sum(len(set(gi[i].tolist()) & set(ti[i].tolist())) for i in range(ne))
-        recall = hits / float(ne * k)
-        bf.close()
-    if rank == 0 and world > 1 and args.workload == "ah":
-        # the merged rows of the last timed step, checked against the oracle on the FULL
-        # database (rank 0 regenerates it; checker only)
+    # ---------------- batch-size sweep (batches {1, 100, 1024}, >= 10 reps, median) -----------
+    sweep = None
+    if not args.no_batch_sweep and not replica:
+        sweep = {}
+        for bsz in (1, 100, Q):
+            ts = []
+            qd = qdev[0][:bsz].contiguous()
+            for r in range(3 + 12):
+                barrier()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                step(r, qd, bsz)
+                torch.cuda.synchronize()
+                if r >= 3:
+                    ts.append(time.perf_counter() - t1)
+            med = statistics.median(ts)
+            if nproc > 1:
+                t = torch.tensor([med], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                med = float(t[0].item())
+            sweep[str(bsz)] = {"ms_per_call": med * 1e3, "queries_per_s": bsz / med}
+        device_status()
+
+    # ---------------- recall10@10 (bin/ann_benchmark.rs:427-471 semantics) ------------------------------
+    recall = checked = None
+    ne = min(args.eval_queries, queries_all.shape[0])
+    qe = np.ascontiguousarray(queries_all[:ne])
+    if not args.no_recall and args.workload != "bf_dot" and not replica:
+        if sharded:
+            # ground truth = exact brute force over every rank's shard (library kernels), merged on rank 0
+            qt = torch.from_numpy(qe).to(device)
+            gi = torch.empty((ne, k), dtype=torch.int32, device=device)
+            gd = torch.empty((ne, k), dtype=torch.float32, device=device)
+            gc = torch.empty((ne,), dtype=torch.int32, device=device)
+            for a0 in range(0, ne, Q):
+                nb = min(Q, ne - a0)
+                hip.check(L.scann_hip_txh_search_sharded_device(
+                    index.h, comm.h, dev_ptr(qt[a0:a0 + nb]), nb, dim, k, ctypes.byref(opts), 0, dev_ptr(gi[a0:a0 + nb]),
+                    dev_ptr(gd[a0:a0 + nb]), dev_ptr(gc[a0:a0 + nb]), ctypes.c_void_p(streams[0].cuda_stream)))
+            torch.cuda.synchronize()
+            comm.last_status()
+            bf = hip.bf_create(st["data"], n, dim, stride, hip.SQUARED_L2, device=local_rank)
+            ti, td, _ = bf.search_batched(qe, k)
+            bf.close()
+            tid = st["ids"][ti.astype(np.int64)].astype(np.int64)         # global datapoint indices
+            parts_d = [torch.zeros((ne, k)) for _ in range(nproc)]
+            parts_i = [torch.zeros((ne, k), dtype=torch.int64) for _ in range(nproc)]
+            dist.all_gather(parts_d, torch.from_numpy(td.astype(np.float32)))
+            dist.all_gather(parts_i, torch.from_numpy(tid))
+            if rank == 0:
+                ad = torch.cat(parts_d, 1).numpy()
+                ai = torch.cat(parts_i, 1).numpy()
+                o2 = np.argsort(ad, axis=1, kind="stable")[:, :k]
+                truth = np.take_along_axis(ai, o2, 1)
+                got = gi.cpu().numpy().view(np.uint32).astype(np.int64)
+                recall = sum(len(set(got[i].tolist()) & set(truth[i].tolist())) for i in range(ne)) / float(ne * k)
+                # exact distances of the sharded rows must be ascending and bit-equal to the brute-force
+                # distances of the same points wherever the two lists share a point
+                gdn = gd.cpu().numpy()
+                tdn = np.take_along_axis(ad, o2, 1)
+                ok = bool(np.all(np.diff(gdn, axis=1) >= 0))
+                for i in range(ne):
+                    pos = {int(p): j for j, p in enumerate(truth[i])}
+                    for j in range(k):
+                        if int(got[i, j]) in pos:
+                            ok = ok and gdn[i, j].view(np.uint32) == tdn[i, pos[int(got[i, j])]].view(np.uint32)
+                checked = ok
+        elif rank == 0:
+            gi, gd, gc = index.search_batched(qe, k, opts)
+            bf = hip.bf_create(data, n, dim, stride, hip.SQUARED_L2, device=local_rank)
+            ti, td, tc = bf.search_batched(qe, k)
+            recall = sum(len(set(gi[i].tolist()) & set(ti[i].tolist())) for i in range(ne)) / float(ne * k)
+            bf.close()
+    if rank == 0 and nproc == 1:
+        # result rows of the LAST TIMED step checked against the oracle (checker only)
         from oracle import pyoracle as orc
-        full = np.zeros((n, stride), np.float32)
-        full[:, :dim] = synth.uniform_f32(n, dim, 42)
-        fcodes = trainer.encode(codebook, full[:, :dim])
-        last = np.ascontiguousarray(queries_all[((args.steps - 1) % nbatches) * Q:][:4])
-        gi = out_idx[:4].cpu().numpy().view(np.uint32)
-        gd = out_dist[:4].cpu().numpy()
+        gi = last_out[0].cpu().numpy().view(np.uint32)
+        gd = last_out[1].cpu().numpy()
         ok = True
         for i in range(4):
-            oi, od = orc.ah_search_with_reordering(codebook, fcodes, full, stride, last[i], k, m)
-            ok = ok and np.array_equal(gd[i].view(np.uint32), od.view(np.uint32)) \
-                and sorted(gi[i].tolist()) == sorted(oi.tolist())
-        checked = bool(ok)
-    if rank == 0 and world == 1:
-        # result rows of the timed path checked against the oracle (checker only)
-        from oracle import pyoracle as orc
-        nchk = 4
-        qe = np.ascontiguousarray(queries_all[:nchk])
-        gi, gd, gc = index.search_batched(qe, k, opts)
-        ok = True
-        for i in range(nchk):
             if args.workload == "bf_dot":
-                oi, od = orc.bf_search(data, n, dim, stride, orc.DOT_PRODUCT, qe[i], k)
+                oi, od = orc.bf_search(data, n, dim, stride, orc.DOT_PRODUCT, last_q[i], k)
             elif args.workload == "txh":
-                oi, od = orc.txh_search(txh_state["oracle_index"](orc, m, k), qe[i], k)
+                oi, od = orc.txh_search(st["oracle_index"](orc, m, k), last_q[i], k)
             else:
-                oi, od = orc.ah_search_with_reordering(codebook, codes, data, stride, qe[i], k, m)
+                oi, od = orc.ah_search_with_reordering(codebook, codes, data, stride, last_q[i], k, m)
             ok = ok and np.array_equal(gd[i].view(np.uint32), od.view(np.uint32)) \
                 and sorted(gi[i].tolist()) == sorted(oi.tolist())
         checked = bool(ok)
 
-    # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N = 1) -------
+    # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N = 1) -----------------
     cpu = None
     if rank == 0 and nproc == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle as orc
         threads = orc.max_threads()
-        nq0 = min(threads, queries_all.shape[0])
-        qs = np.ascontiguousarray(queries_all[:nq0])
 
-        def run_cpu(qb):
+        def run_cpu(qb, nthreads):
             t1 = time.perf_counter()
             if args.workload == "bf_dot":
-                orc.bf_search_batched(data, n, dim, stride, orc.DOT_PRODUCT, qb, k, threads)
+                orc.bf_search_batched(data, n, dim, stride, orc.DOT_PRODUCT, qb, k, nthreads)
             elif args.workload == "txh":
-                orc.txh_search_batched(txh_state["oracle_index"](orc, m, k), qb, k, threads)
+                orc.txh_search_batched(st["oracle_index"](orc, m, k), qb, k, nthreads)
             else:
-                orc.ah_search_batched(codebook, codes, data, stride, qb, k, m, True, threads)
+                orc.ah_search_batched(codebook, codes, data, stride, qb, k, m, True, nthreads)
             return time.perf_counter() - t1
 
-        t_probe = run_cpu(qs)
-        reps = int(max(1, min(64, args.cpu_baseline_seconds / max(t_probe, 1e-3))))
-        nq1 = min(queries_all.shape[0], nq0 * reps)
-        t_run = run_cpu(np.ascontiguousarray(queries_all[:nq1]))
+        # one thread, sequential queries (bin/ann_benchmark.rs:172-178): a probe query sizes the sample
+        t_one = run_cpu(np.ascontiguousarray(queries_all[:1]), 1)
+        n1 = int(max(1, min(32, 0.25 * args.cpu_baseline_seconds / max(t_one, 1e-4))))
+        t_seq = run_cpu(np.ascontiguousarray(queries_all[:n1]), 1)
+        # all host threads, one task per query (tree_x_hybrid/mod.rs:404-408, brute_force/searcher.rs:204-207)
+        nq1 = min(threads, queries_all.shape[0])
+        t_run = run_cpu(np.ascontiguousarray(queries_all[:nq1]), threads)
+        if 2.0 * t_run < 0.75 * args.cpu_baseline_seconds:   # cheap workload: a longer sample
+            reps = int(max(2, min(64, 0.75 * args.cpu_baseline_seconds / max(t_run, 1e-3))))
+            nq1 = min(queries_all.shape[0], nq1 * reps)
+            t_run = run_cpu(np.ascontiguousarray(queries_all[:nq1]), threads)
         cpu = {"value": nq1 / t_run, "unit": "queries/s", "cores": threads, "kind": "port",
-               "sample": "%d queries of the same workload (same index, k, pre_reorder_k), "
-                         "one OpenMP task per query, %.1f s" % (nq1, t_run)}
+               "cpu_model": cpu_model(),
+               "sample": "%d queries of the same workload (same index, k, pre_reorder_k), one OpenMP task per "
+                         "query on %d threads, %.1f s" % (nq1, threads, t_run),
+               "single_thread": {"value": n1 / t_seq, "unit": "queries/s", "cores": 1,
+                                 "sample": "%d sequential queries, %.1f s" % (n1, t_seq)},
+               "label": "CPU restatement of the reference path (oracle/; the Rust toolchain is unavailable)"}
+
+    # ---------------- the replica layout as a secondary number of the sharded run ---------------------
+    secondary = None
+    if sharded and not args.no_secondary:
+        secondary = replica_secondary(args, torch, dist, hip, synth, trainer, device, local_rank, rank, nproc)
 
     if rank == 0:
+        algo = None
         if args.workload == "bf_dot" and kernel_name == "bf_stream_kernel":
-            # a few queries: one coalesced pass over the database per 8 queries (SURVEY 8d: N*d*4 B)
             passes = (Q + 7) // 8
-            achieved = algo_bytes_per_query * passes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
+            by = n * dim * 4
+            achieved = by * passes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kernel_name,
-                    "kernel_ms": kernel_ms,
-                    "algorithmic": "N*d*4 = %d B per database pass x %d passes (8 queries each) per launch"
-                                   % (algo_bytes_per_query, passes)}
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kernel_name, "kernel_ms": kernel_ms,
+                    "algorithmic": "N*d*4 = %d B per database pass x %d passes (8 queries each) per launch" % (by, passes)}
         elif args.workload == "bf_dot":
             achieved = flops_per_query * Q / (kernel_ms * 1e-3) / 1e12 if kernel_ms else 0.0
             peak = BF16_MFMA_PEAK_TFLOPS if kernel_name == "bf_bf16_kernel" else F32_MFMA_PEAK_TFLOPS
-            roof = {"bound": "mfma", "achieved": achieved, "peak": peak,
-                    "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
-                    "kernel": kernel_name, "kernel_ms": kernel_ms,
+            roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                    "traffic": None, "kernel": kernel_name, "kernel_ms": kernel_ms,
                     "algorithmic": "2*N*d flop per query x %d queries per launch (%s)"
-                                   % (Q, "bf16 MFMA shortlist pass; the shortlisted rows are re-scored with "
-                                         "the reference's f32 arithmetic and the result is verified"
+                                   % (Q, "bf16 MFMA shortlist pass; the shortlisted rows are re-scored with the "
+                                         "reference's f32 arithmetic and the result is verified"
                                       if kernel_name == "bf_bf16_kernel" else "f32 MFMA, exact")}
+            tr = traffic_for(hip, args.workload, kernel_name)
+            if tr:
+                roof["traffic"], roof["traffic_source"] = tr["bytes"], tr["source"]
         else:
-            achieved = algo_bytes_per_query * Q / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
-            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kernel_name,
-                    "kernel_ms": kernel_ms,
-                    "algorithmic": ("%d B per query (scanned codes + LUTs of the selected leaves) x %d "
-                                    "queries per launch (rank 0)" if args.workload == "txh" else
-                                    "%d B per query (N_local*code_bytes + S*K*4 LUT + k*8 out) x %d "
-                                    "queries per launch (rank 0)") % (algo_bytes_per_query, Q)}
-        tr = os.path.join(ROOT, "profiles", "traffic.json")
-        # PMC-measured HBM bytes per launch (profiles/traffic.json, collected with rocprofv3 --pmc
-        # on this workload's default configuration only: single GPU, 1M x 128, batch 1024)
-        default_cfg = world == 1 and n == 1_000_000 and dim == 128 and Q == 1024 and \
-            (args.workload != "ah" or m == 5000) and args.workload != "txh"
-        if os.path.exists(tr) and default_cfg:
-            try:
-                roof["traffic"] = json.load(open(tr)).get(args.workload)
-            except Exception:
-                pass
+            scanned = float(n) if args.workload == "ah" else st["scanned_points"]
+            pairs = 1 if args.workload == "ah" else args.partitions_to_search
+            roof, algo = scan_roofline(hip, "txh_sharded" if sharded else args.workload, kernel_name, kernel_ms,
+                                       scanned, S, K, Q, k, pairs)
+        if roof["frac"] > 1.0:
+            roof["warning"] = "fraction above 1: the assumed bound is not the binding one"
         line = {
-            "metric": "QPS @ recall10@10 + achieved HBM GB/s, 1M x 128 f32",
-            "value": qps, "unit": "queries/s", "n_gpus": nproc, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak" if (replica or nproc == 1) else "strong",
+            "metric": METRIC, "value": qps, "unit": "queries/s", "n_gpus": nproc, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if (replica or nproc == 1) else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload_name, "n": n, "dim": dim, "k": k, "batch": Q,
-                       "global_batch": Q * (nproc if replica else 1),
+            "config": {"workload": workload_name, "n": n * (nproc if sharded else 1), "n_per_gpu": n, "dim": dim,
+                       "k": k, "batch": Q, "global_batch": Q * (nproc if replica else 1),
                        "pre_reorder_k": m if args.workload != "bf_dot" else None,
-                       "pre_reorder_k_per_rank": m_local if world > 1 else None,
+                       "pre_reorder_k_per_rank": (args.m_local or m) if sharded else None,
                        "distribution": args.dist if args.workload != "txh" else "clustered (1000 Gaussians)",
-                       "leaves": args.leaves if args.workload == "txh" else None,
+                       "leaves": (args.leaves * (nproc if sharded else 1)) if args.workload == "txh" else None,
                        "partitions_to_search": args.partitions_to_search if args.workload == "txh" else None,
-                       "recall10@10": recall,
-                       "oracle_check": checked,
-                       "parallelism": "1 process/GPU, leaf(row-range)-sharded x%d + RCCL all_to_all of candidates"
-                                      % world if world > 1 else
+                       "scanned_points_per_query": (st["scanned_points_global"] if sharded else
+                                                    st["scanned_points"]) if st else float(n),
+                       "recall10@10": recall, "oracle_check": checked,
+                       "parallelism": ("1 process/GPU; leaf-sharded index (one 12.5M x 96-shaped shard per GPU), "
+                                       "library entry point scann_hip_txh_search_sharded_device: local stage -> ONE "
+                                       "RCCL all-to-all (grouped ncclSend/ncclRecv) -> merge -> ncclAllGather; "
+                                       "work per step fixed and split over %d ranks" % nproc) if sharded else
                                       ("1 process/GPU, %d query-parallel replicas of the index (no data-path "
-                                       "collective); --multi-gpu shard = leaf-sharded index + RCCL all_to_all"
-                                       % nproc) if replica else "single GPU"},
-            "roofline": roof, "cpu_baseline": cpu,
+                                       "collective)" % nproc) if replica else "single GPU"},
+            "roofline": roof, "algorithmic_hbm": algo, "cpu_baseline": cpu, "batch_sweep": sweep,
+            "secondary": secondary, "lib_sha256": lib_sha256(hip),
         }
         print(json.dumps(line), flush=True)
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.close()
     if nproc > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def replica_secondary(args, torch, dist, hip, synth, trainer, device, local_rank, rank, nproc):
+    """N query-parallel copies of the N = 1 headline workload (AH LUT16 1M x 128): each rank searches its
+    own batch, no data-path collective; reported beside the sharded number."""
+    n, dim, S, K, k, Q, m = 1_000_000, 128, 32, 16, args.k, args.batch, 5000
+    stride = hip.compute_stride(dim)
+    rows = synth.uniform_f32(n, dim, 42)
+    sample = synth.uniform_rows((synth.splitmix64(0xC0DE, 0, 65536) % np.uint64(n)).astype(np.int64), dim, 42)
+    codebook = trainer.train_codebook(sample, S, K, iters=25, seed=42, sample=1 << 30)
+    codes = hip.encode(codebook, rows, stride=stride, device=local_rank)
+    index = hip.txh_create(data=rows, n_rows=n, dim=dim, stride=stride, centers=None, leaf_offsets=None,
+                           leaf_ids=None, codebook=codebook, codes=codes, use_residuals=False,
+                           partitions_to_search=1, pre_reorder_multiplier=float(m) / k, device=local_rank)
+    L = hip.load()
+    o = hip.default_opts()
+    o.pre_reorder_k, o.exact_reorder = m, 1
+    q = torch.from_numpy(np.roll(synth.uniform_f32(Q * 4, dim, 123), -rank * Q, axis=0)[:Q].copy()).to(device)
+    oi = torch.empty((Q, k), dtype=torch.int32, device=device)
+    od = torch.empty((Q, k), dtype=torch.float32, device=device)
+    oc = torch.empty((Q,), dtype=torch.int32, device=device)
+    sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    hip.check(L.scann_hip_index_reserve(index.h, Q, k, ctypes.byref(o)))
+    steps = 100
+
+    def run(cnt):
+        for _ in range(cnt):
+            hip.check(L.scann_hip_search_batched_device(index.h, dev_ptr(q), Q, dim, k, ctypes.byref(o), dev_ptr(oi),
+                                                        dev_ptr(od), dev_ptr(oc), sp))
+    run(5)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    hip.check(L.scann_hip_index_last_device_status(index.h, sp))
+    index.close()
+    return {"layout": "replica", "workload": "AsymmetricHasher LUT16 S=32 K=16 + exact re-rank, 1M x 128 per GPU",
+            "value": Q * steps * nproc / float(t[0].item()), "unit": "queries/s", "steps": steps,
+            "note": "N independent copies of the N = 1 headline workload, one batch per rank per step"}
 
 
 if __name__ == "__main__":

@@ -73,6 +73,11 @@ int scann_hip_init(int device_id, scann_hip_ctx **out_ctx);
 void scann_hip_shutdown(scann_hip_ctx *ctx);
 const char *scann_hip_last_error(void);
 const char *scann_hip_version(void);
+/* ABI guard for bindings written by hand (Rust #[repr(C)], ctypes): fills out[0..n) with
+ * { sizeof(scann_hip_txh_desc), offsetof(.., distance_measure), sizeof(scann_hip_search_opts),
+ *   offsetof(.., bf_exact), sizeof(scann_hip_file_info), offsetof(.., has_data) } and returns the
+ * number of values defined (6).  A binding asserts these against its own layout once at start-up. */
+uint32_t scann_hip_abi_layout(uint32_t *out, uint32_t n);
 /* data_format/dataset.rs:90-96 (DenseDataset::compute_stride for f32) */
 uint32_t scann_hip_compute_stride(uint32_t dim);
 
@@ -142,7 +147,13 @@ typedef struct {
 
 /* Replaces the search side of TreeXHybridSearcher::build / AsymmetricHasher::build.
  * Errors: n_local == 0 -> InvalidArgument (mod.rs:132-134, hasher.rs:110-112);
- * dim % S != 0 -> InvalidArgument (codebook.rs:154-159). */
+ * dim % S != 0 -> InvalidArgument (codebook.rs:154-159).
+ * The arrays' CONTENTS are validated too, so that no search can read out of bounds: leaf_offsets
+ * monotone and spanning [0, n_local]; every leaf_ids[i] < n_rows when data is indexed by datapoint
+ * (data != NULL, data_is_csr_order == 0); n_rows >= n_local when rows are read in CSR order
+ * (AsymmetricHasher mode with data); leaf_sizes_global[l] >= the local length of leaf l; every code
+ * < num_codes (packed or not).  Violations -> InvalidArgument here, DataLoss from
+ * scann_hip_index_load_file (a file whose sizes are consistent but whose contents are not). */
 int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *desc,
                          scann_hip_index **out_index);
 
@@ -257,6 +268,49 @@ int scann_hip_txh_pack_blocks_device(scann_hip_ctx *ctx, uint32_t world, uint32_
 int scann_hip_assign_leaves(const uint32_t *leaf_sizes, uint32_t num_partitions,
                             uint32_t world, uint32_t *out_owner);
 
+/* ---- multi-GPU exchange inside the library: RCCL over xGMI --------------------
+ * One process per GPU; every process holds a communicator.  A host that is not Python needs
+ * nothing else: rank 0 calls scann_hip_comm_unique_id and hands the 128 bytes to the other ranks
+ * over any side channel (a file, a socket, MPI, torch.distributed ...), every rank then calls
+ * scann_hip_comm_create (collective).  librccl.so.1 is loaded on first use; without it these entry
+ * points return Unavailable and everything else in the library keeps working.
+ *
+ * scann_hip_txh_search_sharded_device = the whole north-star step for a leaf-sharded index
+ * (every rank created its shard with leaf_sizes_global set and data_is_csr_order = 1):
+ *   local stage (this rank's best m_local candidates per query by merge key + their exact
+ *   distances) -> one block per destination rank -> ONE all-to-all as grouped ncclSend/ncclRecv
+ *   (xGMI is point-to-point: each peer receives only the candidates of the nq/world queries it
+ *   merges) -> merge of this rank's queries (stable sort by key, truncate m, stable sort by exact,
+ *   truncate k: tree_x_hybrid/mod.rs:283-293, 360-361) -> ncclAllGather of the k result rows.
+ * All ranks pass the same queries, nq, k and options; every rank receives all nq result rows
+ * ([nq][k] / [nq], device pointers).  m_local = 0 means m (exact by construction); a smaller
+ * m_local is verified by the merge (scann_hip_comm_last_status -> Aborted: repeat with 0).
+ * The exchange runs on the communicator's own stream; `hip_stream` carries the local stage and,
+ * at the end of the call, waits for the results.  Internal buffers are double-buffered and ordered
+ * with events, so a caller that alternates between two streams (and two sets of output buffers)
+ * overlaps one step's exchange with the next step's local stage. */
+typedef struct scann_hip_comm scann_hip_comm;
+#define SCANN_HIP_UNIQUE_ID_BYTES 128
+int scann_hip_comm_unique_id(void *out_id /* SCANN_HIP_UNIQUE_ID_BYTES */);
+int scann_hip_comm_create(scann_hip_ctx *ctx, const void *unique_id, int rank, int world,
+                          scann_hip_comm **out_comm);
+void scann_hip_comm_destroy(scann_hip_comm *comm);
+int scann_hip_txh_search_sharded_device(scann_hip_index *index, scann_hip_comm *comm,
+                                        const float *d_queries, uint32_t nq, uint32_t q_stride,
+                                        uint32_t k, const scann_hip_search_opts *opts,
+                                        uint32_t m_local, uint32_t *d_out_idx, float *d_out_dist,
+                                        uint32_t *d_out_count, void *hip_stream);
+/* Byte layout of one sharded step for nq queries (no GPU needed; for hosts that size their own
+ * buffers and for the protocol tests): out[0..12) = { qr = queries merged per rank (the batch is
+ * padded to qr * world), nq_pad, block_bytes (one destination block: [keys u64 | idx u32 | exact f32
+ * | count u32] of qr queries x m_local), offset of idx, of exact, of count inside a block, bytes of
+ * the local-stage arrays [nq][m_local] and the offsets of idx, exact, count inside them, bytes of
+ * the result rows ([nq_pad][k] idx | dist | [nq_pad] count) and the offset of dist }. */
+int scann_hip_comm_layout(uint32_t nq, uint32_t world, uint32_t m_local, uint32_t k, uint64_t *out12);
+/* Status of the merges since the last call of this function (0 = ok, Aborted = an m_local < m list
+ * was too short); synchronises the communicator's stream and clears the word. */
+int scann_hip_comm_last_status(scann_hip_comm *comm);
+
 /* ---- index files ---------------------------------------------------------
  * The reference keeps indexes in memory only (no save/load: SURVEY section 5); its arrays are the
  * DenseDataset buffer (data_format/dataset.rs:46-61), TreePartitioner.centers and the partition
@@ -313,6 +367,12 @@ int scann_hip_adc_distances(scann_hip_index *index, const float *luts, uint32_t 
 int scann_hip_lut16_distances_batch(scann_hip_ctx *ctx, const uint8_t *packed_codes,
                                     const uint8_t *lut8, uint32_t num_subspaces, uint64_t n,
                                     float bias, float multiplier, float *out);
+/* Lut16SimdTables::from_float_tables (hashes/lut16_simd.rs:39-90): global min / max over the
+ * S x 16 f32 tables, scale = 255 / range, lut8 = round((v - min) * scale) as u8 (round half away
+ * from zero, saturating), bias = min, multiplier = 1 / scale; range < 1e-10 -> scale = multiplier
+ * = 1.  S == 0 -> bias 0, multiplier 1, nothing written.  Runs on the device (one workgroup). */
+int scann_hip_lut16_quantize(scann_hip_ctx *ctx, const float *tables, uint32_t num_subspaces,
+                             uint8_t *out_lut8, float *out_bias, float *out_multiplier);
 /* Codebook::encode over rows (hashes/codebook.rs:82-95, 205-215); optional residual
  * against centers[leaf_of_row[i]] (tree_x_hybrid/mod.rs:177-189).  out_codes [n][S]. */
 int scann_hip_encode(scann_hip_ctx *ctx, const float *codebook, uint32_t num_subspaces,
@@ -329,20 +389,30 @@ int scann_hip_bf_distances(scann_hip_index *index, const float *queries, uint32_
  * K-means over the rows of a brute-force index, or over the column window [col_offset,
  * col_offset + sub_dim) of them (per-subspace codebook training, src/hashes/codebook.rs:177-199).
  *
- * scann_hip_kmeans_init_pp: KMeans::kmeans_plusplus_init (src/trees/kmeans.rs:295-349) with a
- *   documented splitmix64 stream (the reference's rand::StdRng is not reproducible);
- *   centers_out [k][sub_dim].
+ * simd_threshold = KMeansConfig.simd_threshold (src/trees/kmeans.rs:43-46, default 128): distances
+ *   over sub_dim >= simd_threshold values use the AVX2 summation order of squared_l2_f32 (8 FMA lane
+ *   chains + fixed horizontal-sum tree + unfused scalar tail, simd/x86.rs:139-165), shorter ones the
+ *   sequential scalar sum (:419-431).  0 = always the AVX2 order, UINT32_MAX = always sequential.
+ * scann_hip_kmeans_init_pp: KMeans::kmeans_plusplus_init (src/trees/kmeans.rs:295-349); centers_out
+ *   [k][sub_dim].  DEVIATION (seeding parity is unpinned by construction): the reference draws from
+ *   rand::StdRng, which is not reproducible here -- a documented splitmix64 stream is
+ *   used instead -- and its D^2 sampling sums min_d sequentially in f32 (:318-331), an n-long
+ *   dependent chain per seed; here the total and the cumulative search run in f64 with a fixed
+ *   reduction tree.  The minimum distances themselves follow the reference's arithmetic.
  * scann_hip_kmeans_lloyd: the Lloyd loop of KMeans::fit_single (:210-263) from the caller's initial
- *   centres (updated in place): assign_clusters (strict '<', lowest index on ties; sequential-scalar
- *   SquaredL2), inertia = f64 sum of the minimum distances, stop when |prev - inertia| / (prev + 1e-10)
- *   < convergence_threshold, update_centers (f64 sums in ascending datapoint order, mean cast to f32,
- *   empty cluster c takes row c % n), then the final assignment.  Outputs may be NULL. */
+ *   centres (updated in place): assign_clusters (strict '<', lowest index on ties), inertia = the f64
+ *   sum of the minimum distances in datapoint order (:376; computed by a reduction tree when every
+ *   partial sum is exactly representable -- then all orders agree -- and by the sequential chain
+ *   otherwise), stop when |prev - inertia| / (prev + 1e-10) < convergence_threshold, update_centers
+ *   (f64 sums in ascending datapoint order, mean cast to f32, empty cluster c takes row c % n), then
+ *   the final assignment.  Bit-identical to the reference's loop from the same initial centres.
+ *   Outputs may be NULL. */
 int scann_hip_kmeans_init_pp(scann_hip_index *bf_index, uint32_t col_offset, uint32_t sub_dim, uint32_t k,
-                             uint64_t seed, float *centers_out);
+                             uint64_t seed, uint32_t simd_threshold, float *centers_out);
 int scann_hip_kmeans_lloyd(scann_hip_index *bf_index, uint32_t col_offset, uint32_t sub_dim, float *centers,
                            uint32_t k, uint32_t max_iterations, double convergence_threshold,
-                           uint32_t *out_assign, uint32_t *out_sizes, double *out_inertia,
-                           uint32_t *out_iterations, int *out_converged);
+                           uint32_t simd_threshold, uint32_t *out_assign, uint32_t *out_sizes,
+                           double *out_inertia, uint32_t *out_iterations, int *out_converged);
 
 /* BruteForceSearcher::search_radius (src/brute_force/searcher.rs:142-167) for one query: every
  * datapoint with distance <= radius, stable-sorted by distance.  Writes at most `capacity` rows;

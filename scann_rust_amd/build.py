@@ -1,35 +1,70 @@
-"""Builds libscann_hip.so (gfx950) in-tree with hipcc.  No GPU needed to build."""
+"""Builds libscann_hip.so (gfx950) in-tree with hipcc.  No GPU needed to build.
+
+Every source is compiled to its own object (in parallel, rebuilt only when it or a header
+changed) and the objects are linked into the shared library, so editing one kernel file costs one
+compile."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libscann_hip.so")
-SOURCES = ["api.hip", "txh.hip", "bf.hip", "index_file.hip"]
-HEADERS = ["common.h", "txh.h", "bf.h", os.path.join("..", "..", "include", "scann_hip.h")]
+SOURCES = ["api.hip", "txh.hip", "bf.hip", "index_file.hip", "comm.hip", "scan_mfma.hip"]
+HEADERS = ["common.h", "txh.h", "bf.h", "comm.h", os.path.join("..", "..", "include", "scann_hip.h")]
 # -ffp-contract=off: the reference never contracts a*b+c (Rust); FMA is used only via
 # explicit fmaf()/MFMA where the reference uses _mm256_fmadd_ps.
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wall", "-Wno-unused-function"]
+CFLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-Wall",
+          "-Wno-unused-function"]
+LDFLAGS = ["-shared", "-fPIC", "--offload-arch=gfx950", "-ldl"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    for f in SOURCES + HEADERS:
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _newest_header():
+    t = 0.0
+    for f in HEADERS:
         p = os.path.join(CSRC, f)
-        if os.path.exists(p) and os.path.getmtime(p) > t:
-            return True
-    return False
+        if os.path.exists(p):
+            t = max(t, os.path.getmtime(p))
+    return max(t, os.path.getmtime(os.path.abspath(__file__)))
+
+
+def _obj(src):
+    return os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+
+
+def _stale_objects(force, extra_flags):
+    th = _newest_header()
+    out = []
+    for s in _sources():
+        o, p = _obj(s), os.path.join(CSRC, s)
+        if force or extra_flags or not os.path.exists(o) or os.path.getmtime(o) < max(th, os.path.getmtime(p)):
+            out.append(s)
+    return out
 
 
 def build(force=False, verbose=False, extra_flags=()):
-    if not force and not _stale():
-        return LIB
+    os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + list(extra_flags) + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    todo = _stale_objects(force, extra_flags)
+    objs = [_obj(s) for s in _sources()]
+    if not todo and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(o) for o in objs):
+        return LIB
+
+    def compile_one(s):
+        cmd = [hipcc] + CFLAGS + list(extra_flags) + ["-c", "-o", _obj(s), os.path.join(CSRC, s)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=CSRC)
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = [hipcc] + LDFLAGS + ["-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)

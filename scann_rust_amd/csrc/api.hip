@@ -3,6 +3,7 @@
 // search entry point runs the HIP kernels or fails.
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -11,6 +12,7 @@
 #include <vector>
 
 #include "bf.h"
+#include "comm.h"
 #include "common.h"
 #include "txh.h"
 
@@ -96,10 +98,20 @@ static int set_device(const scann_hip_ctx *ctx) {
     return SCANN_HIP_OK;
 }
 
+int scann::ctx_device(const scann_hip_ctx *ctx) { return ctx ? ctx->device : 0; }
+
 extern "C" {
 
 const char *scann_hip_last_error(void) { return g_last_error.c_str(); }
 const char *scann_hip_version(void) { return "scann_hip 0.1.0 (gfx950)"; }
+
+uint32_t scann_hip_abi_layout(uint32_t *out, uint32_t n) {
+    const uint32_t v[6] = {(uint32_t)sizeof(scann_hip_txh_desc), (uint32_t)offsetof(scann_hip_txh_desc, distance_measure),
+                           (uint32_t)sizeof(scann_hip_search_opts), (uint32_t)offsetof(scann_hip_search_opts, bf_exact),
+                           (uint32_t)sizeof(scann_hip_file_info), (uint32_t)offsetof(scann_hip_file_info, has_data)};
+    for (uint32_t i = 0; i < 6 && i < n && out; ++i) out[i] = v[i];
+    return 6;
+}
 
 uint32_t scann_hip_compute_stride(uint32_t dim) {
     const uint32_t per_line = 64 / sizeof(float);  // data_format/dataset.rs:90-96
@@ -249,7 +261,12 @@ int scann_hip_bf_create(scann_hip_ctx *ctx, const float *data, uint64_t n, uint3
 // =====================================================================================
 // Tree-X-Hybrid / AsymmetricHasher index
 // =====================================================================================
-int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_hip_index **out) {
+}  // extern "C"
+
+// content_status: what inconsistent array CONTENTS are reported as (InvalidArgument for caller-built
+// descriptors, DataLoss for index files, whose section sizes were already checked)
+int scann::txh_create_checked(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_hip_index **out,
+                              int content_status) {
     if (!ctx || !d || !out) return fail(SCANN_HIP_INVALID_ARGUMENT, "null ctx/desc/out_index");
     const bool ah = d->num_partitions == 0;
     if (d->n_local == 0)  // tree_x_hybrid/mod.rs:132-134, hashes/hasher.rs:110-112
@@ -287,14 +304,26 @@ int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_
         if (d->num_partitions > kMaxLeavesSelect)
             return fail(SCANN_HIP_UNIMPLEMENTED, "num_partitions > 16384");
         if (d->leaf_offsets[0] != 0 || d->leaf_offsets[d->num_partitions] != d->n_local)
-            return fail(SCANN_HIP_INVALID_ARGUMENT, "leaf_offsets must span [0, n_local]");
-        for (uint32_t l = 0; l < d->num_partitions; ++l)
+            return fail(content_status, "leaf_offsets must span [0, n_local]");
+        for (uint32_t l = 0; l < d->num_partitions; ++l) {
             if (d->leaf_offsets[l + 1] < d->leaf_offsets[l])
-                return fail(SCANN_HIP_INVALID_ARGUMENT, "leaf_offsets not monotone");
+                return fail(content_status, "leaf_offsets not monotone");
+            // merge keys and their decoding assume a leaf's local rows are a prefix of the global leaf
+            if (d->leaf_sizes_global && d->leaf_sizes_global[l] < d->leaf_offsets[l + 1] - d->leaf_offsets[l])
+                return fail(content_status, "leaf_sizes_global smaller than the local leaf");
+        }
+        // the re-rank and the exact leaf scan read data + leaf_ids[row] * stride
+        if (d->data && !d->data_is_csr_order)
+            for (uint64_t i = 0; i < d->n_local; ++i)
+                if (d->leaf_ids[i] >= d->n_rows)
+                    return fail(content_status, "leaf_ids entry " + std::to_string(i) + " >= n_rows");
     }
     if (d->data && d->stride < d->dim) return fail(SCANN_HIP_INVALID_ARGUMENT, "stride < dim");
     if (d->data && d->data_is_csr_order && d->n_rows != d->n_local)
         return fail(SCANN_HIP_INVALID_ARGUMENT, "CSR-ordered data must have n_local rows");
+    // AsymmetricHasher mode reads row i of data for CSR row i
+    if (d->data && ah && d->n_rows < d->n_local)
+        return fail(content_status, "data has fewer rows than the index has points");
     SCANN_TRY(set_device(ctx));
 
     auto *ix = new scann_hip_index();
@@ -334,6 +363,12 @@ int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_
     if (exact) {
         // no codes
     } else if (d->codes_packed4) {
+        if (K < 16) {   // every nibble must address a trained centre (K == 16: all values are valid)
+            const size_t nbytes = (size_t)n * bpp;
+            for (size_t i = 0; i < nbytes; ++i)
+                if ((d->codes[i] & 15u) >= K || (d->codes[i] >> 4) >= K)
+                    return bail(fail(content_status, "code value >= num_codes"));
+        }
         if ((reinterpret_cast<uintptr_t>(d->codes) & 3u) == 0) {
             code_words = reinterpret_cast<const uint32_t *>(d->codes);
         } else {
@@ -348,7 +383,7 @@ int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_
             uint32_t *w = words.data() + i * nw;
             for (uint32_t sidx = 0; sidx < S; ++sidx) {
                 if (c[sidx] >= K) {
-                    return bail(fail(SCANN_HIP_INVALID_ARGUMENT, "code value >= num_codes"));
+                    return bail(fail(content_status, "code value >= num_codes"));
                 }
                 if (bits == 4) w[sidx >> 3] |= (uint32_t)(c[sidx] & 0x0F) << (4 * (sidx & 7u));
                 else w[sidx >> 2] |= (uint32_t)c[sidx] << (8 * (sidx & 3u));
@@ -400,6 +435,12 @@ int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_
     ix->multiplier = d->pre_reorder_multiplier;
     *out = ix;
     return SCANN_HIP_OK;
+}
+
+extern "C" {
+
+int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_hip_index **out) {
+    return scann::txh_create_checked(ctx, d, out, SCANN_HIP_INVALID_ARGUMENT);
 }
 
 // ---- per-call parameter resolution --------------------------------------------------
@@ -466,12 +507,30 @@ static int resolve_params(const scann_hip_index *ix, uint32_t k, const scann_hip
     return SCANN_HIP_OK;
 }
 
+}  // extern "C"
+
+int scann::txh_resolve_m(scann_hip_index *ix, uint32_t k, const scann_hip_search_opts *opts, uint32_t *out_m) {
+    if (!ix || ix->kind != KIND_TXH) return fail(SCANN_HIP_INVALID_ARGUMENT, "not a tree index");
+    scann_hip_search_opts o;
+    if (opts) o = *opts; else scann_hip_search_opts_default(&o);
+    o.exact_reorder = 1;
+    TxhCallParams p;
+    SCANN_TRY(resolve_params(ix, k, &o, false, &p));
+    *out_m = p.m;
+    return SCANN_HIP_OK;
+}
+
+extern "C" {
+
 static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t nq, const TxhCallParams &p,
                                 bool own_queries, uint32_t q_stride, bool own_outputs,
                                 TxhWork *w) {
     const TxhIndexDev &t = ix->tx;
     const uint32_t L = t.L, P = p.P, m = std::max(1u, p.m), k = std::max(1u, p.k);
-    const uint32_t max_slots = nq * P + 3 * L + 4;
+    const uint64_t max_slots64 = (uint64_t)nq * P + 3ull * L + 4;
+    if (max_slots64 > 0xFFFFFFF0ull)
+        return fail(SCANN_HIP_RESOURCE_EXHAUSTED, "batch x partitions_to_search exceeds the pair table (2^32 slots)");
+    const uint32_t max_slots = (uint32_t)max_slots64;
     const uint32_t max_quads = max_slots / 4 + 1;
     if (own_queries) SCANN_TRY(s.queries.ensure((size_t)nq * q_stride * 4));
     if (!t.ah_mode) SCANN_TRY(s.cdist.ensure((size_t)nq * L * 4));
@@ -1019,6 +1078,30 @@ int scann_hip_lut16_distances_batch(scann_hip_ctx *ctx, const uint8_t *packed, c
     return SCANN_HIP_OK;
 }
 
+int scann_hip_lut16_quantize(scann_hip_ctx *ctx, const float *tables, uint32_t S, uint8_t *out_lut8,
+                             float *out_bias, float *out_multiplier) {
+    if (!ctx) return fail(SCANN_HIP_INVALID_ARGUMENT, "ctx is null");
+    if (!out_bias || !out_multiplier) return fail(SCANN_HIP_INVALID_ARGUMENT, "null bias/multiplier");
+    if (S == 0) {   // lut16_simd.rs:42-49
+        *out_bias = 0.0f;
+        *out_multiplier = 1.0f;
+        return SCANN_HIP_OK;
+    }
+    if (!tables || !out_lut8) return fail(SCANN_HIP_INVALID_ARGUMENT, "null tables/output");
+    SCANN_TRY(set_device(ctx));
+    DevBuf dt, dq, dp;
+    SCANN_TRY(upload(dt, tables, (size_t)S * 16 * 4));
+    SCANN_TRY(dq.ensure((size_t)S * 16));
+    SCANN_TRY(dp.ensure(8));
+    SCANN_TRY(launch_lut16_quantize(dt.as<float>(), S, dq.as<uint8_t>(), dp.as<float>(), nullptr));
+    float bm[2];
+    SCANN_HIP_CHECK(hipMemcpy(out_lut8, dq.p, (size_t)S * 16, hipMemcpyDeviceToHost));
+    SCANN_HIP_CHECK(hipMemcpy(bm, dp.p, 8, hipMemcpyDeviceToHost));
+    *out_bias = bm[0];
+    *out_multiplier = bm[1];
+    return SCANN_HIP_OK;
+}
+
 int scann_hip_encode(scann_hip_ctx *ctx, const float *codebook, uint32_t S, uint32_t K, uint32_t dsub,
                      const float *rows, uint64_t n, uint32_t stride, const float *centers,
                      const uint32_t *leaf_of_row, uint8_t *out_codes) {
@@ -1092,23 +1175,23 @@ static int kmeans_args(scann_hip_index *ix, uint32_t col_offset, uint32_t sub_di
 }
 
 int scann_hip_kmeans_init_pp(scann_hip_index *ix, uint32_t col_offset, uint32_t sub_dim, uint32_t k,
-                             uint64_t seed, float *centers_out) {
+                             uint64_t seed, uint32_t simd_threshold, float *centers_out) {
     SCANN_TRY(kmeans_args(ix, col_offset, sub_dim, k, centers_out));
     std::lock_guard<std::mutex> lock(ix->mu);
     SCANN_TRY(set_device(ix->ctx));
-    return bf_kmeans_init_pp_host(ix->bf, col_offset, sub_dim, k, seed, centers_out, ix->stream);
+    return bf_kmeans_init_pp_host(ix->bf, col_offset, sub_dim, k, seed, simd_threshold, centers_out, ix->stream);
 }
 
 int scann_hip_kmeans_lloyd(scann_hip_index *ix, uint32_t col_offset, uint32_t sub_dim, float *centers,
                            uint32_t k, uint32_t max_iterations, double convergence_threshold,
-                           uint32_t *out_assign, uint32_t *out_sizes, double *out_inertia,
-                           uint32_t *out_iterations, int *out_converged) {
+                           uint32_t simd_threshold, uint32_t *out_assign, uint32_t *out_sizes,
+                           double *out_inertia, uint32_t *out_iterations, int *out_converged) {
     SCANN_TRY(kmeans_args(ix, col_offset, sub_dim, k, centers));
     std::lock_guard<std::mutex> lock(ix->mu);
     SCANN_TRY(set_device(ix->ctx));
     return bf_kmeans_lloyd_host(ix->bf, col_offset, sub_dim, centers, k, max_iterations,
-                                convergence_threshold, out_assign, out_sizes, out_inertia, out_iterations,
-                                out_converged, ix->stream);
+                                convergence_threshold, simd_threshold, out_assign, out_sizes, out_inertia,
+                                out_iterations, out_converged, ix->stream);
 }
 
 }  // extern "C"

@@ -67,10 +67,11 @@ int bf_assign_nearest_host(const BfIndexDev &ix, const float *centers, uint32_t 
 // sub_dim)): k-means++ seeding (trees/kmeans.rs:295-349, splitmix64 stream) and the Lloyd loop of
 // KMeans::fit_single (:210-263) from caller-supplied centres [k][sub_dim] (updated in place).
 int bf_kmeans_init_pp_host(const BfIndexDev &ix, uint32_t col_offset, uint32_t sub_dim, uint32_t k,
-                           uint64_t seed, float *centers_out, hipStream_t stream);
+                           uint64_t seed, uint32_t simd_threshold, float *centers_out, hipStream_t stream);
 int bf_kmeans_lloyd_host(const BfIndexDev &ix, uint32_t col_offset, uint32_t sub_dim, float *centers,
                          uint32_t k, uint32_t max_iterations, double convergence_threshold,
-                         uint32_t *out_assign, uint32_t *out_sizes, double *out_inertia,
-                         uint32_t *out_iterations, int *out_converged, hipStream_t stream);
+                         uint32_t simd_threshold, uint32_t *out_assign, uint32_t *out_sizes,
+                         double *out_inertia, uint32_t *out_iterations, int *out_converged,
+                         hipStream_t stream);
 
 }  // namespace scann

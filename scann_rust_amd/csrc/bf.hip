@@ -602,6 +602,81 @@ __global__ __launch_bounds__(256) void assign_nearest_kernel(BfIndexDev ix, cons
     }
 }
 
+// The same assignment with squared_l2_avx2's summation order (simd/x86.rs:139-165), taken by
+// KMeans::squared_distance_with_threshold when dim >= simd_threshold (trees/kmeans.rs:419-431):
+// lane chain j accumulates fma(d, d, acc) over the dims = j (mod 8), the chains are combined by the
+// fixed tree ((s0+s4 + s1+s5) + (s2+s6 + s3+s7)) of horizontal_sum_f32_avx2 (x86.rs:31-44), the
+// dims past the last whole chunk of 8 are added unfused.  One thread per row, kAvxTC centres per
+// LDS tile, the 8 chains of a centre as 4 packed-f32 pairs (v_pk_fma_f32 keeps both halves exact).
+constexpr int kAvxTC = 8;
+
+__global__ __launch_bounds__(256) void assign_nearest_avx_kernel(BfIndexDev ix, const float *__restrict__ centers,
+                                                                 uint32_t k, uint32_t *__restrict__ out_idx,
+                                                                 float *__restrict__ out_dist) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) float cs[];   // [kAvxTC][dimp]
+    const uint32_t dim = ix.dim, dimp = (dim + 3u) & ~3u, chunks = dim >> 3;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = i < ix.n;
+    const float *row = ix.rows + (act ? i : 0) * ix.stride;
+    const bool vec = ((ix.stride & 3u) == 0) && ((reinterpret_cast<uintptr_t>(ix.rows) & 15u) == 0);
+    float best = __builtin_inff();
+    uint32_t bi = 0;
+    for (uint32_t c0 = 0; c0 < k; c0 += kAvxTC) {
+        for (uint32_t e = threadIdx.x; e < kAvxTC * dimp; e += blockDim.x) {
+            const uint32_t c = e / dimp, j = e - c * dimp;
+            cs[e] = (c0 + c < k && j < dim) ? centers[(size_t)(c0 + c) * dim + j] : 0.0f;
+        }
+        __syncthreads();
+        f32x2 acc[kAvxTC][4];
+#pragma unroll
+        for (int c = 0; c < kAvxTC; ++c)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[c][u] = f32x2{0.0f, 0.0f};
+        for (uint32_t ch = 0; ch < chunks; ++ch) {
+            float4 xa, xb;
+            if (vec) {
+                xa = *reinterpret_cast<const float4 *>(row + 8 * ch);
+                xb = *reinterpret_cast<const float4 *>(row + 8 * ch + 4);
+            } else {
+                xa = make_float4(row[8 * ch], row[8 * ch + 1], row[8 * ch + 2], row[8 * ch + 3]);
+                xb = make_float4(row[8 * ch + 4], row[8 * ch + 5], row[8 * ch + 6], row[8 * ch + 7]);
+            }
+            const f32x2 x[4] = {f32x2{xa.x, xa.y}, f32x2{xa.z, xa.w}, f32x2{xb.x, xb.y}, f32x2{xb.z, xb.w}};
+#pragma unroll
+            for (int c = 0; c < kAvxTC; ++c) {
+                const float4 ca = *reinterpret_cast<const float4 *>(cs + c * dimp + 8 * ch);
+                const float4 cb = *reinterpret_cast<const float4 *>(cs + c * dimp + 8 * ch + 4);
+                const f32x2 cv[4] = {f32x2{ca.x, ca.y}, f32x2{ca.z, ca.w}, f32x2{cb.x, cb.y}, f32x2{cb.z, cb.w}};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x2 d = x[u] - cv[u];
+                    acc[c][u] = __builtin_elementwise_fma(d, d, acc[c][u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kAvxTC; ++c) {
+            // chains 0..7 = acc[0].x acc[0].y acc[1].x acc[1].y acc[2].x ...: (v0+v4, v1+v5), (v2+v6, v3+v7)
+            const f32x2 s01 = acc[c][0] + acc[c][2], s23 = acc[c][1] + acc[c][3];
+            float r = (s01.x + s01.y) + (s23.x + s23.y);
+            for (uint32_t j = chunks * 8; j < dim; ++j) {   // scalar tail, not fused
+                const float d = row[j] - cs[c * dimp + j];
+                r = r + d * d;
+            }
+            if (c0 + c < k && r < best) {
+                best = r;
+                bi = c0 + c;
+            }
+        }
+        __syncthreads();
+    }
+    if (act) {
+        out_idx[i] = bi;
+        if (out_dist) out_dist[i] = best;
+    }
+}
+
 // =====================================================================================
 // bf16 shortlist path (exact results, verified).  MI355X runs bf16 MFMA at 16x the f32 MFMA
 // rate, but bf16 scores cannot meet the parity bar.  They CAN order the database
@@ -1844,24 +1919,61 @@ int bf_assign_nearest_host(const BfIndexDev &ix, const float *centers, uint32_t 
 // [col_offset, col_offset + sub_dim) of them (per-subspace codebook training,
 // hashes/codebook.rs:177-199):
 //   assign_clusters :352-379   nearest centre, strict '<' (lowest index on ties); sequential
-//                              scalar SquaredL2 (the reference switches to its AVX2 order at
-//                              dim >= simd_threshold = 128; not reproduced, training parity
-//                              is unpinned anyway: the reference seeds from an unpinned RNG)
-//   inertia                    f64 sum of the minimum distances (fixed reduction tree)
+//                              scalar SquaredL2 below simd_threshold dims, squared_l2_avx2's order
+//                              from there on (:419-431): assign_nearest_kernel / _avx_kernel
+//   inertia :376               f64 sum of the minimum distances in datapoint order: a reduction
+//                              tree when provably exact (then every order agrees), else the chain
 //   update_centers :382-414    f64 sums in ascending datapoint order per (cluster, dim), mean
 //                              cast to f32; empty cluster c takes row c % n
 // =====================================================================================
 __global__ __launch_bounds__(256) void km_sum_f64_kernel(const float *__restrict__ v, uint64_t n,
-                                                         double *__restrict__ partials) {
+                                                         double *__restrict__ partials,
+                                                         uint32_t *__restrict__ min_pos_bits) {
     __shared__ double s[256];
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    s[threadIdx.x] = i < n ? (double)v[i] : 0.0;
+    const float x = i < n ? v[i] : 0.0f;
+    s[threadIdx.x] = (double)x;
+    // smallest positive term (bit pattern order == value order for positive floats)
+    if (min_pos_bits) {   // kernel-uniform
+        uint32_t b = x > 0.0f ? __float_as_uint(x) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) b = min(b, (uint32_t)__shfl_xor((int)b, o));
+        if ((threadIdx.x & 63u) == 0 && b != 0xFFFFFFFFu) atomicMin(min_pos_bits, b);
+    }
     __syncthreads();
     for (uint32_t o = 128; o > 0; o >>= 1) {
         if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
         __syncthreads();
     }
     if (threadIdx.x == 0) partials[blockIdx.x] = s[0];
+}
+
+// inertia as the reference computes it (kmeans.rs:376): f64 += (f64)min_dist in datapoint order, one
+// dependent chain.  Only used when the tree sum above is not provably exact.  One block: waves 1-3
+// stage the next 4096 values in LDS while lane 0 adds the current ones.
+__global__ __launch_bounds__(256) void km_sum_f64_sequential_kernel(const float *__restrict__ v, uint64_t n,
+                                                                    double *__restrict__ total_out) {
+    constexpr uint32_t T = 4096;
+    __shared__ float s_x[2][T];
+    const uint32_t tid = threadIdx.x;
+    auto stage = [&](uint64_t i0, uint32_t buf, uint32_t t0, uint32_t nt) {
+        const uint32_t cnt = (uint32_t)min((uint64_t)T, n - i0);
+        for (uint32_t f = t0; f < cnt; f += nt) s_x[buf][f] = v[i0 + f];
+    };
+    if (n) stage(0, 0, tid, 256);
+    __syncthreads();
+    double sum = 0.0;
+    uint32_t buf = 0;
+    for (uint64_t i0 = 0; i0 < n; i0 += T, buf ^= 1u) {
+        const uint32_t cnt = (uint32_t)min((uint64_t)T, n - i0);
+        if (tid >= 64) {
+            if (i0 + T < n) stage(i0 + T, buf ^ 1u, tid - 64, 192);
+        } else if (tid == 0) {
+            for (uint32_t f = 0; f < cnt; ++f) sum += (double)s_x[buf][f];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *total_out = sum;
 }
 
 // partials -> total (fixed order: per-thread chunks, then the 256 chunk sums in order); optional
@@ -1931,15 +2043,26 @@ __global__ __launch_bounds__(256) void km_total_pick_kernel(const double *__rest
     }
 }
 
-// min_d[i] = min(min_d[i], ||row_i - row_sel||^2)  (kmeans.rs:303-345); first = overwrite
+// min_d[i] = min(min_d[i], ||row_i - row_sel||^2)  (kmeans.rs:303-345); first = overwrite.
+// avx: squared_l2_avx2's order (dim >= simd_threshold), else the sequential scalar sum.
 __global__ __launch_bounds__(256) void km_mind_update_kernel(BfIndexDev ix, const uint32_t *__restrict__ sel,
-                                                             int first, float *__restrict__ min_d) {
+                                                             int first, int avx, float *__restrict__ min_d) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= ix.n) return;
     const float *row = ix.rows + i * ix.stride, *c = ix.rows + (uint64_t)(*sel) * ix.stride;
     float d = 0.0f;
     uint32_t j = 0;
-    if (((ix.stride & 3u) == 0) && ((reinterpret_cast<uintptr_t>(ix.rows) & 15u) == 0)) {
+    if (avx) {
+        float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        for (; j + 8 <= ix.dim; j += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float t = row[j + u] - c[j + u];
+                acc[u] = fmaf(t, t, acc[u]);
+            }
+        }
+        d = ((acc[0] + acc[4]) + (acc[1] + acc[5])) + ((acc[2] + acc[6]) + (acc[3] + acc[7]));
+    } else if (((ix.stride & 3u) == 0) && ((reinterpret_cast<uintptr_t>(ix.rows) & 15u) == 0)) {
         for (; j + 4 <= ix.dim; j += 4) {   // 16-byte loads, same sequential sum
             const float4 x = *reinterpret_cast<const float4 *>(row + j);
             const float4 y = *reinterpret_cast<const float4 *>(c + j);
@@ -2073,18 +2196,25 @@ static BfIndexDev km_view(const BfIndexDev &ix, uint32_t col_offset, uint32_t su
 }
 
 static int km_launch_assign(const BfIndexDev &v, const float *d_centers, uint32_t k, uint32_t *d_assign,
-                            float *d_dist, hipStream_t st) {
+                            float *d_dist, bool avx, hipStream_t st) {
     const uint32_t dimp = (v.dim + 3u) & ~3u;
-    const size_t lds = (size_t)kAsgTC * dimp * sizeof(float);
-    SCANN_TRY(set_dyn_lds(assign_nearest_kernel, lds));
-    hipLaunchKernelGGL(assign_nearest_kernel, dim3((uint32_t)ceil_div_u64(v.n, 256)), dim3(256), lds, st, v,
-                       d_centers, k, d_assign, d_dist);
+    const dim3 grid((uint32_t)ceil_div_u64(v.n, 256));
+    if (avx) {
+        const size_t lds = (size_t)kAvxTC * dimp * sizeof(float);
+        SCANN_TRY(set_dyn_lds(assign_nearest_avx_kernel, lds));
+        hipLaunchKernelGGL(assign_nearest_avx_kernel, grid, dim3(256), lds, st, v, d_centers, k, d_assign, d_dist);
+    } else {
+        const size_t lds = (size_t)kAsgTC * dimp * sizeof(float);
+        SCANN_TRY(set_dyn_lds(assign_nearest_kernel, lds));
+        hipLaunchKernelGGL(assign_nearest_kernel, grid, dim3(256), lds, st, v, d_centers, k, d_assign, d_dist);
+    }
     LAUNCH_CHECK();
     return SCANN_HIP_OK;
 }
 
 int bf_kmeans_init_pp_host(const BfIndexDev &ix, uint32_t col_offset, uint32_t sub_dim, uint32_t k,
-                           uint64_t seed, float *centers_out, hipStream_t st) {
+                           uint64_t seed, uint32_t simd_threshold, float *centers_out, hipStream_t st) {
+    const int avx = sub_dim >= simd_threshold ? 1 : 0;   // kmeans.rs:419-431
     const BfIndexDev v = km_view(ix, col_offset, sub_dim);
     const uint64_t n = v.n;
     if (n == 0 || k == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "empty dataset / no clusters");
@@ -2100,12 +2230,12 @@ int bf_kmeans_init_pp_host(const BfIndexDev &ix, uint32_t col_offset, uint32_t s
     SCANN_HIP_CHECK(hipMemcpyAsync(dpicks.p, &first, 4, hipMemcpyHostToDevice, st));
     for (uint32_t c = 1; c <= k; ++c) {
         uint32_t *sel = dpicks.as<uint32_t>() + (c - 1);
-        hipLaunchKernelGGL(km_mind_update_kernel, dim3(nb), dim3(256), 0, st, v, sel, c == 1 ? 1 : 0,
+        hipLaunchKernelGGL(km_mind_update_kernel, dim3(nb), dim3(256), 0, st, v, sel, c == 1 ? 1 : 0, avx,
                            dmin.as<float>());
         LAUNCH_CHECK();
         if (c == k) break;
         hipLaunchKernelGGL(km_sum_f64_kernel, dim3(nb), dim3(256), 0, st, dmin.as<float>(), n,
-                           dpart.as<double>());
+                           dpart.as<double>(), (uint32_t *)nullptr);
         LAUNCH_CHECK();
         const double u = (double)(km_splitmix(s) >> 11) * (1.0 / 9007199254740992.0);
         const uint32_t fallback = (uint32_t)(km_splitmix(s) % n);
@@ -2123,9 +2253,10 @@ int bf_kmeans_init_pp_host(const BfIndexDev &ix, uint32_t col_offset, uint32_t s
 
 int bf_kmeans_lloyd_host(const BfIndexDev &ix, uint32_t col_offset, uint32_t sub_dim, float *centers,
                          uint32_t k, uint32_t max_iterations, double convergence_threshold,
-                         uint32_t *out_assign, uint32_t *out_sizes, double *out_inertia,
+                         uint32_t simd_threshold, uint32_t *out_assign, uint32_t *out_sizes, double *out_inertia,
                          uint32_t *out_iterations, int *out_converged, hipStream_t st) {
     const BfIndexDev v = km_view(ix, col_offset, sub_dim);
+    const bool avx = sub_dim >= simd_threshold;   // kmeans.rs:419-431
     const uint64_t n = v.n;
     if (n == 0 || k == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "Cannot cluster empty dataset");
     const uint32_t nb = (uint32_t)ceil_div_u64(n, 256);
@@ -2134,7 +2265,7 @@ int bf_kmeans_lloyd_host(const BfIndexDev &ix, uint32_t col_offset, uint32_t sub
     SCANN_TRY(dassign.ensure(n * 4));
     SCANN_TRY(ddist.ensure(n * 4));
     SCANN_TRY(dpart.ensure((size_t)nb * 8));
-    SCANN_TRY(dtotal.ensure(8));
+    SCANN_TRY(dtotal.ensure(16));
     SCANN_TRY(dkeys.ensure(n * 8));
     SCANN_TRY(dsorted.ensure(n * 8));
     SCANN_TRY(doff.ensure((size_t)(k + 1) * 4));
@@ -2146,16 +2277,42 @@ int bf_kmeans_lloyd_host(const BfIndexDev &ix, uint32_t col_offset, uint32_t sub
     int key_bits = 33;   // 32 index bits + the bits of the cluster id
     while (key_bits < 64 && (1ull << (key_bits - 32)) < k) ++key_bits;
 
+    // dtotal: [0] f64 total, [1] (as u32) bit pattern of the smallest positive term
     auto assign_and_inertia = [&](double *inertia) -> int {
-        SCANN_TRY(km_launch_assign(v, dcent.as<float>(), k, dassign.as<uint32_t>(), ddist.as<float>(), st));
+        SCANN_TRY(km_launch_assign(v, dcent.as<float>(), k, dassign.as<uint32_t>(), ddist.as<float>(), avx, st));
+        uint32_t *d_minpos = reinterpret_cast<uint32_t *>(dtotal.as<double>() + 1);
+        SCANN_HIP_CHECK(hipMemsetAsync(d_minpos, 0xFF, 4, st));
         hipLaunchKernelGGL(km_sum_f64_kernel, dim3(nb), dim3(256), 0, st, ddist.as<float>(), n,
-                           dpart.as<double>());
+                           dpart.as<double>(), d_minpos);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(km_total_pick_kernel, dim3(1), dim3(256), 0, st, dpart.as<double>(), nb,
                            (const float *)nullptr, n, 0.0, 0u, dtotal.as<double>(), (uint32_t *)nullptr);
         LAUNCH_CHECK();
-        SCANN_HIP_CHECK(hipMemcpyAsync(inertia, dtotal.p, 8, hipMemcpyDeviceToHost, st));
+        struct { double total; uint32_t minpos; uint32_t pad; } h;
+        SCANN_HIP_CHECK(hipMemcpyAsync(&h, dtotal.p, 16, hipMemcpyDeviceToHost, st));
         SCANN_HIP_CHECK(hipStreamSynchronize(st));
+        // The reference adds the terms in datapoint order (kmeans.rs:376).  Every term is a
+        // non-negative multiple of g = ulp(smallest positive term); if total <= 2^53 * g every
+        // partial sum of every order is exactly representable, so the tree sum IS that sum.
+        bool exact = false;
+        if (h.minpos == 0xFFFFFFFFu) {
+            exact = true;   // all terms are zero
+        } else if (h.total == h.total && h.total < INFINITY) {
+            float mp;
+            std::memcpy(&mp, &h.minpos, 4);
+            int e = 0;
+            (void)std::frexp(mp, &e);                    // mp = f * 2^e, f in [0.5, 1)
+            const int ge = std::max(e - 24, -149);       // ulp exponent (denormals: 2^-149)
+            exact = h.total <= std::ldexp(1.0, ge + 53);
+        }
+        if (!exact) {
+            hipLaunchKernelGGL(km_sum_f64_sequential_kernel, dim3(1), dim3(256), 0, st, ddist.as<float>(), n,
+                               dtotal.as<double>());
+            LAUNCH_CHECK();
+            SCANN_HIP_CHECK(hipMemcpyAsync(&h.total, dtotal.p, 8, hipMemcpyDeviceToHost, st));
+            SCANN_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        *inertia = h.total;
         return SCANN_HIP_OK;
     };
 

@@ -14,6 +14,9 @@ namespace scann {
 // ---- error plumbing ---------------------------------------------------------------
 void set_last_error(const std::string &msg);
 int fail(int status, const std::string &msg);
+// scann_hip_txh_create with the status reported for inconsistent array CONTENTS (api.hip)
+int txh_create_checked(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_hip_index **out,
+                       int content_status);
 
 #define SCANN_HIP_CHECK(expr)                                                         \
     do {                                                                              \

@@ -319,7 +319,7 @@ int scann_hip_index_load_file(scann_hip_ctx *ctx, const char *path, scann_hip_in
         SCANN_TRY(section(m, path, "codes", bytes3(h.n_local, bpp, 1), true, &p));
         d.codes = static_cast<const uint8_t *>(p);
     }
-    return scann_hip_txh_create(ctx, &d, out);
+    return scann::txh_create_checked(ctx, &d, out, SCANN_HIP_DATA_LOSS);
 }
 
 }  // extern "C"

@@ -185,6 +185,10 @@ int launch_lut16_u8_batch(const uint8_t *d_packed, const uint8_t *d_lut8, uint32
                           uint64_t n, float bias, float mult, float *d_out,
                           hipStream_t stream);
 
+// Lut16SimdTables::from_float_tables (hashes/lut16_simd.rs:39-90); d_bias_mult = {bias, multiplier}
+int launch_lut16_quantize(const float *d_tables, uint32_t S, uint8_t *d_lut8, float *d_bias_mult,
+                          hipStream_t stream);
+
 int launch_encode(const float *d_codebook, uint32_t S, uint32_t K, uint32_t dsub,
                   const float *d_rows, uint64_t n, uint32_t stride, const float *d_centers,
                   const uint32_t *d_leaf_of_row, uint8_t *d_out, hipStream_t stream);

@@ -1947,6 +1947,46 @@ __global__ __launch_bounds__(256) void lut16_u8_batch_kernel(
     }
 }
 
+// Lut16SimdTables::from_float_tables (hashes/lut16_simd.rs:39-90): global min / max of the S x 16
+// entries (f32::min / f32::max: a NaN operand is ignored), range = max - min, scale = 255 / range
+// (1 when range < 1e-10), lut8 = round((v - min) * scale) as u8 (round half away from zero; `as u8`
+// saturates and maps NaN to 0), bias = min, multiplier = 1 / scale (1 in the degenerate case).
+__global__ __launch_bounds__(256) void lut16_quantize_kernel(const float *__restrict__ tables, uint32_t S,
+                                                             uint8_t *__restrict__ lut8,
+                                                             float *__restrict__ bias_mult) {
+    __shared__ float s_min[4], s_max[4];
+    const uint32_t tid = threadIdx.x, n = S * 16;
+    float mn = 3.40282347e+38f, mx = -3.40282347e+38f;   // f32::MAX / f32::MIN
+    for (uint32_t i = tid; i < n; i += 256) {
+        const float v = tables[i];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o));
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+    }
+    if ((tid & 63u) == 0) {
+        s_min[tid >> 6] = mn;
+        s_max[tid >> 6] = mx;
+    }
+    __syncthreads();
+    mn = fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
+    mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    const float range = mx - mn;
+    const bool degenerate = range < 1e-10f;
+    const float scale = degenerate ? 1.0f : 255.0f / range;
+    for (uint32_t i = tid; i < n; i += 256) {
+        const float r = roundf((tables[i] - mn) * scale);
+        lut8[i] = !(r > 0.0f) ? (uint8_t)0 : (r >= 255.0f ? (uint8_t)255 : (uint8_t)r);
+    }
+    if (tid == 0) {
+        bias_mult[0] = mn;
+        bias_mult[1] = degenerate ? 1.0f : 1.0f / scale;
+    }
+}
+
 // Codebook::encode (hashes/codebook.rs:82-95): per subspace argmin over K with strict '<'.
 __global__ __launch_bounds__(256) void encode_kernel(
     const float *__restrict__ codebook, uint32_t S, uint32_t K, uint32_t dsub,
@@ -2331,6 +2371,14 @@ int launch_lut16_u8_batch(const uint8_t *d_packed, const uint8_t *d_lut8, uint32
     const uint32_t gx = (uint32_t)std::min<uint64_t>(ceil_div_u64(n, 256), 8192);
     hipLaunchKernelGGL(lut16_u8_batch_kernel, dim3(gx), dim3(256), (size_t)S * 16, st, d_packed, d_lut8,
                        S, n, bias, mult, d_out);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+int launch_lut16_quantize(const float *d_tables, uint32_t S, uint8_t *d_lut8, float *d_bias_mult,
+                          hipStream_t st) {
+    if (S == 0) return SCANN_HIP_OK;
+    hipLaunchKernelGGL(lut16_quantize_kernel, dim3(1), dim3(256), 0, st, d_tables, S, d_lut8, d_bias_mult);
     LAUNCH_CHECK();
     return SCANN_HIP_OK;
 }

@@ -37,6 +37,9 @@ EXPORTS = [
     "scann_hip_index_last_kernel_ms",
     "scann_hip_txh_write_file", "scann_hip_bf_write_file", "scann_hip_index_file_info",
     "scann_hip_index_load_file",
+    "scann_hip_abi_layout", "scann_hip_lut16_quantize",
+    "scann_hip_comm_unique_id", "scann_hip_comm_create", "scann_hip_comm_destroy",
+    "scann_hip_txh_search_sharded_device", "scann_hip_comm_last_status", "scann_hip_comm_layout",
 ]
 
 
@@ -145,10 +148,22 @@ def load():
     L.scann_hip_bf_assign_nearest.argtypes = [vp, f32p, C.c_uint32, u32p, f32p]
     L.scann_hip_txh_pack_blocks_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp,
                                                    C.c_uint64, vp]
-    L.scann_hip_kmeans_init_pp.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, f32p]
+    L.scann_hip_kmeans_init_pp.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
+                                           f32p]
     L.scann_hip_kmeans_lloyd.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, C.c_uint32, C.c_uint32,
-                                         C.c_double, u32p, u32p, C.POINTER(C.c_double), u32p,
+                                         C.c_double, C.c_uint32, u32p, u32p, C.POINTER(C.c_double), u32p,
                                          C.POINTER(C.c_int)]
+    L.scann_hip_abi_layout.restype = C.c_uint32
+    L.scann_hip_abi_layout.argtypes = [u32p, C.c_uint32]
+    L.scann_hip_lut16_quantize.argtypes = [vp, f32p, C.c_uint32, u8p, f32p, f32p]
+    L.scann_hip_comm_unique_id.argtypes = [vp]
+    L.scann_hip_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.scann_hip_comm_destroy.argtypes = [vp]
+    L.scann_hip_comm_destroy.restype = None
+    L.scann_hip_txh_search_sharded_device.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                      C.POINTER(SearchOpts), C.c_uint32, vp, vp, vp, vp]
+    L.scann_hip_comm_last_status.argtypes = [vp]
+    L.scann_hip_comm_layout.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u64p]
     L.scann_hip_bf_search_radius.argtypes = [vp, f32p, C.c_uint32, C.c_float, u32p, f32p, C.c_uint64,
                                              C.POINTER(C.c_uint64)]
     L.scann_hip_index_size.restype = C.c_uint64
@@ -404,6 +419,59 @@ def lut16_distances_batch(packed, lut8, S, n, bias, mult, device=0):
     return out
 
 
+def lut16_quantize(tables, device=0):
+    """Lut16SimdTables::from_float_tables on the device: (lut8 [S][16] u8, bias, multiplier)."""
+    t = f32(tables)
+    S = t.shape[0]
+    lut8 = np.zeros((S, 16), np.uint8)
+    bias = C.c_float(0)
+    mult = C.c_float(0)
+    check(load().scann_hip_lut16_quantize(context(device), ptr(t, f32p) if S else None, S,
+                                          ptr(lut8, u8p) if S else None, C.byref(bias), C.byref(mult)))
+    return lut8, float(np.float32(bias.value)), float(np.float32(mult.value))
+
+
+def abi_layout():
+    out = np.zeros(6, np.uint32)
+    n = load().scann_hip_abi_layout(ptr(out, u32p), 6)
+    return [int(v) for v in out[:n]]
+
+
+_LAYOUT_KEYS = ["qr", "nq_pad", "block_bytes", "blk_idx", "blk_exact", "blk_count", "soa_bytes", "soa_idx",
+                "soa_exact", "soa_count", "res_bytes", "res_dist"]
+
+
+def comm_layout(nq, world, m_local, k):
+    """scann_hip_comm_layout as a dict (no GPU needed)."""
+    out = np.zeros(12, np.uint64)
+    check(load().scann_hip_comm_layout(nq, world, m_local, k, ptr(out, u64p)))
+    return {n: int(v) for n, v in zip(_LAYOUT_KEYS, out)}
+
+
+class Comm:
+    """One RCCL communicator of the library (scann_hip_comm_*)."""
+
+    def __init__(self, unique_id, rank, world, device=0):
+        h = vp()
+        self._id = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        check(load().scann_hip_comm_create(context(device), C.cast(self._id, vp), rank, world, C.byref(h)))
+        self.h, self.rank, self.world = h, rank, world
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        check(load().scann_hip_comm_unique_id(C.cast(buf, vp)))
+        return bytes(buf)
+
+    def last_status(self):
+        check(load().scann_hip_comm_last_status(self.h))
+
+    def close(self):
+        if self.h:
+            load().scann_hip_comm_destroy(self.h)
+            self.h = None
+
+
 def encode(codebook, rows, stride=None, centers=None, leaf_of_row=None, device=0):
     cb = f32(codebook)
     rows = f32(rows)
@@ -440,15 +508,20 @@ def bf_search_radius(index, query, radius, capacity=None):
     return idx[:n], dist[:n], int(cnt.value)
 
 
-def kmeans_init_pp(index, k, seed, col_offset=0, sub_dim=None):
+KMEANS_SIMD_THRESHOLD = 128   # KMeansConfig::default().simd_threshold (trees/kmeans.rs:59)
+
+
+def kmeans_init_pp(index, k, seed, col_offset=0, sub_dim=None, simd_threshold=KMEANS_SIMD_THRESHOLD):
     """k-means++ seeding on the GPU over the rows of a brute-force index: centres [k][sub_dim]."""
     sd = index.dimensionality() if sub_dim is None else sub_dim
     out = np.zeros((k, sd), np.float32)
-    check(load().scann_hip_kmeans_init_pp(index.h, col_offset, sd, k, C.c_uint64(seed), ptr(out, f32p)))
+    check(load().scann_hip_kmeans_init_pp(index.h, col_offset, sd, k, C.c_uint64(seed), simd_threshold,
+                                          ptr(out, f32p)))
     return out
 
 
-def kmeans_lloyd(index, centers, max_iterations=100, convergence_threshold=1e-5, col_offset=0):
+def kmeans_lloyd(index, centers, max_iterations=100, convergence_threshold=1e-5, col_offset=0,
+                 simd_threshold=KMEANS_SIMD_THRESHOLD):
     """KMeans::fit_single's Lloyd loop on the GPU from given centres.
     Returns (centers, assign, sizes, inertia, iterations, converged)."""
     c = np.array(centers, np.float32, copy=True, order="C")
@@ -457,7 +530,7 @@ def kmeans_lloyd(index, centers, max_iterations=100, convergence_threshold=1e-5,
     assign = np.zeros(n, np.uint32); sizes = np.zeros(k, np.uint32)
     inertia = C.c_double(0); iters = C.c_uint32(0); conv = C.c_int(0)
     check(load().scann_hip_kmeans_lloyd(index.h, col_offset, sd, ptr(c, f32p), k, max_iterations,
-                                        C.c_double(convergence_threshold), ptr(assign, u32p),
+                                        C.c_double(convergence_threshold), simd_threshold, ptr(assign, u32p),
                                         ptr(sizes, u32p), C.byref(inertia),
                                         C.cast(C.byref(iters), u32p), C.byref(conv)))
     return c, assign, sizes, inertia.value, iters.value, bool(conv.value)

@@ -204,18 +204,21 @@ inline uint64_t splitmix(uint64_t &s) {
 
 // KMeans::fit (trees/kmeans.rs:166-263) on the GPU over the rows of the brute-force index `bf`,
 // restricted to columns [c0, c0 + d): k-means++ seeding (scann_hip_kmeans_init_pp, splitmix64 stream)
-// then the Lloyd loop of fit_single (scann_hip_kmeans_lloyd: sequential-scalar assignment with the
-// lowest index on ties, f64 centre update in datapoint order, the reference's convergence test).
+// then the Lloyd loop of fit_single (scann_hip_kmeans_lloyd: assignment with the lowest index on ties
+// -- sequential-scalar distances below KMeansConfig.simd_threshold dims, the AVX2 order from there
+// on -- f64 centre update in datapoint order, the reference's convergence test).
+constexpr uint32_t kKMeansSimdThreshold = 128;   // KMeansConfig::default (trees/kmeans.rs:59)
 inline void kmeans_gpu(scann_hip_index *bf, size_t n, size_t c0, size_t d, size_t k, size_t max_iterations,
                        double convergence_threshold, uint64_t seed, std::vector<float> &centers,
                        std::vector<uint32_t> &assign) {
     k = std::min(k, n);   // kmeans.rs:171-175: at most n clusters
     centers.assign(k * d, 0.0f);
     assign.assign(n, 0);
-    check(scann_hip_kmeans_init_pp(bf, (uint32_t)c0, (uint32_t)d, (uint32_t)k, seed, centers.data()));
+    check(scann_hip_kmeans_init_pp(bf, (uint32_t)c0, (uint32_t)d, (uint32_t)k, seed, kKMeansSimdThreshold,
+                                   centers.data()));
     check(scann_hip_kmeans_lloyd(bf, (uint32_t)c0, (uint32_t)d, centers.data(), (uint32_t)k,
-                                 (uint32_t)max_iterations, convergence_threshold, assign.data(), nullptr,
-                                 nullptr, nullptr, nullptr));
+                                 (uint32_t)max_iterations, convergence_threshold, kKMeansSimdThreshold,
+                                 assign.data(), nullptr, nullptr, nullptr, nullptr));
 }
 
 // Codebook::train (hashes/codebook.rs:146-202): per-subspace k-means with seed + s, on the GPU over

@@ -101,3 +101,45 @@ def unpack_blocks(buf, nq, m_local, world):
     exact = np.stack([buf[g, oe:oc].view(np.float32).reshape(qr, m_local) for g in range(world)])
     cnt = np.stack([buf[g, oc:oc + qr * 4].view(np.uint32) for g in range(world)])
     return keys, idx, exact, cnt
+
+
+# ---- the library's own exchange (csrc/comm.hip, scann_hip_txh_search_sharded_device) --------------
+def comm_layout(nq, world, m_local, k):
+    """Python statement of comm.hip::comm_layout (checked against scann_hip_comm_layout by the tests):
+    the batch is padded to qr * world queries; queries past nq travel with count 0."""
+    qr = (nq + world - 1) // world
+    per = qr * m_local
+    return dict(qr=qr, nq_pad=qr * world, block_bytes=(per * 16 + qr * 4 + 15) // 16 * 16,
+                blk_idx=per * 8, blk_exact=per * 12, blk_count=per * 16,
+                soa_bytes=nq * m_local * 16 + nq * 4, soa_idx=nq * m_local * 8, soa_exact=nq * m_local * 12,
+                soa_count=nq * m_local * 16, res_bytes=qr * world * (2 * k + 1) * 4, res_dist=qr * world * k * 4)
+
+
+def comm_pack_reference(keys, idx, exact, counts, world, lay):
+    """Numpy statement of comm.hip::comm_pack_kernel: uint8 [world][block_bytes]."""
+    nq, m = keys.shape
+    qr = lay["qr"]
+    out = np.zeros((world, lay["block_bytes"]), np.uint8)
+    for d in range(world):
+        q0, q1 = min(nq, d * qr), min(nq, (d + 1) * qr)
+        n = q1 - q0
+        kb = np.zeros((qr, m), np.uint64); ib = np.zeros((qr, m), np.uint32); eb = np.zeros((qr, m), np.float32)
+        cb = np.zeros(qr, np.uint32)
+        kb[:n], ib[:n], eb[:n], cb[:n] = keys[q0:q1], idx[q0:q1], exact[q0:q1], counts[q0:q1]
+        out[d, :lay["blk_idx"]] = kb.view(np.uint8).reshape(-1)
+        out[d, lay["blk_idx"]:lay["blk_exact"]] = ib.view(np.uint8).reshape(-1)
+        out[d, lay["blk_exact"]:lay["blk_count"]] = eb.view(np.uint8).reshape(-1)
+        out[d, lay["blk_count"]:lay["blk_count"] + qr * 4] = cb.view(np.uint8).reshape(-1)
+    return out
+
+
+def comm_unpack(buf, world, m_local, lay):
+    """(keys, idx, exact, counts) [world][qr][...] of a received [world][block_bytes] buffer."""
+    qr = lay["qr"]
+    buf = np.ascontiguousarray(buf).reshape(world, lay["block_bytes"])
+    keys = np.stack([buf[g, :lay["blk_idx"]].view(np.uint64).reshape(qr, m_local) for g in range(world)])
+    idx = np.stack([buf[g, lay["blk_idx"]:lay["blk_exact"]].view(np.uint32).reshape(qr, m_local) for g in range(world)])
+    exact = np.stack([buf[g, lay["blk_exact"]:lay["blk_count"]].view(np.float32).reshape(qr, m_local)
+                      for g in range(world)])
+    cnt = np.stack([buf[g, lay["blk_count"]:lay["blk_count"] + qr * 4].view(np.uint32) for g in range(world)])
+    return keys, idx, exact, cnt

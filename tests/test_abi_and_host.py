@@ -94,3 +94,87 @@ def test_trainer_index_is_consistent():
     assert ix["codes"].max() < 16
     with pytest.raises(ValueError):
         trainer.train_codebook(X, 7, 16)   # 32 % 7 != 0 (codebook.rs:154-159)
+
+
+# ---- one struct, three statements: the C header, the ctypes binding, the Rust block of INTEGRATION.md --------
+_C_WIDTH = {"uint64_t": 8, "uint32_t": 4, "int32_t": 4, "float": 4, "int": 4}
+_RUST_WIDTH = {"u64": 8, "u32": 4, "i32": 4, "c_float": 4, "f32": 4, "c_int": 4}
+
+
+def _header_structs():
+    """{struct name: [(field, width in bytes)]} parsed from include/scann_hip.h (pointers are 8 bytes)."""
+    text = open(os.path.join(ROOT, "include", "scann_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for body, name in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(scann_hip_\w+)\s*;", text, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            m = re.match(r"(?:const\s+)?(\w+)\s*(\**)\s*(.*)$", decl, flags=re.S)
+            ctype, stars, names = m.group(1), m.group(2), m.group(3)
+            for nm in names.split(","):
+                nm = nm.strip()
+                ptr = bool(stars) or nm.startswith("*")
+                fields.append((nm.lstrip("* "), 8 if ptr else _C_WIDTH[ctype]))
+        out[name] = fields
+    return out
+
+
+def _rust_structs():
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    out = {}
+    for name, body in re.findall(r"#\[repr\(C\)\]\npub struct (scann_hip_\w+) \{\n(.*?)\n\}", text, flags=re.S):
+        fields = []
+        for nm, ty in re.findall(r"pub (\w+):\s*([^,\n]+),", body):
+            ty = ty.strip()
+            fields.append((nm, 8 if ty.startswith("*") else _RUST_WIDTH[ty]))
+        if fields:
+            out[name] = fields
+    return out
+
+
+def test_struct_layouts_agree_header_ctypes_rust():
+    """INTEGRATION.md's scann_hip_txh_desc had drifted from the header (a missing trailing
+    field = an out-of-bounds read by the library).  Field names, order and widths of every ABI struct
+    must be the same in the header, in hip.py's ctypes classes and in INTEGRATION.md's #[repr(C)] block,
+    and the compiled library's own sizeof/offsetof must equal the ctypes layout."""
+    from scann_rust_amd import build, hip
+    build.build()
+    hdr, rust = _header_structs(), _rust_structs()
+    classes = {"scann_hip_txh_desc": hip.TxhDesc, "scann_hip_search_opts": hip.SearchOpts,
+               "scann_hip_file_info": hip.FileInfo}
+    assert set(hdr) == set(classes), sorted(hdr)
+    for name, cls in classes.items():
+        ct = [(f, ctypes.sizeof(t)) for f, t in cls._fields_]
+        assert ct == hdr[name], "%s: ctypes %s != header %s" % (name, ct, hdr[name])
+        assert name in rust, "INTEGRATION.md lacks a #[repr(C)] %s" % name
+        assert rust[name] == hdr[name], "%s: INTEGRATION.md %s != header %s" % (name, rust[name], hdr[name])
+    lay = hip.abi_layout()
+    assert lay == [ctypes.sizeof(hip.TxhDesc), hip.TxhDesc.distance_measure.offset,
+                   ctypes.sizeof(hip.SearchOpts), hip.SearchOpts.bf_exact.offset,
+                   ctypes.sizeof(hip.FileInfo), hip.FileInfo.has_data.offset]
+
+
+def test_integration_md_lists_every_extern():
+    import subprocess
+    import sys
+    # the Rust block is generated from the header; a stale block fails here
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "gen_rust_binding.py")]) == 0
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    bound = set(re.findall(r"\bfn (scann_hip_[a-z0-9_]+)\s*\(", text))
+    missing = [s for s in _declared_symbols() if s not in bound]
+    assert not missing, "INTEGRATION.md's extern block lacks %s" % missing
+
+
+def test_comm_layout_python_mirror_matches_library_constants():
+    """sharding.comm_layout is the Python statement of comm.hip's block layout (used by the gloo test)."""
+    from scann_rust_amd import build, hip, sharding
+    build.build()
+    lay = sharding.comm_layout(nq=10, world=4, m_local=7, k=3)
+    assert lay["qr"] == 3 and lay["nq_pad"] == 12
+    assert lay["block_bytes"] % 16 == 0 and lay["block_bytes"] >= 3 * 7 * 16 + 3 * 4
+    assert lay["blk_idx"] == 3 * 7 * 8 and lay["blk_exact"] == 3 * 7 * 12 and lay["blk_count"] == 3 * 7 * 16
+    for nq, world, m, k in ((10, 4, 7, 3), (1024, 8, 8192, 10), (1, 1, 1, 1), (12, 3, 40, 10), (5, 8, 30, 10)):
+        assert sharding.comm_layout(nq, world, m, k) == hip.comm_layout(nq, world, m, k)

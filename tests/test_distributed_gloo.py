@@ -185,3 +185,62 @@ def test_all_to_all_exchange_matches_single_process(world):
     [p.join(300) for p in procs]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def _worker_comm(rank, world, port, ret, nq):
+    """The protocol of scann_hip_txh_search_sharded_device (csrc/comm.hip), rank by rank on the CPU:
+    the LIBRARY's block layout (scann_hip_comm_layout), the batch padded to a multiple of the ranks,
+    all-to-all of destination blocks, merge of the rank's qr queries, in-place all-gather of the rows."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pyoracle as orc
+        from scann_rust_amd import hip, sharding, synth, trainer
+        rows = synth.uniform_f32(N, DIM, 11)
+        queries = synth.uniform_f32(NQ, DIM, 12)
+        data, stride = orc.to_strided(rows)
+        ix = trainer.build_txh_index(rows, L, S, seed=3, kmeans_iters=3, pq_iters=3)
+        kw = sharding.shard_txh_index(ix, data, stride, rank, world)
+        tokens = np.stack([orc.partition(ix["centers"], q, P)[0] for q in queries]).astype(np.int64)
+        keys, idx, exact, cnt = (a[:nq] for a in _local_stage(kw, ix, queries, tokens))
+        lay = hip.comm_layout(nq, world, M, K)                  # the library's constants
+        assert lay == sharding.comm_layout(nq, world, M, K)
+        send = sharding.comm_pack_reference(keys.view(np.uint64), idx.view(np.uint32), exact,
+                                            cnt.view(np.uint32), world, lay)
+        recv = torch.empty(send.size, dtype=torch.uint8)
+        dist.all_to_all_single(recv, torch.from_numpy(send.reshape(-1)))
+        gk, gi, ge, gc = sharding.comm_unpack(recv.numpy(), world, M, lay)
+        oi, od, oc = sharding.merge_reference(gk, gi, ge, gc, M, K)      # my qr queries (padding: count 0)
+        qr = lay["qr"]
+        outs = []
+        for arr in (oi.view(np.int32), od, oc.view(np.int32)):           # three all-gathers, rank g at g * qr
+            t = torch.from_numpy(np.ascontiguousarray(arr).reshape(-1))  # (gloo has no unsigned 32-bit type)
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            outs.append(np.concatenate([p.numpy() for p in parts]))
+        outs[0], outs[2] = outs[0].view(np.uint32), outs[2].view(np.uint32)
+        all_i, all_d, all_c = outs[0].reshape(-1, K)[:nq], outs[1].reshape(-1, K)[:nq], outs[2][:nq]
+        oix = orc.TxhIndex(data, stride, DIM, ix["centers"], ix["leaf_off"], ix["leaf_ids"],
+                           ix["codebook"], ix["codes"], partitions_to_search=P,
+                           pre_reorder_multiplier=M / K)
+        ok = outs[2].size == qr * world and np.all(outs[2][nq:] == 0)
+        for q in range(nq):
+            wi, wd = orc.txh_search(oix, queries[q], K)
+            ok = ok and all_c[q] == wi.size and np.array_equal(all_i[q, :wi.size], wi) \
+                and np.array_equal(all_d[q, :wi.size].view(np.uint32), wd.view(np.uint32))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nq", [(2, 11), (4, 9)])
+def test_library_exchange_protocol_with_padding_matches_single_process(world, nq):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_comm, args=(r, world, port, ret, nq)) for r in range(world)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert all(ret.get(r) for r in range(world)), dict(ret)

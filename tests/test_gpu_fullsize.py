@@ -185,3 +185,119 @@ def test_scann_partitioned_1m_all_leaves_equals_brute_force(big, measure):
             loaded = hip.load_file(p)
             li, ld, lc = loaded.search_batched(q, K)
             assert np.array_equal(li, idx) and np.array_equal(ld.view(np.uint32), dist.view(np.uint32))
+
+
+# ---- BASELINE.json configs[3] and the shard shape of configs[4] (untested configs) --------------
+def _build_big_txh(n, dim, L, S, kmeans_iters=6):
+    """Clustered synthetic set (mixture of 1000 Gaussians) generated with torch on the GPU
+    (harness plumbing: numpy would need minutes at this size), index built by the LIBRARY's GPU k-means
+    (partitioner on all rows, per-subspace codebooks on a residual sample, residual encode).  The
+    dataset is stored in leaf order, so datapoint index == CSR row and leaf_ids is the identity."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    cen = torch.rand((1000, dim), generator=g, device=dev)
+    sig = 0.1 * (1.0 / 6.0) ** 0.5
+    X = cen[torch.randint(0, 1000, (n,), generator=g, device=dev)] + sig * torch.randn((n, dim), generator=g, device=dev)
+    Q = cen[torch.randint(0, 1000, (256,), generator=g, device=dev)] + sig * torch.randn((256, dim), generator=g,
+                                                                                        device=dev)
+    stride = hip.compute_stride(dim)
+    assert stride == dim
+    x_np = X.cpu().numpy()
+    bf = hip.bf_create(x_np, n, dim, stride, hip.SQUARED_L2)
+    centers, assign, sizes, _, iters, _ = hip.kmeans_lloyd(bf, hip.kmeans_init_pp(bf, L, seed=42),
+                                                            max_iterations=kmeans_iters)
+    bf.close()
+    del x_np
+    assert sizes.sum() == n and iters >= 1
+    a_t = torch.from_numpy(assign.astype(np.int64)).to(dev)
+    order = torch.argsort(a_t, stable=True)
+    X = X[order]                                         # the dataset, in leaf order
+    leaf_of_row = a_t[order]
+    leaf_off = np.zeros(L + 1, np.uint32)
+    leaf_off[1:] = np.cumsum(sizes)
+    c_t = torch.from_numpy(centers).to(dev)
+    ns = 131072
+    pick = torch.randperm(n, generator=g, device=dev)[:ns]
+    sub = np.ascontiguousarray((X[pick] - c_t[leaf_of_row[pick]]).cpu().numpy())
+    rbf = hip.bf_create(sub, ns, dim, stride, hip.SQUARED_L2)
+    dsub = dim // S
+    cb = np.stack([hip.kmeans_lloyd(rbf, hip.kmeans_init_pp(rbf, 16, seed=42 + s, col_offset=s * dsub, sub_dim=dsub),
+                                    max_iterations=8, col_offset=s * dsub)[0] for s in range(S)])
+    rbf.close()
+    data = X.cpu().numpy()
+    lor = leaf_of_row.cpu().numpy().astype(np.uint32)
+    del X, a_t, order, leaf_of_row
+    torch.cuda.empty_cache()
+    codes = hip.encode(cb, data, stride=stride, centers=centers, leaf_of_row=lor)
+    sel = np.arange(0, n, 99991)
+    assert np.array_equal(codes[sel], orc.encode_many(cb, data[sel] - centers[lor[sel]]))
+    ids = np.arange(n, dtype=np.uint32)
+    index = hip.txh_create(data=data, n_rows=n, dim=dim, stride=stride, centers=centers, leaf_offsets=leaf_off,
+                           leaf_ids=ids, codebook=cb, codes=codes, use_residuals=True, partitions_to_search=10,
+                           pre_reorder_multiplier=3.0)
+    return dict(index=index, data=data, stride=stride, dim=dim, centers=centers, leaf_off=leaf_off, ids=ids, cb=cb,
+                codes=codes, q=Q.cpu().numpy())
+
+
+def _check_big_txh(b, k, P, m, oracle_rows):
+    """Stage-by-stage oracle check on a few queries, size-independent properties on all of them."""
+    o = hip.default_opts()
+    o.partitions_to_search, o.pre_reorder_k = P, m
+    q = b["q"]
+    idx, dist, cnt, (tok, tokd, ci, cd, cc) = b["index"].search_batched(q, k, o, stages=True)
+    assert np.all(cnt == k) and np.all(np.diff(dist, axis=1) >= 0)
+    oix = orc.TxhIndex(b["data"], b["stride"], b["dim"], b["centers"], b["leaf_off"], b["ids"], b["cb"], b["codes"],
+                       use_residuals=True, partitions_to_search=P, pre_reorder_multiplier=m / k)
+    for i in oracle_rows:
+        H.check_txh_query(oix, q[i], k, idx[i, :cnt[i]], dist[i, :cnt[i]], tok[i], tokd[i], ci[i, :cc[i]],
+                          cd[i, :cc[i]], what="P=%d m=%d q%d" % (P, m, i))
+    # the returned distances are the reference's exact arithmetic on the returned rows, bit for bit
+    for i in range(0, q.shape[0], 5):
+        want = orc.one_to_many(q[i], b["data"][idx[i]].ravel(), b["dim"], k, hip.SQUARED_L2)
+        assert np.array_equal(want.view(np.uint32), dist[i].view(np.uint32))
+        assert len(set(idx[i].tolist())) == k
+    # batch-split invariance (rows do not depend on the batch they travel in) and idempotence
+    parts = [b["index"].search_batched(q[a:a + 37], k, o) for a in range(0, q.shape[0], 37)]
+    assert np.array_equal(np.concatenate([p[0] for p in parts]), idx)
+    assert np.array_equal(np.concatenate([p[1] for p in parts]).view(np.uint32), dist.view(np.uint32))
+    return idx
+
+
+def test_txh_10m_gpu_build_and_oracle():
+    """BASELINE configs[3]: Tree-X-Hybrid, KMeansTree 1000 leaves + AH LUT16 (32 x 16) + exact re-rank,
+    10M x 128 -- including pre_reorder_k = 8192, the library's hard cap."""
+    b = _build_big_txh(10_000_000, 128, 1000, 32)
+    k = 10
+    got = {}
+    for P, m, rows in ((10, 1000, range(0, 256, 32)), (10, 8192, range(0, 256, 64)), (50, 1000, range(0, 256, 64)),
+                       (50, 8192, (0, 128))):
+        got[(P, m)] = _check_big_txh(b, k, P, m, rows)
+    # recall against exact brute force is monotone in m and in P (nested candidate streams)
+    bf = hip.bf_create(b["data"], 10_000_000, 128, b["stride"], hip.SQUARED_L2)
+    ti, _, _ = bf.search_batched(b["q"], k)
+    bf.close()
+    rec = {pm: H.recall_at_k(g, ti, k) for pm, g in got.items()}
+    assert rec[(10, 8192)] >= rec[(10, 1000)] - 1e-9 and rec[(50, 8192)] >= rec[(50, 1000)] - 1e-9
+    assert rec[(50, 8192)] >= rec[(10, 8192)] - 1e-9 and rec[(10, 8192)] > 0.9, rec
+    # one more than the cap is refused, not truncated
+    o = hip.default_opts()
+    o.pre_reorder_k = 8193
+    with pytest.raises(hip.ScannError) as e:
+        b["index"].search_batched(b["q"][:2], k, o)
+    assert e.value.code == hip.UNIMPLEMENTED
+
+
+def test_txh_c5_shard_shape():
+    """The per-GPU shard of BASELINE configs[4] (100M x 96 over 8 GPUs): 12.5M x 96, S = 24, 1250 leaves."""
+    b = _build_big_txh(12_500_000, 96, 1250, 24)
+    k = 10
+    got = {}
+    for P, m, rows in ((10, 1000, range(0, 256, 32)), (10, 8192, range(0, 256, 64))):
+        got[(P, m)] = _check_big_txh(b, k, P, m, rows)
+    bf = hip.bf_create(b["data"], 12_500_000, 96, b["stride"], hip.SQUARED_L2)
+    ti, _, _ = bf.search_batched(b["q"], k)
+    bf.close()
+    r1, r2 = H.recall_at_k(got[(10, 1000)], ti, k), H.recall_at_k(got[(10, 8192)], ti, k)
+    assert r2 >= r1 - 1e-9 and r2 > 0.9, (r1, r2)

@@ -88,6 +88,52 @@ def test_lut16_reference_vectors():  # src/simd/tests.rs:237-264, src/hashes/lut
     assert list(got) == [15.0, 15.0, 30.0, 0.0]
 
 
+# ---- a13: Lut16SimdTables::from_float_tables on the device (hashes/lut16_simd.rs:39-90) ----------------
+@pytest.mark.parametrize("S,kind", [(1, "rand"), (2, "rand"), (16, "rand"), (32, "rand"), (64, "wide"), (7, "neg"),
+                                    (3, "const"), (4, "tiny"), (5, "nan"), (32, "lut")])
+def test_lut16_quantize_bit_exact(S, kind):
+    rng = np.random.default_rng(S)
+    t = rng.random((S, 16), dtype=np.float32) * 3.0
+    if kind == "wide":
+        t = (t * np.float32(1e6)).astype(np.float32)
+    if kind == "neg":
+        t = (t - np.float32(1.5)).astype(np.float32)
+    if kind == "const":                       # degenerate range: scale = multiplier = 1, bias = the value
+        t[:] = np.float32(2.5)
+    if kind == "tiny":                        # range < 1e-10 but not zero
+        t = (np.float32(1.0) + t * np.float32(1e-12)).astype(np.float32)
+    if kind == "nan":                         # f32::min / f32::max ignore a NaN operand; NaN as u8 = 0
+        t[1, 3] = np.nan
+    if kind == "lut":                         # a real query table
+        cb = trainer.train_codebook(synth.uniform_f32(2000, 128, 3), 32, 16, iters=2, seed=1)
+        t = orc.lut_from_query(cb, synth.uniform_f32(1, 128, 9)[0])
+    g8, gb, gm = hip.lut16_quantize(t)
+    o8, ob, om = orc.lut16_quantize(t)
+    assert np.array_equal(g8, o8)
+    assert np.float32(gb).view(np.uint32) == np.float32(ob).view(np.uint32)
+    assert np.float32(gm).view(np.uint32) == np.float32(om).view(np.uint32)
+
+
+def test_lut16_quantize_reference_vectors_end_to_end():
+    """hashes/lut16_simd.rs:306-375 run on the GPU end to end: quantise -> batch kernel -> dequantise."""
+    t0 = np.arange(16, dtype=np.float32)
+    t1 = (15 - np.arange(16)).astype(np.float32)
+    lut8, bias, mult = hip.lut16_quantize(np.stack([t0, t1]))
+    # test_quantization_roundtrip (:306-330): codes [0,0] -> 15, [15,15] -> 15, [5,10] -> 10, tol 0.1
+    got = hip.lut16_distances_batch(orc.pack4(np.array([[0, 0], [15, 15], [5, 10]], np.uint8)), lut8, 2, 3, bias, mult)
+    assert np.all(np.abs(got - np.array([15.0, 15.0, 10.0], np.float32)) < 0.1)
+    # test_two_subspace_packed (:354-375): 0x00, 0x55, 0x0F, 0xF0 -> 15, 15, 30, 0, tol 0.5
+    got = hip.lut16_distances_batch(np.array([0x00, 0x55, 0x0F, 0xF0], np.uint8), lut8, 2, 4, bias, mult)
+    assert np.all(np.abs(got - np.array([15.0, 15.0, 30.0, 0.0], np.float32)) < 0.5)
+    # test_batch_computation (:332-352): one subspace, 0x00 0x05 0x0A 0x0F -> 0, 5, 10, 15, tol 0.1
+    l1, b1, m1 = hip.lut16_quantize(t0[None])
+    got = hip.lut16_distances_batch(np.array([0x00, 0x05, 0x0A, 0x0F], np.uint8), l1, 1, 4, b1, m1)
+    assert np.all(np.abs(got - np.array([0.0, 5.0, 10.0, 15.0], np.float32)) < 0.1)
+    # S == 0 (:42-49)
+    e8, eb, em = hip.lut16_quantize(np.zeros((0, 16), np.float32))
+    assert e8.shape == (0, 16) and eb == 0.0 and em == 1.0
+
+
 # ---- a14: Codebook::encode -------------------------------------------------------------------------
 def test_encode_bit_exact():
     X = synth.uniform_f32(4000, 128, 21)
@@ -575,23 +621,59 @@ def test_bf_search_radius(measure, n, dim):
 
 
 # ---- index build: K-means on the GPU (trees/kmeans.rs:210-414) -------------------------------------
-@pytest.mark.parametrize("n,dim,k,col,sub", [(5000, 32, 16, 0, 32), (20000, 96, 50, 0, 96),
-                                             (3000, 64, 16, 8, 4), (4000, 64, 256, 61, 3), (300, 7, 3, 0, 7)])
-def test_kmeans_lloyd_matches_oracle(n, dim, k, col, sub):
-    """Same initial centres -> bit-identical centres, assignments and iteration count as the CPU
-    restatement of KMeans::fit_single (dims < 128: both sides use the sequential scalar distance)."""
+@pytest.mark.parametrize("n,dim,k,col,sub,thr", [
+    (5000, 32, 16, 0, 32, 128), (20000, 96, 50, 0, 96, 128), (3000, 64, 16, 8, 4, 128), (4000, 64, 256, 61, 3, 128),
+    (300, 7, 3, 0, 7, 128),
+    # dim >= simd_threshold (the reference's default 128, trees/kmeans.rs:59): squared_l2_avx2's order
+    (6000, 128, 40, 0, 128, 128), (3000, 256, 24, 0, 256, 128), (2500, 200, 10, 32, 131, 128),
+    (2000, 140, 9, 0, 140, 128),
+    # configurable threshold: 0 = always the AVX2 order, a huge one = always sequential
+    (3000, 64, 16, 3, 37, 0), (2000, 160, 8, 0, 160, 1 << 30)])
+def test_kmeans_lloyd_matches_oracle(n, dim, k, col, sub, thr):
+    """Same initial centres -> bit-identical centres, assignments, iteration count AND f64 inertia as the
+    CPU restatement of KMeans::fit_single, on both sides of simd_threshold (trees/kmeans.rs:419-431)."""
     rows, _ = synth.clustered_f32(n, dim, 71, n_clusters=max(4, k // 2))
     data, stride = orc.to_strided(rows)
     index = hip.bf_create(data, n, dim, stride, hip.SQUARED_L2)
     pick = (synth.splitmix64(5, 0, k) % np.uint64(n)).astype(np.int64)
     init = np.ascontiguousarray(rows[pick][:, col:col + sub])
-    gc, ga, gs, gi, git, gconv = hip.kmeans_lloyd(index, init, max_iterations=12, col_offset=col)
+    gc, ga, gs, gi, git, gconv = hip.kmeans_lloyd(index, init, max_iterations=12, col_offset=col,
+                                                  simd_threshold=thr)
     oc, oa, os_, oi, oit, oconv = orc.kmeans_lloyd(data, n, stride, sub, init, max_iterations=12,
-                                                   col_offset=col)
+                                                   col_offset=col, simd_threshold=thr)
     assert git == oit and gconv == oconv
     assert np.array_equal(bits(gc), bits(oc))
     assert np.array_equal(ga, oa) and np.array_equal(gs, os_)
-    assert abs(gi - oi) <= 1e-9 * max(1.0, abs(oi))      # f64 inertia: reduction order differs
+    assert np.float64(gi).view(np.uint64) == np.float64(oi).view(np.uint64)   # the datapoint-order f64 sum
+
+
+def test_kmeans_inertia_sequential_fallback():
+    """Distances spanning > 2^53 ulps of the smallest one: the reduction tree is not provably exact, the
+    library must take the datapoint-order chain (kmeans.rs:376) and still match the oracle bit for bit."""
+    rng = np.random.default_rng(3)
+    n, dim = 20000, 8
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows[:64] *= np.float32(1e-9)            # tiny distances next to O(1e4) ones
+    rows[64:128] *= np.float32(1e3)
+    data, stride = orc.to_strided(rows)
+    index = hip.bf_create(data, n, dim, stride, hip.SQUARED_L2)
+    init = np.zeros((2, dim), np.float32)
+    init[1] = 0.5
+    g = hip.kmeans_lloyd(index, init, max_iterations=3)
+    o = orc.kmeans_lloyd(data, n, stride, dim, init, max_iterations=3)
+    assert np.array_equal(bits(g[0]), bits(o[0])) and np.array_equal(g[1], o[1]) and g[4] == o[4]
+    assert np.float64(g[3]).view(np.uint64) == np.float64(o[3]).view(np.uint64)
+
+
+def test_kmeans_init_pp_avx_order_min_distances():
+    """Seeding with dim >= simd_threshold: deterministic, every seed is a row (the D^2 sampling itself is
+    a documented deviation: f64 tree sums, scann_hip.h)."""
+    rows, _ = synth.clustered_f32(3000, 128, 5, n_clusters=12)
+    data, stride = orc.to_strided(rows)
+    index = hip.bf_create(data, 3000, 128, stride, hip.SQUARED_L2)
+    a = hip.kmeans_init_pp(index, 12, seed=9)
+    assert np.array_equal(a, hip.kmeans_init_pp(index, 12, seed=9))
+    assert all(any(np.array_equal(r, p) for p in rows) for r in a)
 
 
 def test_kmeans_reference_unit_tests_on_gpu():
@@ -961,3 +1043,68 @@ def test_bf_shortlist_aggressive_filter_bound_stays_exact(monkeypatch, force_sho
     assert np.array_equal(cnt, oc)
     for i in range(nq):
         H.assert_topk_equal_up_to_ties(idx[i], dist[i], oi[i], od[i], what="tail %s q%d" % (tail, i))
+
+
+# ---- multi-GPU exchange inside the library (csrc/comm.hip) ---------------------------------------------
+def test_sharded_search_through_rccl_world1():
+    """scann_hip_txh_search_sharded_device with a 1-rank communicator: the whole path (local stage, block
+    packing with batch padding, grouped ncclSend/ncclRecv to self, merge, in-place ncclAllGather, copy-out)
+    runs through RCCL on the communicator's stream and must equal the plain search bit for bit; two
+    alternating caller streams exercise the double-buffered event ordering."""
+    import ctypes
+    import torch
+    rows, data, stride, ix, oix, kw = H.make_txh_case(6000, 64, 16, 8, seed=21, P=5, mult=4.0, kmeans_iters=3,
+                                                      pq_iters=3)
+    sizes = (kw["leaf_offsets"][1:] - kw["leaf_offsets"][:-1]).astype(np.uint32)
+    # a "sharded" index holding every leaf: global sizes given, rows in CSR order
+    order = kw["leaf_ids"].astype(np.int64)
+    data2 = np.ascontiguousarray(np.asarray(data).reshape(6000, stride)[order])
+    skw = dict(kw, data=data2, leaf_sizes_global=sizes, data_is_csr_order=True)
+    index = hip.txh_create(**skw)
+    comm = hip.Comm(hip.Comm.unique_id(), 0, 1)
+    dev = torch.device("cuda", 0)
+    k, nq = 10, 37
+    o = hip.default_opts()
+    o.partitions_to_search, o.pre_reorder_k = 5, 40
+    L = hip.load()
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    outs = []
+    qs = [synth.uniform_f32(nq, 64, 100 + i) for i in range(4)]
+    hip.check(L.scann_hip_index_reserve(index.h, nq, k, ctypes.byref(o)))
+    for i, q in enumerate(qs):
+        st = streams[i & 1]
+        qd = torch.from_numpy(q).to(dev)
+        oi = torch.empty((nq, k), dtype=torch.int32, device=dev)
+        od = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        oc = torch.empty((nq,), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        hip.check(L.scann_hip_txh_search_sharded_device(index.h, comm.h, ctypes.c_void_p(qd.data_ptr()), nq, 64, k,
+                                                        ctypes.byref(o), 0, ctypes.c_void_p(oi.data_ptr()),
+                                                        ctypes.c_void_p(od.data_ptr()), ctypes.c_void_p(oc.data_ptr()),
+                                                        ctypes.c_void_p(st.cuda_stream)))
+        outs.append((qd, oi, od, oc))
+    torch.cuda.synchronize()
+    comm.last_status()
+    plain = hip.txh_create(**kw)
+    for q, (qd, oi, od, oc) in zip(qs, outs):
+        wi, wd, wc = plain.search_batched(q, k, o)
+        assert np.array_equal(oc.cpu().numpy().view(np.uint32), wc)
+        assert np.array_equal(od.cpu().numpy().view(np.uint32), wd.view(np.uint32))
+        assert np.array_equal(oi.cpu().numpy().view(np.uint32), wi)
+    for i in range(0, nq, 9):                       # and the oracle on a few rows
+        wi, wd = orc.txh_search(orc.TxhIndex(data, stride, 64, ix["centers"], ix["leaf_off"], ix["leaf_ids"],
+                                             ix["codebook"], ix["codes"], partitions_to_search=5,
+                                             pre_reorder_multiplier=4.0), qs[0][i], k)
+        H.assert_topk_equal_up_to_ties(outs[0][1][i].cpu().numpy().view(np.uint32)[:wi.size],
+                                       outs[0][2][i].cpu().numpy()[:wi.size], wi, wd, what="sharded q%d" % i)
+    # m_local < m that is too short must be reported, not silently wrong
+    hip.check(L.scann_hip_txh_search_sharded_device(index.h, comm.h, ctypes.c_void_p(outs[0][0].data_ptr()), nq, 64, k,
+                                                    ctypes.byref(o), 12, ctypes.c_void_p(outs[0][1].data_ptr()),
+                                                    ctypes.c_void_p(outs[0][2].data_ptr()),
+                                                    ctypes.c_void_p(outs[0][3].data_ptr()),
+                                                    ctypes.c_void_p(streams[0].cuda_stream)))
+    torch.cuda.synchronize()
+    with pytest.raises(hip.ScannError) as e:
+        comm.last_status()
+    assert e.value.code == 10
+    comm.close()

@@ -164,3 +164,81 @@ def test_loaded_bf_index_and_corrupt_sections(tmp_path):
     with pytest.raises(hip.ScannError) as e:
         hip.load_file(str(bad))
     assert e.value.code == DATA_LOSS
+
+
+@pytest.mark.gpu
+def test_inconsistent_contents_are_rejected(tmp_path):
+    """a file (or descriptor) whose section SIZES are right but whose CONTENTS would make a
+    search read out of bounds must be refused -- DataLoss from the loader, InvalidArgument from
+    txh_create -- not accepted and searched."""
+    rows, data, stride, ix, oix, kw = H.make_txh_case(700, 32, 5, 8, seed=3, P=2, kmeans_iters=2, pq_iters=2)
+
+    def refused(mut, code_create=hip.INVALID_ARGUMENT):
+        bad = dict(kw)
+        mut(bad)
+        with pytest.raises(hip.ScannError) as e:
+            hip.txh_create(**bad)
+        assert e.value.code == code_create, e.value
+        p = str(tmp_path / "bad.scannidx")
+        hip.txh_write_file(p, **bad)          # the writer copies bytes; it does not judge them
+        with pytest.raises(hip.ScannError) as e:
+            hip.load_file(p)
+        assert e.value.code == DATA_LOSS, e.value
+
+    def ids_out_of_range(b):
+        ids = b["leaf_ids"].copy()
+        ids[123] = 700                        # >= n_rows: the re-rank would read row 700 of 700
+        b["leaf_ids"] = ids
+    refused(ids_out_of_range)
+
+    def offsets_not_monotone(b):
+        off = b["leaf_offsets"].copy()
+        off[2] = off[1] - 1 if off[1] > 0 else off[3] + 1
+        b["leaf_offsets"] = off
+    refused(offsets_not_monotone)
+
+    def code_out_of_range(b):
+        cb = b["codebook"][:, :12].copy()     # 12 trained centres, codes up to 15 remain
+        b["codebook"] = cb
+    if kw["codes"].max() >= 12:
+        refused(code_out_of_range)
+
+    def packed_code_out_of_range(b):
+        b["codebook"] = b["codebook"][:, :12].copy()
+        b["codes"] = orc.pack4(kw["codes"])
+        b["codes_packed4"] = True
+    if kw["codes"].max() >= 12:
+        refused(packed_code_out_of_range)
+
+    def global_sizes_too_small(b):
+        sizes = (b["leaf_offsets"][1:] - b["leaf_offsets"][:-1]).astype(np.uint32)
+        sizes[0] -= 1
+        b["leaf_sizes_global"] = sizes
+    refused(global_sizes_too_small)
+
+    # AsymmetricHasher mode reads data row i for point i: fewer rows than points is refused
+    rows2, data2, stride2, ix2, kw2 = H.make_ah_case(300, 64, 8, seed=4, pq_iters=2)
+    bad = dict(kw2, data=np.ascontiguousarray(np.asarray(data2).reshape(300, stride2)[:200]), n_rows=200)
+    with pytest.raises(hip.ScannError) as e:
+        hip.txh_create(**bad)
+    assert e.value.code == hip.INVALID_ARGUMENT
+    # a header whose n_rows was lowered after writing (sizes of every section still consistent
+    # with the data section being absent is not possible: tamper n_rows and the data section length)
+    p = str(tmp_path / "ah.scannidx")
+    hip.txh_write_file(p, **bad)
+    with pytest.raises(hip.ScannError) as e:
+        hip.load_file(p)
+    assert e.value.code == DATA_LOSS
+
+
+@pytest.mark.gpu
+def test_pair_table_overflow_is_reported():
+    """batch x partitions_to_search beyond 2^32 pair slots: ResourceExhausted, not a wrapped size."""
+    rows, data, stride, ix, oix, kw = H.make_txh_case(9000, 16, 4200, 8, seed=2, P=4, kmeans_iters=1,
+                                                      pq_iters=1)
+    index = hip.txh_create(**kw)
+    o = hip.default_opts()
+    o.partitions_to_search = 4096
+    with pytest.raises(hip.ScannError) as e:
+        hip.check(hip.load().scann_hip_index_reserve(index.h, 1 << 21, 10, o))
+    assert e.value.code == hip.RESOURCE_EXHAUSTED
