@@ -469,7 +469,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0].item())
     qps = Q * args.steps * (nproc if replica else 1) / elapsed
-    last_out = outs[(args.steps - 1) & 1]
+    last_out = tuple(t.clone() for t in outs[(args.steps - 1) & 1])   # the sweep below reuses the buffers
     last_q = queries_all[((args.steps - 1) % nbatches) * Q:][:Q]
 
     # ---------------- batch-size sweep (batches {1, 100, 1024}, >= 10 reps, median) -----------
