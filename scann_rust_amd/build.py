@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libscann_hip.so")
-SOURCES = ["api.hip", "txh.hip", "bf.hip", "index_file.hip", "comm.hip", "scan_mfma.hip"]
+SOURCES = ["api.hip", "txh.hip", "bf.hip", "index_file.hip", "comm.hip"]
 HEADERS = ["common.h", "txh.h", "bf.h", "comm.h", os.path.join("..", "..", "include", "scann_hip.h")]
 # -ffp-contract=off: the reference never contracts a*b+c (Rust); FMA is used only via
 # explicit fmaf()/MFMA where the reference uses _mm256_fmadd_ps.

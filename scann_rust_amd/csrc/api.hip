@@ -40,7 +40,7 @@ struct TxhWorkspace {
     DevBuf queries, cdist, tokens, token_dists, vbase, leaf_cnt, leaf_cursor, pair_off, tile_off,
         counters, pair_q, pair_leaf, pair_vbase, pair_thr, slot_of, lutq, thr, cand_cnt, cand, cand_key,
         cand_idx, cand_dist, cand_exact, cand_row, cand_count, out_idx, out_dist, out_count, allow,
-        sbase, pair_sbase, stile_off, samp;
+        sbase, pair_sbase, stile_off, samp, lut8, lut8_meta, cand32, cand32_cnt;
 };
 
 // An extra stream + workspaces: host-side searches of concurrent caller threads (Searcher: Send +
@@ -620,6 +620,36 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
             if (v == 2) w->resident = (t.code_bits == 4 && t.S <= 32) ? 1u : 0u;
         }
         if (const char *e = std::getenv("SCANN_HIP_RES_CL")) w->res_cl = (uint32_t)std::max(1, std::atoi(e));
+        // Integer-MFMA prefilter + exact refine (txh.hip K6d): 4-bit codes, a filter bound to prove
+        // against, and enough pairs per leaf to fill 32-column MFMA tiles (a leaf scanned by few
+        // queries would leave most columns empty; the LDS-gather kernels take those).
+        w->mfma = (t.code_bits == 4 && !p.no_threshold && !t.exact_scan && quads_per_leaf >= 6) ? 1u : 0u;
+        // SCANN_HIP_MFMA: 0 = never, 2 = whenever the code layout allows (tests), else the heuristic
+        if (const char *e = std::getenv("SCANN_HIP_MFMA")) {
+            const int v = std::atoi(e);
+            if (v == 0) w->mfma = 0u;
+            if (v == 2) w->mfma = (t.code_bits == 4 && !p.no_threshold && !t.exact_scan) ? 1u : 0u;
+        }
+        if (w->mfma) w->resident = 0u;
+    }
+    w->lut8 = nullptr;
+    w->lut8_meta = nullptr;
+    w->cand32 = nullptr;
+    w->cand32_cnt = nullptr;
+    w->cap32 = 0;
+    if (w->mfma) {
+        // survivors of the integer bound: the f32 filter's (<= cap) plus the quantisation margin
+        const uint64_t ms2 = std::min<uint64_t>(std::max<uint64_t>(1, max_stream(ix, P)), 0xFFFFFFFFull);
+        const uint64_t cap32 = std::min<uint64_t>(ms2, (uint64_t)p.cap * 2 + 2048);
+        SCANN_TRY(s.lut8.ensure((size_t)max_slots * t.S * 16 + 64));
+        SCANN_TRY(s.lut8_meta.ensure((size_t)(max_slots + 4) * 16));
+        SCANN_TRY(s.cand32.ensure((size_t)nq * cap32 * 4));
+        SCANN_TRY(s.cand32_cnt.ensure((size_t)nq * 4));
+        w->lut8 = s.lut8.as<int8_t>();
+        w->lut8_meta = s.lut8_meta.p;
+        w->cand32 = s.cand32.as<uint32_t>();
+        w->cand32_cnt = s.cand32_cnt.as<uint32_t>();
+        w->cap32 = (uint32_t)cap32;
     }
     w->sbase = s.sbase.as<uint32_t>();
     w->pair_sbase = s.pair_sbase.as<uint32_t>();
@@ -754,7 +784,7 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
         SCANN_TRY(txh_launch_search(ix->tx, w, false, stream, sl.primary ? ix->ev0 : nullptr,
                                     sl.primary ? ix->ev1 : nullptr));
         if (sl.primary) ix->timing_valid = ix->timing;
-        if (sl.primary) ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
+        if (sl.primary) ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.mfma ? "adc_mfma_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
         uint32_t counters[CNT_N];
         SCANN_HIP_CHECK(hipMemcpyAsync(counters, w.counters, sizeof(counters), hipMemcpyDeviceToHost,
                                        stream));
@@ -888,7 +918,7 @@ int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries,
     SCANN_TRY(txh_launch_search(ix->tx, w, false, st, ix->ev0,
                                 ix->ev1));
     ix->timing_valid = ix->timing;
-    ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
+    ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.mfma ? "adc_mfma_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
     return SCANN_HIP_OK;
 }
 
@@ -940,7 +970,7 @@ int scann_hip_txh_search_local_device(scann_hip_index *ix, const float *d_querie
     SCANN_TRY(txh_launch_search(ix->tx, w, true, st, ix->ev0,
                                 ix->ev1));
     ix->timing_valid = ix->timing;
-    ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
+    ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.mfma ? "adc_mfma_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
     return SCANN_HIP_OK;
 }
 

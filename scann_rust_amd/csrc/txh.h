@@ -128,6 +128,12 @@ struct TxhWork {
     uint32_t st, scap, sqpt;   // sample stride, per-query sample capacity, quads per sample tile
     uint32_t qpt;              // quads per scan tile
     uint32_t resident, res_cl; // resident-table scan kernel (long leaves) and its chunks per tile
+    uint32_t mfma;             // integer-MFMA prefilter + exact refine instead of the f32 LDS-gather scan
+    int8_t *lut8;              // [max_slots][S][16] quantised tables (value - 128)
+    void *lut8_meta;           // [max_slots] {f64 bias_sum, f64 scale}
+    uint32_t *cand32_cnt;      // [nq]
+    uint32_t *cand32;          // [nq][cap32] stream positions of the prefilter's survivors
+    uint32_t cap32;
     uint32_t *sbase;           // [nq][P+2] prefix of per-leaf sample counts; [P]=samples, [P+1]=local points
     uint32_t *pair_sbase;      // [max_slots]
     uint32_t *stile_off;       // [L+1] tile table of the sample pass

@@ -203,13 +203,16 @@ __global__ void ah_tokens_kernel(uint32_t nq, const uint32_t *__restrict__ leaf_
 __global__ void txh_init_kernel(uint32_t L, uint32_t nq, uint32_t max_slots,
                                 uint32_t *__restrict__ leaf_cnt, uint32_t *__restrict__ leaf_cursor,
                                 uint32_t *__restrict__ counters, uint32_t *__restrict__ cand_cnt,
-                                uint32_t *__restrict__ pair_q) {
+                                uint32_t *__restrict__ cand32_cnt, uint32_t *__restrict__ pair_q) {
     const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
     for (uint32_t i = i0; i < L; i += step) {
         leaf_cnt[i] = 0;
         leaf_cursor[i] = 0;
     }
-    for (uint32_t i = i0; i < nq; i += step) cand_cnt[i] = 0;
+    for (uint32_t i = i0; i < nq; i += step) {
+        cand_cnt[i] = 0;
+        if (cand32_cnt) cand32_cnt[i] = 0;
+    }
     for (uint32_t i = i0; i < max_slots; i += step) pair_q[i] = kInvalid;
     for (uint32_t i = i0; i < CNT_WORDS; i += step) counters[i] = 0;
 }
@@ -929,6 +932,340 @@ __global__ __launch_bounds__(kResThreads, 6) void adc_scan_res_kernel(TxhIndexDe
 }
 
 // =====================================================================================
+// K6d: ADC scan as an integer-MFMA prefilter + exact refine (4-bit codes, threshold known).
+//
+// The f32 scan above is bound by the LDS table gather (one ds_read_b128 per point, subspace and
+// quad of queries).  The same sums over QUANTISED tables are a matrix product:
+//     one-hot(codes) [points x (S*16)]  x  lut8 [(S*16) x pairs]   (u8 tables as i8 minus 128)
+// which v_mfma_i32_32x32x32_i8 computes exactly (integer) at 1024 MAC/clk/SIMD: a 32-point x
+// 32-pair tile costs S/2 MFMAs.  The integer sum BOUNDS the reference's f32 sum: with per-subspace
+// offsets mn_s and one scale sc per pair, every table entry v satisfies |v - (mn_s + sc*q)| <=
+// sc*(0.5 + 1e-9), so a point whose f32 sum passes the filter bound T has
+//     sum_q <= (T*(1 + S*2^-23) - sum mn_s)/sc + S/2 + 1
+// (the factor covers the rounding of the sequential f32 adds of non-negative terms).  Points under
+// that integer bound -- the true survivors plus ~10 % -- are listed per query as stream positions,
+// and adc_refine_kernel recomputes THEIR distances with the reference's arithmetic (f32 tables,
+// subspace order: hashes/lut.rs:74-82), forms the merge keys and applies the exact filter.  The
+// candidate lists handed to select_rerank_kernel are therefore identical to adc_scan_kernel's:
+// the same shortlist-plus-proof pattern as the bf16 brute-force pass (bf.hip).
+//
+// Work decomposition: every WAVE pulls its own items (leaf, tile of 32 pair slots, range of
+// kMfmaRange points) from the tile queues; the pair tile's tables are the wave's B fragments for
+// the whole item (S/2 x 4 VGPRs), the A fragment of a (point, subspace pair) is one row of a
+// 16 x 16-byte identity table in LDS (one conflict-free ds_read_b128 at offset code * 16), the
+// 16 results of a lane belong to ONE pair (column) and are compared with that pair's bound.
+// Survivors are staged per (wave, pair) in LDS and written at the end of the item as one
+// contiguous segment per pair behind ONE returning atomic per pair.
+// =====================================================================================
+constexpr uint32_t kDecodeStage = 512;    // selected leaves whose decode tables are staged in LDS
+constexpr uint32_t kMfmaRange = 2048;     // points per item
+constexpr uint32_t kMfmaStage = 56;       // staged survivors per (wave, pair)
+constexpr uint32_t kMfmaWaves = 4;        // waves per workgroup
+constexpr uint32_t kRefineTablesMax = 40; // pair tables (2 KB each at S = 32) staged in LDS by the refine
+
+struct Lut8Meta {
+    double bias_sum;   // sum over subspaces of the per-subspace minimum
+    double scale;      // table step; 0 = this pair is not prefiltered (every point passes)
+};
+
+// lutq [quad][s][16][4] f32 -> lut8 [slot][s][16] i8 (quantised value - 128) + meta[slot]
+__global__ __launch_bounds__(256) void lut8_build_kernel(uint32_t S, const float *__restrict__ lutq,
+                                                        const uint32_t *__restrict__ counters,
+                                                        int8_t *__restrict__ lut8, Lut8Meta *__restrict__ meta) {
+    __shared__ float s_min[4][64], s_rng[4][64];
+    __shared__ double s_scale[4];
+    __shared__ int s_bad[4];
+    const uint32_t quad = blockIdx.x, tid = threadIdx.x;
+    if (quad >= counters[CNT_TOTAL_QUADS]) return;
+    const float4 *src = reinterpret_cast<const float4 *>(lutq) + (size_t)quad * S * 16;
+    if (tid < 4) s_bad[tid] = 0;
+    __syncthreads();
+    const uint32_t p = tid & 3u, sub = tid >> 2;    // thread = (pair of the quad, subspace)
+    float v[16];
+    if (sub < S) {
+        float mn = __builtin_inff(), mx = -__builtin_inff();
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float4 e = src[sub * 16 + c];
+            const float x = p == 0 ? e.x : p == 1 ? e.y : p == 2 ? e.z : e.w;
+            v[c] = x;
+            bad = bad || !(x >= 0.0f) || !(x < __builtin_inff());   // NaN, negative, infinite
+            mn = fminf(mn, x);
+            mx = fmaxf(mx, x);
+        }
+        s_min[p][sub] = mn;
+        s_rng[p][sub] = mx - mn;
+        if (bad) atomicOr(&s_bad[p], 1);
+    }
+    __syncthreads();
+    if (tid < 4) {
+        double bias = 0.0;
+        float r = 0.0f;
+        for (uint32_t j = 0; j < S; ++j) {
+            bias += (double)s_min[tid][j];
+            r = fmaxf(r, s_rng[tid][j]);
+        }
+        const double sc = (s_bad[tid] || !(r > 0.0f)) ? 0.0 : (double)r / 255.0;
+        s_scale[tid] = sc;
+        Lut8Meta m;
+        m.bias_sum = bias;
+        m.scale = sc;
+        meta[(size_t)quad * 4 + tid] = m;
+    }
+    __syncthreads();
+    if (sub < S) {
+        const double sc = s_scale[p], mn = (double)s_min[p][sub];
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            int q = 0;
+            if (sc > 0.0) {
+                const double t = ((double)v[c] - mn) / sc;
+                q = (int)floor(t + 0.5);
+                q = q < 0 ? 0 : (q > 255 ? 255 : q);
+            }
+            w[c >> 2] |= (uint32_t)((q - 128) & 0xFF) << (8 * (c & 3));
+        }
+        *reinterpret_cast<uint4 *>(lut8 + (((size_t)quad * 4 + p) * S + sub) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+struct MfmaArgs {
+    const uint32_t *pair_off, *tile_off, *pair_q, *pair_vbase;
+    uint32_t *counters;
+    const int8_t *lut8;
+    const Lut8Meta *meta;
+    const uint64_t *pair_thr;
+    uint32_t *cand32_cnt;     // [nq]
+    uint32_t *cand32;         // [nq][cap32] stream positions of the prefilter's survivors
+    uint32_t cap32;
+};
+
+template <int S_>
+__global__ __launch_bounds__(kMfmaWaves * 64, 2) void adc_mfma_kernel(TxhIndexDev ix, MfmaArgs a) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef int v16i __attribute__((ext_vector_type(16)));
+    constexpr int S = S_, KS = S / 2, NW = S / 8;
+    __shared__ __attribute__((aligned(16))) uint32_t s_ident[64];                 // 16 one-hot rows of 16 bytes
+    __shared__ uint32_t s_stage[kMfmaWaves][32][kMfmaStage];
+    __shared__ uint32_t s_cnt[kMfmaWaves][32];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t col = lane & 31u, h = lane >> 5;
+    // row c (16 bytes = words 4c .. 4c+3): byte c set to 1  ->  word 4c + (c >> 2) holds 1 << 8*(c & 3)
+    if (tid < 64) {
+        const uint32_t c = tid >> 2, wsel = tid & 3u;
+        s_ident[tid] = (wsel == (c >> 2)) ? (1u << (8 * (c & 3u))) : 0u;
+    }
+    __syncthreads();
+    const uint32_t total_tiles = a.counters[CNT_TOTAL_TILES];
+    const char *ident = reinterpret_cast<const char *>(s_ident);
+
+    for (;;) {
+        uint32_t tile = 0;
+        if (lane == 0) tile = grab_tile(a.counters + CNT_XQ, total_tiles);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile == kInvalid) break;
+        uint32_t lo = 0, hi = ix.L;            // leaf = largest l with tile_off[l] <= tile
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (uniform_load(a.tile_off + mid) <= tile) lo = mid; else hi = mid;
+        }
+        const uint32_t leaf = lo;
+        const uint32_t lb = uniform_load(ix.leaf_off + leaf);
+        const uint32_t size = uniform_load(ix.leaf_off + leaf + 1) - lb;
+        const uint32_t nranges = (size + kMfmaRange - 1) / kMfmaRange;
+        const uint32_t local = tile - uniform_load(a.tile_off + leaf);
+        const uint32_t range = local % nranges, pt = local / nranges;
+        const uint32_t slot0 = uniform_load(a.pair_off + leaf);
+        const uint32_t slot_end = uniform_load(a.pair_off + leaf + 1);
+        const uint32_t c0 = range * kMfmaRange;
+        const uint32_t npts = min(kMfmaRange, size - c0);
+
+        // this lane's pair (column): tables, bound, key base
+        const uint32_t slot = slot0 + pt * 32u + col;
+        const bool pair_ok = slot < slot_end;
+        const uint32_t pq = pair_ok ? a.pair_q[slot] : kInvalid;
+        const uint32_t vb = pair_ok ? a.pair_vbase[slot] : 0u;
+        v4i b[KS];
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            b[t] = v4i{0, 0, 0, 0};
+            if (pair_ok) b[t] = *reinterpret_cast<const v4i *>(a.lut8 + ((size_t)slot * S + 2 * t + h) * 16);
+        }
+        int thr = -2147483647 - 1;             // nothing passes (padding slots)
+        if (pq != kInvalid) {
+            const uint64_t T = a.pair_thr[slot];
+            const Lut8Meta m = a.meta[slot];
+            thr = 2147483647;                  // everything passes (no bound, or a table that is not quantised)
+            if (T != SCANN_KEY_MAX && m.scale > 0.0) {
+                const double Tf = (double)ordered_to_f32((uint32_t)(T >> 32));
+                const double qmax = floor((Tf * (1.0 + (double)S * 1.1920928955078125e-07) - m.bias_sum) / m.scale +
+                                          0.5 * (double)S + 1.0) - 128.0 * (double)S;
+                thr = qmax >= 2147483647.0 ? 2147483647 : (qmax <= -2147483648.0 ? (-2147483647 - 1) : (int)qmax);
+            }
+        }
+        if (lane < 32) s_cnt[wave][lane] = 0;
+        // (s_cnt / s_stage are private to the wave: no workgroup barrier anywhere in this loop)
+
+        const uint32_t ntile = (npts + 31u) >> 5;
+        uint32_t wn[NW];
+        {
+            const uint32_t j = c0 + col;
+            Codec<S, 4>::load_words(ix.codes + (size_t)(lb + (j < size ? j : 0u)) * NW, wn);
+        }
+        for (uint32_t tl = 0; tl < ntile; ++tl) {
+            // nibbles of this lane's subspace parity h, pre-shifted to byte offsets code * 16
+            uint32_t rg[NW];
+#pragma unroll
+            for (int wi = 0; wi < NW; ++wi) rg[wi] = h ? (wn[wi] & 0xF0F0F0F0u) : ((wn[wi] & 0x0F0F0F0Fu) << 4);
+            if (tl + 1 < ntile) {
+                const uint32_t j = c0 + (tl + 1) * 32u + col;
+                Codec<S, 4>::load_words(ix.codes + (size_t)(lb + (j < size ? j : 0u)) * NW, wn);
+            }
+            v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+                const uint32_t off = (rg[t >> 2] >> (8 * (t & 3))) & 0xFFu;     // code * 16 of subspace 2t + h
+                const v4i av = *reinterpret_cast<const v4i *>(ident + off);
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[t], acc, 0, 0, 0);
+            }
+            // lane (col, h), register r: point row (r & 3) + 8 * (r >> 2) + 4 * h of the tile
+            const uint32_t base = c0 + tl * 32u + 4u * h;
+            const uint32_t lim = size;         // rows at or past the leaf's end are padding
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t j = base + (uint32_t)((r & 3) + 8 * (r >> 2));
+                if (acc[r] <= thr && j < lim) {
+                    const uint32_t sl = atomicAdd(&s_cnt[wave][col], 1u);
+                    if (sl < kMfmaStage) {
+                        s_stage[wave][col][sl] = j;
+                    } else {   // stage full: direct (slow) append
+                        const uint32_t pos = atomicAdd(&a.cand32_cnt[pq], 1u);
+                        if (pos < a.cap32) a.cand32[(size_t)pq * a.cap32 + pos] = vb + j;
+                    }
+                }
+            }
+        }
+        // flush: one returning atomic per pair, then one contiguous segment per pair
+        uint32_t n = 0, gbase = 0;
+        if (lane < 32) {
+            n = min(s_cnt[wave][lane], kMfmaStage);
+            if (n) gbase = atomicAdd(&a.cand32_cnt[pq], n);
+        }
+        for (uint32_t c = 0; c < 32; ++c) {
+            const uint32_t nc = (uint32_t)__shfl((int)n, (int)c);
+            if (nc == 0) continue;             // wave-uniform
+            const uint32_t bc = (uint32_t)__shfl((int)gbase, (int)c);
+            const uint32_t qc = (uint32_t)__shfl((int)pq, (int)c);
+            const uint32_t vc = (uint32_t)__shfl((int)vb, (int)c);
+            if (lane < nc && bc + lane < a.cap32) a.cand32[(size_t)qc * a.cap32 + bc + lane] = vc + s_stage[wave][c][lane];
+        }
+    }
+}
+
+// Exact refine of the prefilter's survivors: block per query.  Recomputes the reference's f32 sums
+// (LookupTable::compute_distance, hashes/lut.rs:74-82: acc = lut[0][c0]; acc += lut[s][cs], s
+// ascending), forms the merge keys and keeps key <= T -- exactly adc_scan_kernel's survivors.
+struct RefineArgs {
+    uint32_t P, cap, cap32;
+    const uint32_t *tokens, *vbase, *slot_of;
+    const float *lutq;
+    const uint64_t *thr;
+    const uint32_t *cand32_cnt, *cand32;
+    uint32_t *cand_cnt;
+    uint64_t *cand;
+    uint32_t *counters;
+    const uint64_t *allow;
+    uint64_t allow_bits;
+};
+
+template <typename C>
+__global__ __launch_bounds__(256) void adc_refine_kernel(TxhIndexDev ix, RefineArgs a) {
+    constexpr int S = C::S, NW = C::NWORDS;
+    extern __shared__ __attribute__((aligned(16))) float s_tab[];       // [min(P, kRefineTablesMax)][S][16]
+    __shared__ uint32_t s_dvb[kDecodeStage], s_drow[kDecodeStage], s_slot[kDecodeStage], s_out;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t P = a.P;
+    const uint32_t cnt = a.cand32_cnt[q];
+    if (cnt > a.cap32) {   // list overflow: report, never a wrong row
+        if (tid == 0) {
+            atomicMax(&a.counters[CNT_STATUS], (uint32_t)SCANN_HIP_RESOURCE_EXHAUSTED);
+            a.cand_cnt[q] = a.cap + 1u;
+        }
+        return;
+    }
+    const uint64_t T = a.thr[q];
+    const bool staged = P <= kDecodeStage;
+    const bool tabs = P <= kRefineTablesMax;
+    const uint32_t *vbq = a.vbase + (size_t)q * (P + 1);
+    if (staged)
+        for (uint32_t r = tid; r < P; r += 256) {
+            s_dvb[r] = vbq[r];
+            s_drow[r] = ix.leaf_off[a.tokens[(size_t)q * P + r]];
+            s_slot[r] = a.slot_of[(size_t)q * P + r];
+        }
+    if (tid == 0) s_out = 0;
+    __syncthreads();
+    if (tabs) {   // this query's pair tables, de-interleaved: [r][s][16]
+        for (uint32_t e = tid; e < P * S * 16; e += 256) {
+            const uint32_t r = e / (S * 16), sc = e - r * (S * 16);
+            const uint32_t slot = staged ? s_slot[r] : a.slot_of[(size_t)q * P + r];
+            s_tab[e] = slot == kInvalid ? 0.0f : a.lutq[((size_t)(slot >> 2) * S * 16 + sc) * 4 + (slot & 3u)];
+        }
+        __syncthreads();
+    }
+    uint64_t *out = a.cand + (size_t)q * a.cap;
+    const uint32_t *list = a.cand32 + (size_t)q * a.cap32;
+    for (uint32_t b0 = 0; b0 < cnt; b0 += 256) {
+        const uint32_t e = b0 + tid;
+        bool keep = false;
+        uint64_t key = 0;
+        if (e < cnt) {
+            const uint32_t vpos = list[e];
+            uint32_t lo = 0, hi = P;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((staged ? s_dvb[mid] : vbq[mid]) <= vpos) lo = mid; else hi = mid;
+            }
+            const uint32_t csr = (staged ? s_drow[lo] : ix.leaf_off[a.tokens[(size_t)q * P + lo]]) +
+                                 (vpos - (staged ? s_dvb[lo] : vbq[lo]));
+            uint32_t w[NW];
+            C::load_words(ix.codes + (size_t)csr * NW, w);
+            float acc = 0.0f;
+            if (tabs) {
+                const float *tb = s_tab + lo * (S * 16);
+#pragma unroll
+                for (int s2 = 0; s2 < S; ++s2) {
+                    const uint32_t code = (w[s2 >> 3] >> (4 * (s2 & 7))) & 15u;
+                    const float tv = tb[s2 * 16 + code];
+                    acc = s2 == 0 ? tv : acc + tv;
+                }
+            } else {
+                const uint32_t slot = staged ? s_slot[lo] : a.slot_of[(size_t)q * P + lo];
+                const float *tb = a.lutq + (size_t)(slot >> 2) * S * 64 + (slot & 3u);
+#pragma unroll 8
+                for (int s2 = 0; s2 < S; ++s2) {
+                    const uint32_t code = (w[s2 >> 3] >> (4 * (s2 & 7))) & 15u;
+                    const float tv = tb[(s2 * 16 + code) * 4];
+                    acc = s2 == 0 ? tv : acc + tv;
+                }
+            }
+            key = make_key(acc, vpos);
+            keep = key <= T && row_allowed(ix, a.allow, a.allow_bits, csr);
+        }
+        uint32_t wtot;
+        const uint32_t wpre = wave_prefix_count(keep, &wtot);
+        uint32_t base = 0;
+        if (lane == 0 && wtot) base = atomicAdd(&s_out, wtot);
+        base = (uint32_t)__shfl((int)base, 0);
+        if (keep && base + wpre < a.cap) out[base + wpre] = key;
+    }
+    __syncthreads();
+    if (tid == 0) a.cand_cnt[q] = s_out;   // > cap: select_rerank reports the overflow
+}
+
+// =====================================================================================
 // K5: threshold from a strided sample (plan: sample_stride / sample_plan / sample_rank).
 //
 // K5a adc_sample_kernel: the scan's tiled LUT16 gather over every st-th point of each
@@ -1318,7 +1655,6 @@ __global__ __launch_bounds__(256) void leaf_exact_scan_kernel(TxhIndexDev ix, Ex
 //   reference's AVX2 arithmetic (simd/x86.rs:139-165: 8 FMA lane chains, fixed hsum
 //   tree, scalar tail) -> stable sort by exact -> first k.
 // =====================================================================================
-constexpr uint32_t kDecodeStage = 512;   // selected leaves whose decode tables are staged in LDS
 
 struct SelectArgs {
     uint32_t P, m, k, cap;
@@ -2111,6 +2447,31 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
                            w.no_threshold, w.sbase, w.samp, w.scap, w.slot_of, w.thr, w.pair_thr);
         LAUNCH_CHECK();
     }
+    if constexpr (C::BITS == 4) {
+        if (w.mfma) {
+            hipLaunchKernelGGL(lut8_build_kernel, dim3(w.max_quads), dim3(256), 0, st, (uint32_t)C::S, w.lutq,
+                               w.counters, w.lut8, reinterpret_cast<Lut8Meta *>(w.lut8_meta));
+            LAUNCH_CHECK();
+            MfmaArgs ma;
+            ma.pair_off = w.pair_off; ma.tile_off = w.tile_off; ma.pair_q = w.pair_q; ma.pair_vbase = w.pair_vbase;
+            ma.counters = w.counters; ma.lut8 = w.lut8; ma.meta = reinterpret_cast<const Lut8Meta *>(w.lut8_meta);
+            ma.pair_thr = w.pair_thr; ma.cand32_cnt = w.cand32_cnt; ma.cand32 = w.cand32; ma.cap32 = w.cap32;
+            if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
+            hipLaunchKernelGGL(adc_mfma_kernel<C::S>, dim3((uint32_t)cus * 2u), dim3(kMfmaWaves * 64), 0, st, ix, ma);
+            LAUNCH_CHECK();
+            if (ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
+            RefineArgs ra;
+            ra.P = w.P; ra.cap = w.cap; ra.cap32 = w.cap32; ra.tokens = w.tokens; ra.vbase = w.vbase;
+            ra.slot_of = w.slot_of; ra.lutq = w.lutq; ra.thr = w.thr; ra.cand32_cnt = w.cand32_cnt;
+            ra.cand32 = w.cand32; ra.cand_cnt = w.cand_cnt; ra.cand = w.cand; ra.counters = w.counters;
+            ra.allow = w.allow; ra.allow_bits = w.allow_bits;
+            const size_t lds_rf = w.P <= kRefineTablesMax ? (size_t)w.P * C::S * 16 * sizeof(float) : 16;
+            SCANN_TRY(set_dyn_lds(adc_refine_kernel<C>, lds_rf));
+            hipLaunchKernelGGL(adc_refine_kernel<C>, dim3(w.nq), dim3(256), lds_rf, st, ix, ra);
+            LAUNCH_CHECK();
+            return SCANN_HIP_OK;
+        }
+    }
     ScanArgs a;
     a.pair_off = w.pair_off; a.tile_off = w.tile_off; a.pair_q = w.pair_q;
     a.pair_vbase = w.pair_vbase; a.counters = w.counters; a.lutq = w.lutq; a.pair_thr = w.pair_thr;
@@ -2186,7 +2547,7 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
         const uint32_t work = std::max(std::max(ix.L, w.nq), w.max_slots);
         hipLaunchKernelGGL(txh_init_kernel, dim3(std::min(1024u, ceil_div_u32(work, 256))), dim3(256), 0, st,
                            ix.L, w.nq, w.max_slots, w.leaf_cnt, w.leaf_cursor, w.counters, w.cand_cnt,
-                           w.pair_q);
+                           w.mfma ? w.cand32_cnt : nullptr, w.pair_q);
         LAUNCH_CHECK();
     }
     SCANN_TRY(launch_partition_stage(ix, w, st));
@@ -2197,9 +2558,9 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
     LAUNCH_CHECK();
     hipLaunchKernelGGL(worklist_scan_kernel, dim3(1), dim3(1024), 0, st, ix.L, w.leaf_cnt,
                        ix.leaf_off,
-                       ix.exact_scan ? kExactRows : w.resident ? kResThreads * kScanPPT : scan_tile_points(ix),
-                       ix.exact_scan ? exact_quads_per_tile(ix.dim) : w.resident ? kResQuads : w.qpt,
-                       (w.resident && !ix.exact_scan) ? w.res_cl : 1u, scan_tile_points(ix), w.st,
+                       ix.exact_scan ? kExactRows : w.mfma ? kMfmaRange : w.resident ? kResThreads * kScanPPT : scan_tile_points(ix),
+                       ix.exact_scan ? exact_quads_per_tile(ix.dim) : w.mfma ? 8u : w.resident ? kResQuads : w.qpt,
+                       (w.resident && !ix.exact_scan && !w.mfma) ? w.res_cl : 1u, scan_tile_points(ix), w.st,
                        w.sqpt, w.pair_off, w.tile_off,
                        w.stile_off, w.counters);
     LAUNCH_CHECK();
