@@ -48,6 +48,24 @@ def _stale_objects(force, extra_flags):
     return out
 
 
+def build_variant(name, extra_flags, only=("txh.hip",)):
+    """A tuning variant of the library: `only` sources recompiled with extra -D flags, the other objects
+    reused; written to libscann_hip_<name>.so (select with SCANN_HIP_LIB)."""
+    build()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for s in _sources():
+        if s in only:
+            o = os.path.join(OBJ, os.path.splitext(s)[0] + "_" + name + ".o")
+            subprocess.check_call([hipcc] + CFLAGS + list(extra_flags) + ["-c", "-o", o, os.path.join(CSRC, s)], cwd=CSRC)
+            objs.append(o)
+        else:
+            objs.append(_obj(s))
+    out = os.path.join(HERE, "libscann_hip_%s.so" % name)
+    subprocess.check_call([hipcc] + LDFLAGS + ["-o", out] + objs, cwd=CSRC)
+    return out
+
+
 def build(force=False, verbose=False, extra_flags=()):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -40,7 +40,7 @@ struct TxhWorkspace {
     DevBuf queries, cdist, tokens, token_dists, vbase, leaf_cnt, leaf_cursor, pair_off, tile_off,
         counters, pair_q, pair_leaf, pair_vbase, pair_thr, slot_of, lutq, thr, cand_cnt, cand, cand_key,
         cand_idx, cand_dist, cand_exact, cand_row, cand_count, out_idx, out_dist, out_count, allow,
-        sbase, pair_sbase, stile_off, samp, lut8, lut8_meta, cand32, cand32_cnt;
+        sbase, pair_sbase, stile_off, samp, lut8, lut8_meta, cand32, cand32_cnt, mfma_thr1;
 };
 
 // An extra stream + workspaces: host-side searches of concurrent caller threads (Searcher: Send +
@@ -634,6 +634,7 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
     }
     w->lut8 = nullptr;
     w->lut8_meta = nullptr;
+    w->mfma_thr1 = nullptr;
     w->cand32 = nullptr;
     w->cand32_cnt = nullptr;
     w->cap32 = 0;
@@ -643,10 +644,12 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
         const uint64_t cap32 = std::min<uint64_t>(ms2, (uint64_t)p.cap * 2 + 2048);
         SCANN_TRY(s.lut8.ensure((size_t)max_slots * t.S * 16 + 64));
         SCANN_TRY(s.lut8_meta.ensure((size_t)(max_slots + 4) * 16));
+        SCANN_TRY(s.mfma_thr1.ensure((size_t)(max_slots + 4) * 4));
         SCANN_TRY(s.cand32.ensure((size_t)nq * cap32 * 4));
         SCANN_TRY(s.cand32_cnt.ensure((size_t)nq * 4));
         w->lut8 = s.lut8.as<int8_t>();
         w->lut8_meta = s.lut8_meta.p;
+        w->mfma_thr1 = s.mfma_thr1.as<int>();
         w->cand32 = s.cand32.as<uint32_t>();
         w->cand32_cnt = s.cand32_cnt.as<uint32_t>();
         w->cap32 = (uint32_t)cap32;

@@ -131,6 +131,7 @@ struct TxhWork {
     uint32_t mfma;             // integer-MFMA prefilter + exact refine instead of the f32 LDS-gather scan
     int8_t *lut8;              // [max_slots][S][16] quantised tables (value - 128)
     void *lut8_meta;           // [max_slots] {f64 bias_sum, f64 scale}
+    int *mfma_thr1;            // [max_slots] integer pass bound + 1 of every pair slot
     uint32_t *cand32_cnt;      // [nq]
     uint32_t *cand32;          // [nq][cap32] stream positions of the prefilter's survivors
     uint32_t cap32;

@@ -958,9 +958,19 @@ __global__ __launch_bounds__(kResThreads, 6) void adc_scan_res_kernel(TxhIndexDe
 // contiguous segment per pair behind ONE returning atomic per pair.
 // =====================================================================================
 constexpr uint32_t kDecodeStage = 512;    // selected leaves whose decode tables are staged in LDS
-constexpr uint32_t kMfmaRange = 2048;     // points per item
+#ifndef SCANN_MFMA_RANGE
+#define SCANN_MFMA_RANGE 2048
+#endif
+constexpr uint32_t kMfmaRange = SCANN_MFMA_RANGE;     // points per item
 constexpr uint32_t kMfmaStage = 56;       // staged survivors per (wave, pair)
 constexpr uint32_t kMfmaWaves = 4;        // waves per workgroup
+#ifndef SCANN_MFMA_MINW
+#define SCANN_MFMA_MINW 3
+#endif
+#ifndef SCANN_MFMA_DEPTH
+#define SCANN_MFMA_DEPTH 4
+#endif
+constexpr int kMfmaDepth = SCANN_MFMA_DEPTH;   // one-hot LDS reads in flight per wave
 constexpr uint32_t kRefineTablesMax = 40; // pair tables (2 KB each at S = 32) staged in LDS by the refine
 
 struct Lut8Meta {
@@ -1031,7 +1041,33 @@ __global__ __launch_bounds__(256) void lut8_build_kernel(uint32_t S, const float
     }
 }
 
+// Pass bound of every pair slot on the integer sums (see the derivation above), as thr + 1: a point
+// passes iff acc - thr1 < 0.  Sums lie in [-128 S, 127 S]; the bound is clamped just outside that
+// range (everything passes: no filter bound, or a table that is not quantised; nothing passes:
+// padding slots).
+__global__ void mfma_bounds_kernel(uint32_t nslots, uint32_t S, const uint32_t *__restrict__ pair_q,
+                                   const uint64_t *__restrict__ pair_thr, const Lut8Meta *__restrict__ meta,
+                                   int *__restrict__ thr1) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nslots) return;
+    const int lim = 128 * (int)S + 8;
+    int thr = -lim;
+    if (pair_q[slot] != kInvalid) {
+        const uint64_t T = pair_thr[slot];
+        const Lut8Meta m = meta[slot];
+        thr = lim;
+        if (T != SCANN_KEY_MAX && m.scale > 0.0) {
+            const double Tf = (double)ordered_to_f32((uint32_t)(T >> 32));
+            const double qmax = floor((Tf * (1.0 + (double)S * 1.1920928955078125e-07) - m.bias_sum) / m.scale +
+                                      0.5 * (double)S + 1.0) - 128.0 * (double)S;
+            thr = qmax >= (double)lim ? lim : (qmax <= -(double)lim ? -lim : (int)qmax);
+        }
+    }
+    thr1[slot] = thr + 1;
+}
+
 struct MfmaArgs {
+    const int *thr1;          // [slots] pass bound + 1 (mfma_bounds_kernel)
     const uint32_t *pair_off, *tile_off, *pair_q, *pair_vbase;
     uint32_t *counters;
     const int8_t *lut8;
@@ -1043,7 +1079,7 @@ struct MfmaArgs {
 };
 
 template <int S_>
-__global__ __launch_bounds__(kMfmaWaves * 64, 2) void adc_mfma_kernel(TxhIndexDev ix, MfmaArgs a) {
+__global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) void adc_mfma_kernel(TxhIndexDev ix, MfmaArgs a) {
     typedef int v4i __attribute__((ext_vector_type(4)));
     typedef int v16i __attribute__((ext_vector_type(16)));
     constexpr int S = S_, KS = S / 2, NW = S / 8;
@@ -1061,11 +1097,13 @@ __global__ __launch_bounds__(kMfmaWaves * 64, 2) void adc_mfma_kernel(TxhIndexDe
     const uint32_t total_tiles = a.counters[CNT_TOTAL_TILES];
     const char *ident = reinterpret_cast<const char *>(s_ident);
 
-    for (;;) {
-        uint32_t tile = 0;
-        if (lane == 0) tile = grab_tile(a.counters + CNT_XQ, total_tiles);
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile == kInvalid) break;
+    uint32_t tile = 0;
+    if (lane == 0) tile = grab_tile(a.counters + CNT_XQ, total_tiles);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    while (tile != kInvalid) {
+        // the next item's queue atomic travels while this item is computed
+        uint32_t next_tile = 0;
+        if (lane == 0) next_tile = grab_tile(a.counters + CNT_XQ, total_tiles);
         uint32_t lo = 0, hi = ix.L;            // leaf = largest l with tile_off[l] <= tile
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
@@ -1088,23 +1126,12 @@ __global__ __launch_bounds__(kMfmaWaves * 64, 2) void adc_mfma_kernel(TxhIndexDe
         const uint32_t pq = pair_ok ? a.pair_q[slot] : kInvalid;
         const uint32_t vb = pair_ok ? a.pair_vbase[slot] : 0u;
         v4i b[KS];
+        {
+            const int8_t *bsrc = a.lut8 + ((size_t)(pair_ok ? slot : slot0) * S + h) * 16;   // padding columns: any table
 #pragma unroll
-        for (int t = 0; t < KS; ++t) {
-            b[t] = v4i{0, 0, 0, 0};
-            if (pair_ok) b[t] = *reinterpret_cast<const v4i *>(a.lut8 + ((size_t)slot * S + 2 * t + h) * 16);
+            for (int t = 0; t < KS; ++t) b[t] = *reinterpret_cast<const v4i *>(bsrc + (size_t)t * 32);
         }
-        int thr = -2147483647 - 1;             // nothing passes (padding slots)
-        if (pq != kInvalid) {
-            const uint64_t T = a.pair_thr[slot];
-            const Lut8Meta m = a.meta[slot];
-            thr = 2147483647;                  // everything passes (no bound, or a table that is not quantised)
-            if (T != SCANN_KEY_MAX && m.scale > 0.0) {
-                const double Tf = (double)ordered_to_f32((uint32_t)(T >> 32));
-                const double qmax = floor((Tf * (1.0 + (double)S * 1.1920928955078125e-07) - m.bias_sum) / m.scale +
-                                          0.5 * (double)S + 1.0) - 128.0 * (double)S;
-                thr = qmax >= 2147483647.0 ? 2147483647 : (qmax <= -2147483648.0 ? (-2147483647 - 1) : (int)qmax);
-            }
-        }
+        const int thr1 = pair_ok ? a.thr1[slot] : -(128 * S + 7);   // a point passes iff acc - thr1 < 0
         if (lane < 32) s_cnt[wave][lane] = 0;
         // (s_cnt / s_stage are private to the wave: no workgroup barrier anywhere in this loop)
 
@@ -1114,38 +1141,72 @@ __global__ __launch_bounds__(kMfmaWaves * 64, 2) void adc_mfma_kernel(TxhIndexDe
             const uint32_t j = c0 + col;
             Codec<S, 4>::load_words(ix.codes + (size_t)(lb + (j < size ? j : 0u)) * NW, wn);
         }
-        for (uint32_t tl = 0; tl < ntile; ++tl) {
+        // Software pipeline over the item's tiles, two accumulators: step(t) issues the MFMA chain of tile
+        // t and, between its MFMAs (their shadow hides ~6 vector instructions each), builds the survivor
+        // mask of tile t - 1 from the other accumulator; then the (rare, branchy) survivor staging of
+        // tile t - 1.  One extra step drains the last tile (its MFMAs run on stale codes and are dropped).
+        auto step = [&](v16i &accN, const v16i &accO, uint32_t t) {
             // nibbles of this lane's subspace parity h, pre-shifted to byte offsets code * 16
             uint32_t rg[NW];
 #pragma unroll
             for (int wi = 0; wi < NW; ++wi) rg[wi] = h ? (wn[wi] & 0xF0F0F0F0u) : ((wn[wi] & 0x0F0F0F0Fu) << 4);
-            if (tl + 1 < ntile) {
-                const uint32_t j = c0 + (tl + 1) * 32u + col;
+            if (t + 1 < ntile) {
+                const uint32_t j = c0 + (t + 1) * 32u + col;
                 Codec<S, 4>::load_words(ix.codes + (size_t)(lb + (j < size ? j : 0u)) * NW, wn);
             }
-            v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            accN = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            // A fragments: kMfmaDepth one-hot rows in flight ahead of the MFMA that consumes them
+            constexpr int D = kMfmaDepth < KS ? kMfmaDepth : KS;
+            v4i av[D + 1];
+            auto onehot = [&](int kt) {
+                const uint32_t off = (rg[kt >> 2] >> (8 * (kt & 3))) & 0xFFu;   // code * 16 of subspace 2 kt + h
+                return *reinterpret_cast<const v4i *>(ident + off);
+            };
 #pragma unroll
-            for (int t = 0; t < KS; ++t) {
-                const uint32_t off = (rg[t >> 2] >> (8 * (t & 3))) & 0xFFu;     // code * 16 of subspace 2t + h
-                const v4i av = *reinterpret_cast<const v4i *>(ident + off);
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[t], acc, 0, 0, 0);
+            for (int kt = 0; kt < D; ++kt) av[kt] = onehot(kt);
+            // lane (col, h), register r: point row (r & 3) + 8 * (r >> 2) + 4 * h of the tile.  Survivor
+            // bits of the lane's 16 results without a branch per result (a tile holds ~10 survivors among
+            // 1024 results): v_sub + v_alignbit shift the sign of acc - thr1 into the mask, so result r
+            // ends up at bit 15 - r.
+            uint32_t m16 = 0;
+#pragma unroll
+            for (int kt = 0; kt < KS; ++kt) {
+                if (kt + D < KS) av[(kt + D) % (D + 1)] = onehot(kt + D);
+                accN = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[kt % (D + 1)], b[kt], accN, 0, 0, 0);
+#pragma unroll
+                for (int r = kt * 16 / KS; r < (kt + 1) * 16 / KS; ++r)
+                    m16 = __builtin_amdgcn_alignbit(m16, (uint32_t)(accO[r] - thr1), 31);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // lane (col, h), register r: point row (r & 3) + 8 * (r >> 2) + 4 * h of the tile
-            const uint32_t base = c0 + tl * 32u + 4u * h;
-            const uint32_t lim = size;         // rows at or past the leaf's end are padding
+            if (t == 0) return;                // nothing before the first tile (wave-uniform)
+            const uint32_t base = c0 + (t - 1) * 32u + 4u * h;
+            if (t == ntile && (npts & 31u)) {  // partial last tile: rows past the leaf's end are padding
+                uint32_t okm = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t j = base + (uint32_t)((r & 3) + 8 * (r >> 2));
-                if (acc[r] <= thr && j < lim) {
-                    const uint32_t sl = atomicAdd(&s_cnt[wave][col], 1u);
+                for (int r = 0; r < 16; ++r)
+                    okm |= (base + (uint32_t)((r & 3) + 8 * (r >> 2)) < size ? 1u : 0u) << (15 - r);
+                m16 &= okm;
+            }
+            if (m16) {
+                uint32_t sl = atomicAdd(&s_cnt[wave][col], (uint32_t)__popc(m16));   // one LDS atomic per lane
+                do {
+                    const uint32_t r = 15u - ((uint32_t)__ffs((int)m16) - 1u);
+                    m16 &= m16 - 1u;
+                    const uint32_t j = base + (r & 3u) + ((r >> 2) << 3);
                     if (sl < kMfmaStage) {
                         s_stage[wave][col][sl] = j;
                     } else {   // stage full: direct (slow) append
                         const uint32_t pos = atomicAdd(&a.cand32_cnt[pq], 1u);
                         if (pos < a.cap32) a.cand32[(size_t)pq * a.cap32 + pos] = vb + j;
                     }
-                }
+                    ++sl;
+                } while (m16);
             }
+        };
+        v16i accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA;
+        for (uint32_t tl = 0; tl <= ntile; tl += 2) {
+            step(accA, accB, tl);
+            if (tl + 1 <= ntile) step(accB, accA, tl + 1);
         }
         // flush: one returning atomic per pair, then one contiguous segment per pair
         uint32_t n = 0, gbase = 0;
@@ -1161,6 +1222,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, 2) void adc_mfma_kernel(TxhIndexDe
             const uint32_t vc = (uint32_t)__shfl((int)vb, (int)c);
             if (lane < nc && bc + lane < a.cap32) a.cand32[(size_t)qc * a.cap32 + bc + lane] = vc + s_stage[wave][c][lane];
         }
+        tile = __builtin_amdgcn_readfirstlane(next_tile);
     }
 }
 
@@ -2452,12 +2514,19 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
             hipLaunchKernelGGL(lut8_build_kernel, dim3(w.max_quads), dim3(256), 0, st, (uint32_t)C::S, w.lutq,
                                w.counters, w.lut8, reinterpret_cast<Lut8Meta *>(w.lut8_meta));
             LAUNCH_CHECK();
+            hipLaunchKernelGGL(mfma_bounds_kernel, dim3(ceil_div_u32(w.max_slots, 256)), dim3(256), 0, st, w.max_slots,
+                               (uint32_t)C::S, w.pair_q, w.pair_thr, reinterpret_cast<const Lut8Meta *>(w.lut8_meta),
+                               w.mfma_thr1);
+            LAUNCH_CHECK();
             MfmaArgs ma;
+            ma.thr1 = w.mfma_thr1;
             ma.pair_off = w.pair_off; ma.tile_off = w.tile_off; ma.pair_q = w.pair_q; ma.pair_vbase = w.pair_vbase;
             ma.counters = w.counters; ma.lut8 = w.lut8; ma.meta = reinterpret_cast<const Lut8Meta *>(w.lut8_meta);
             ma.pair_thr = w.pair_thr; ma.cand32_cnt = w.cand32_cnt; ma.cand32 = w.cand32; ma.cap32 = w.cap32;
             if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
-            hipLaunchKernelGGL(adc_mfma_kernel<C::S>, dim3((uint32_t)cus * 2u), dim3(kMfmaWaves * 64), 0, st, ix, ma);
+            uint32_t mwgs = 4;   // workgroups per CU (4 waves each)
+            if (const char *e = std::getenv("SCANN_HIP_MFMA_WGS")) mwgs = (uint32_t)std::max(1, std::atoi(e));
+            hipLaunchKernelGGL(adc_mfma_kernel<C::S>, dim3((uint32_t)cus * mwgs), dim3(kMfmaWaves * 64), 0, st, ix, ma);
             LAUNCH_CHECK();
             if (ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
             RefineArgs ra;
