@@ -83,12 +83,16 @@ def parse():
                    help="N > 1: the leaf-sharded index through the library's RCCL exchange (default), or "
                         "query-parallel replicas of the N = 1 workload")
     p.add_argument("--no-secondary", action="store_true", help="N > 1 shard: skip the replica measurement")
+    p.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    p.add_argument("--force-sharded", action="store_true",
+                   help="rehearsal: run the sharded path (library RCCL exchange included) with however many "
+                        "ranks there are, even one")
     p.add_argument("--m-local", type=int, default=0, help="sharded: candidates sent per (rank, query); 0 = all m")
     p.add_argument("--kmeans-iters", type=int, default=8)
     p.add_argument("--bf-exact", action="store_true",
                    help="bf_dot: exact f32-MFMA kernels only (no bf16 shortlist)")
     a = p.parse_args()
-    sharded = a.gpus > 1 and a.multi_gpu == "shard" and a.workload in (None, "txh")
+    sharded = (a.gpus > 1 or a.force_sharded) and a.multi_gpu == "shard" and a.workload in (None, "txh")
     a.sharded = sharded
     if a.workload is None:
         a.workload = "txh" if sharded else "ah"
@@ -328,6 +332,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if nproc != args.gpus and nproc == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if nproc > 1:
@@ -335,7 +341,7 @@ def main():
         # control plane only (rendezvous, barriers, max over ranks, index broadcast): the data path's
         # collectives are the library's own RCCL calls
         dist.init_process_group("gloo")
-    sharded = args.sharded and nproc > 1
+    sharded = args.sharded and (nproc > 1 or args.force_sharded)
     replica = nproc > 1 and not sharded
 
     L = hip.load()
@@ -355,8 +361,19 @@ def main():
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             uid = torch.frombuffer(bytearray(hip.Comm.unique_id()), dtype=torch.uint8).clone()
-        dist.broadcast(uid, 0)
-        comm = hip.Comm(uid.numpy().tobytes(), rank, nproc, device=local_rank)
+        if nproc > 1:
+            dist.broadcast(uid, 0)
+        # RCCL prints a version banner on STDOUT when the first communicator is created; rank 0's stdout
+        # must carry exactly one JSON line, so the banner is sent to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            comm = hip.Comm(uid.numpy().tobytes(), rank, nproc, device=local_rank)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     elif args.workload == "txh":
         st = build_txh_single(args, torch, hip, device, local_rank, stride)
         index, queries_all, data, codebook, codes = st["index"], st["queries"], st["data"], st["codebook"], st["codes"]
@@ -519,8 +536,11 @@ def main():
             tid = st["ids"][ti.astype(np.int64)].astype(np.int64)         # global datapoint indices
             parts_d = [torch.zeros((ne, k)) for _ in range(nproc)]
             parts_i = [torch.zeros((ne, k), dtype=torch.int64) for _ in range(nproc)]
-            dist.all_gather(parts_d, torch.from_numpy(td.astype(np.float32)))
-            dist.all_gather(parts_i, torch.from_numpy(tid))
+            if nproc > 1:
+                dist.all_gather(parts_d, torch.from_numpy(td.astype(np.float32)))
+                dist.all_gather(parts_i, torch.from_numpy(tid))
+            else:
+                parts_d, parts_i = [torch.from_numpy(td.astype(np.float32))], [torch.from_numpy(tid)]
             if rank == 0:
                 ad = torch.cat(parts_d, 1).numpy()
                 ai = torch.cat(parts_i, 1).numpy()
@@ -538,14 +558,14 @@ def main():
                     for j in range(k):
                         if int(got[i, j]) in pos:
                             ok = ok and gdn[i, j].view(np.uint32) == tdn[i, pos[int(got[i, j])]].view(np.uint32)
-                checked = ok
+                checked = bool(ok)
         elif rank == 0:
             gi, gd, gc = index.search_batched(qe, k, opts)
             bf = hip.bf_create(data, n, dim, stride, hip.SQUARED_L2, device=local_rank)
             ti, td, tc = bf.search_batched(qe, k)
             recall = sum(len(set(gi[i].tolist()) & set(ti[i].tolist())) for i in range(ne)) / float(ne * k)
             bf.close()
-    if rank == 0 and nproc == 1:
+    if rank == 0 and nproc == 1 and not sharded:
         # result rows of the LAST TIMED step checked against the oracle (checker only)
         from oracle import pyoracle as orc
         gi = last_out[0].cpu().numpy().view(np.uint32)
@@ -564,7 +584,7 @@ def main():
 
     # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N = 1) -----------------
     cpu = None
-    if rank == 0 and nproc == 1 and not args.no_cpu_baseline:
+    if rank == 0 and nproc == 1 and not sharded and not args.no_cpu_baseline:
         from oracle import pyoracle as orc
         threads = orc.max_threads()
 
@@ -599,7 +619,7 @@ def main():
 
     # ---------------- the replica layout as a secondary number of the sharded run ---------------------
     secondary = None
-    if sharded and not args.no_secondary:
+    if sharded and nproc > 1 and not args.no_secondary:
         secondary = replica_secondary(args, torch, dist, hip, synth, trainer, device, local_rank, rank, nproc)
 
     if rank == 0:

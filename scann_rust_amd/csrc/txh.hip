@@ -1145,6 +1145,30 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
         // t and, between its MFMAs (their shadow hides ~6 vector instructions each), builds the survivor
         // mask of tile t - 1 from the other accumulator; then the (rare, branchy) survivor staging of
         // tile t - 1.  One extra step drains the last tile (its MFMAs run on stale codes and are dropped).
+        // Staged survivors -> the queries' lists: ONE returning atomic per flushed pair (all of them in one
+        // wave instruction), then one contiguous segment per pair.  all = false flushes only the pairs
+        // whose stage could overflow in the next tile (a tile adds at most 32 per pair): dense pairs --
+        // the nearest leaves of a query, where a large share of the points pass -- flush often, sparse
+        // ones once per item.
+        auto flush = [&](bool all) {
+            uint32_t n = 0, gbase = 0;
+            if (lane < 32) {
+                n = min(s_cnt[wave][lane], kMfmaStage);
+                if (!all && n + 32u <= kMfmaStage) n = 0;
+                if (n) {
+                    gbase = atomicAdd(&a.cand32_cnt[pq], n);
+                    s_cnt[wave][lane] = 0;
+                }
+            }
+            unsigned long long todo = __ballot(n != 0);
+            while (todo) {
+                const int c = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const uint32_t nc = (uint32_t)__shfl((int)n, c), bc = (uint32_t)__shfl((int)gbase, c);
+                const uint32_t qc = (uint32_t)__shfl((int)pq, c), vc = (uint32_t)__shfl((int)vb, c);
+                if (lane < nc && bc + lane < a.cap32) a.cand32[(size_t)qc * a.cap32 + bc + lane] = vc + s_stage[wave][c][lane];
+            }
+        };
         auto step = [&](v16i &accN, const v16i &accO, uint32_t t) {
             // nibbles of this lane's subspace parity h, pre-shifted to byte offsets code * 16
             uint32_t rg[NW];
@@ -1187,6 +1211,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
                     okm |= (base + (uint32_t)((r & 3) + 8 * (r >> 2)) < size ? 1u : 0u) << (15 - r);
                 m16 &= okm;
             }
+            bool risk = false;                 // this lane's pair could overflow its stage in the next tile
             if (m16) {
                 uint32_t sl = atomicAdd(&s_cnt[wave][col], (uint32_t)__popc(m16));   // one LDS atomic per lane
                 do {
@@ -1201,27 +1226,16 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
                     }
                     ++sl;
                 } while (m16);
+                risk = sl + 32u > kMfmaStage;   // (the lane that appended last to a pair saw its full count)
             }
+            if (__any(risk)) flush(false);
         };
         v16i accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA;
         for (uint32_t tl = 0; tl <= ntile; tl += 2) {
             step(accA, accB, tl);
             if (tl + 1 <= ntile) step(accB, accA, tl + 1);
         }
-        // flush: one returning atomic per pair, then one contiguous segment per pair
-        uint32_t n = 0, gbase = 0;
-        if (lane < 32) {
-            n = min(s_cnt[wave][lane], kMfmaStage);
-            if (n) gbase = atomicAdd(&a.cand32_cnt[pq], n);
-        }
-        for (uint32_t c = 0; c < 32; ++c) {
-            const uint32_t nc = (uint32_t)__shfl((int)n, (int)c);
-            if (nc == 0) continue;             // wave-uniform
-            const uint32_t bc = (uint32_t)__shfl((int)gbase, (int)c);
-            const uint32_t qc = (uint32_t)__shfl((int)pq, (int)c);
-            const uint32_t vc = (uint32_t)__shfl((int)vb, (int)c);
-            if (lane < nc && bc + lane < a.cap32) a.cand32[(size_t)qc * a.cap32 + bc + lane] = vc + s_stage[wave][c][lane];
-        }
+        flush(true);
         tile = __builtin_amdgcn_readfirstlane(next_tile);
     }
 }
@@ -1279,49 +1293,61 @@ __global__ __launch_bounds__(256) void adc_refine_kernel(TxhIndexDev ix, RefineA
     }
     uint64_t *out = a.cand + (size_t)q * a.cap;
     const uint32_t *list = a.cand32 + (size_t)q * a.cap32;
-    for (uint32_t b0 = 0; b0 < cnt; b0 += 256) {
-        const uint32_t e = b0 + tid;
-        bool keep = false;
-        uint64_t key = 0;
-        if (e < cnt) {
-            const uint32_t vpos = list[e];
+    constexpr int U = 4;   // entries per thread per pass: their dependent loads (position -> codes) overlap
+    for (uint32_t b0 = 0; b0 < cnt; b0 += 256 * U) {
+        uint32_t vpos[U], csr[U], lo_[U];
+        uint32_t w[U][NW];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t e = b0 + tid + 256u * u;
+            vpos[u] = e < cnt ? list[e] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
             uint32_t lo = 0, hi = P;
+            const uint32_t vp = vpos[u] == 0xFFFFFFFFu ? 0u : vpos[u];
             while (hi - lo > 1) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if ((staged ? s_dvb[mid] : vbq[mid]) <= vpos) lo = mid; else hi = mid;
+                if ((staged ? s_dvb[mid] : vbq[mid]) <= vp) lo = mid; else hi = mid;
             }
-            const uint32_t csr = (staged ? s_drow[lo] : ix.leaf_off[a.tokens[(size_t)q * P + lo]]) +
-                                 (vpos - (staged ? s_dvb[lo] : vbq[lo]));
-            uint32_t w[NW];
-            C::load_words(ix.codes + (size_t)csr * NW, w);
-            float acc = 0.0f;
-            if (tabs) {
-                const float *tb = s_tab + lo * (S * 16);
-#pragma unroll
-                for (int s2 = 0; s2 < S; ++s2) {
-                    const uint32_t code = (w[s2 >> 3] >> (4 * (s2 & 7))) & 15u;
-                    const float tv = tb[s2 * 16 + code];
-                    acc = s2 == 0 ? tv : acc + tv;
-                }
-            } else {
-                const uint32_t slot = staged ? s_slot[lo] : a.slot_of[(size_t)q * P + lo];
-                const float *tb = a.lutq + (size_t)(slot >> 2) * S * 64 + (slot & 3u);
-#pragma unroll 8
-                for (int s2 = 0; s2 < S; ++s2) {
-                    const uint32_t code = (w[s2 >> 3] >> (4 * (s2 & 7))) & 15u;
-                    const float tv = tb[(s2 * 16 + code) * 4];
-                    acc = s2 == 0 ? tv : acc + tv;
-                }
-            }
-            key = make_key(acc, vpos);
-            keep = key <= T && row_allowed(ix, a.allow, a.allow_bits, csr);
+            lo_[u] = lo;
+            csr[u] = (staged ? s_drow[lo] : ix.leaf_off[a.tokens[(size_t)q * P + lo]]) + (vp - (staged ? s_dvb[lo] : vbq[lo]));
+            C::load_words(ix.codes + (size_t)(vpos[u] == 0xFFFFFFFFu ? 0u : csr[u]) * NW, w[u]);
         }
-        uint32_t wtot;
-        const uint32_t wpre = wave_prefix_count(keep, &wtot);
-        uint32_t base = 0;
-        if (lane == 0 && wtot) base = atomicAdd(&s_out, wtot);
-        base = (uint32_t)__shfl((int)base, 0);
-        if (keep && base + wpre < a.cap) out[base + wpre] = key;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bool keep = false;
+            uint64_t key = 0;
+            if (vpos[u] != 0xFFFFFFFFu) {
+                float acc = 0.0f;
+                if (tabs) {
+                    const float *tb = s_tab + lo_[u] * (S * 16);
+#pragma unroll
+                    for (int s2 = 0; s2 < S; ++s2) {
+                        const uint32_t code = (w[u][s2 >> 3] >> (4 * (s2 & 7))) & 15u;
+                        const float tv = tb[s2 * 16 + code];
+                        acc = s2 == 0 ? tv : acc + tv;
+                    }
+                } else {
+                    const uint32_t slot = staged ? s_slot[lo_[u]] : a.slot_of[(size_t)q * P + lo_[u]];
+                    const float *tb = a.lutq + (size_t)(slot >> 2) * S * 64 + (slot & 3u);
+#pragma unroll
+                    for (int s2 = 0; s2 < S; ++s2) {   // (fully unrolled: a dynamic index would push w[] to scratch)
+                        const uint32_t code = (w[u][s2 >> 3] >> (4 * (s2 & 7))) & 15u;
+                        const float tv = tb[(s2 * 16 + code) * 4];
+                        acc = s2 == 0 ? tv : acc + tv;
+                    }
+                }
+                key = make_key(acc, vpos[u]);
+                keep = key <= T && row_allowed(ix, a.allow, a.allow_bits, csr[u]);
+            }
+            uint32_t wtot;
+            const uint32_t wpre = wave_prefix_count(keep, &wtot);
+            uint32_t base = 0;
+            if (lane == 0 && wtot) base = atomicAdd(&s_out, wtot);
+            base = (uint32_t)__shfl((int)base, 0);
+            if (keep && base + wpre < a.cap) out[base + wpre] = key;
+        }
     }
     __syncthreads();
     if (tid == 0) a.cand_cnt[q] = s_out;   // > cap: select_rerank reports the overflow

@@ -1108,3 +1108,48 @@ def test_sharded_search_through_rccl_world1():
         comm.last_status()
     assert e.value.code == 10
     comm.close()
+
+
+# ---- the three scan kernels must produce the same candidate lists ----------------------------------------
+@pytest.mark.parametrize("mode", ["ah", "txh"])
+def test_scan_paths_agree(mode, monkeypatch):
+    """adc_scan_kernel (f32 LDS gather per chunk), adc_scan_res_kernel (resident tables) and the
+    integer-MFMA prefilter + exact refine (adc_mfma_kernel / adc_refine_kernel) are three schedules of the
+    same arithmetic: candidates (approximate distances bitwise, index sets) and final rows must be
+    identical, with a filter bound in force (n >> m) and with an allow-bitmap."""
+    if mode == "ah":
+        rows, data, stride, ix, kw = H.make_ah_case(60000, 128, 32, seed=31, pq_iters=3)
+        o = hip.default_opts()
+        o.pre_reorder_k = 300
+        n = 60000
+    else:
+        rows, data, stride, ix, oix, kw = H.make_txh_case(80000, 96, 20, 24, seed=32, P=6, kmeans_iters=3,
+                                                          pq_iters=3, clustered=True)
+        o = hip.default_opts()
+        o.partitions_to_search, o.pre_reorder_k = 6, 250
+        n = 80000
+    index = hip.txh_create(**kw)
+    q = synth.uniform_f32(96, kw["dim"], 77) if mode == "ah" else synth.clustered_f32(96, 96, 33, n_clusters=20)[0]
+    allow = hip.allow_bitmap(n, np.arange(0, n, 3))
+    got = {}
+    for name, env in (("chunk", {"SCANN_HIP_MFMA": "0", "SCANN_HIP_RESIDENT": "0"}),
+                      ("resident", {"SCANN_HIP_MFMA": "0", "SCANN_HIP_RESIDENT": "2"}),
+                      ("mfma", {"SCANN_HIP_MFMA": "2"})):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        plain = index.search_batched(q, 10, o, stages=True)
+        filt = index.search_batched(q, 10, o, allow=allow)
+        o.allow_bitmap, o.allow_bitmap_bits = None, 0
+        got[name] = (plain, filt)
+        monkeypatch.delenv("SCANN_HIP_RESIDENT", raising=False)
+    ref_plain, ref_filt = got["chunk"]
+    for name in ("resident", "mfma"):
+        plain, filt = got[name]
+        assert np.array_equal(plain[0], ref_plain[0]) and np.array_equal(bits(plain[1]), bits(ref_plain[1])), name
+        assert np.array_equal(plain[2], ref_plain[2]), name
+        (tok, tokd, ci, cd, cc), (rtok, rtokd, rci, rcd, rcc) = plain[3], ref_plain[3]
+        assert np.array_equal(cc, rcc) and np.array_equal(bits(cd), bits(rcd)), name + ": candidate distances"
+        for i in range(q.shape[0]):
+            assert sorted(ci[i, :cc[i]].tolist()) == sorted(rci[i, :rcc[i]].tolist()), name + ": candidate set"
+        assert np.array_equal(filt[0], ref_filt[0]) and np.array_equal(bits(filt[1]), bits(ref_filt[1])), name + " filtered"
+    assert np.all(np.isin(ref_filt[0][ref_filt[0] != 0xFFFFFFFF], np.arange(0, n, 3)))
