@@ -1256,8 +1256,16 @@ struct RefineArgs {
     uint64_t allow_bits;
 };
 
+#ifndef SCANN_REFINE_THREADS
+#define SCANN_REFINE_THREADS 256
+#endif
+#ifndef SCANN_REFINE_U
+#define SCANN_REFINE_U 4
+#endif
+constexpr uint32_t kRefineThreads = SCANN_REFINE_THREADS;
+
 template <typename C>
-__global__ __launch_bounds__(256) void adc_refine_kernel(TxhIndexDev ix, RefineArgs a) {
+__global__ __launch_bounds__(kRefineThreads) void adc_refine_kernel(TxhIndexDev ix, RefineArgs a) {
     constexpr int S = C::S, NW = C::NWORDS;
     extern __shared__ __attribute__((aligned(16))) float s_tab[];       // [min(P, kRefineTablesMax)][S][16]
     __shared__ uint32_t s_dvb[kDecodeStage], s_drow[kDecodeStage], s_slot[kDecodeStage], s_out;
@@ -1276,7 +1284,7 @@ __global__ __launch_bounds__(256) void adc_refine_kernel(TxhIndexDev ix, RefineA
     const bool tabs = P <= kRefineTablesMax;
     const uint32_t *vbq = a.vbase + (size_t)q * (P + 1);
     if (staged)
-        for (uint32_t r = tid; r < P; r += 256) {
+        for (uint32_t r = tid; r < P; r += kRefineThreads) {
             s_dvb[r] = vbq[r];
             s_drow[r] = ix.leaf_off[a.tokens[(size_t)q * P + r]];
             s_slot[r] = a.slot_of[(size_t)q * P + r];
@@ -1284,7 +1292,7 @@ __global__ __launch_bounds__(256) void adc_refine_kernel(TxhIndexDev ix, RefineA
     if (tid == 0) s_out = 0;
     __syncthreads();
     if (tabs) {   // this query's pair tables, de-interleaved: [r][s][16]
-        for (uint32_t e = tid; e < P * S * 16; e += 256) {
+        for (uint32_t e = tid; e < P * S * 16; e += kRefineThreads) {
             const uint32_t r = e / (S * 16), sc = e - r * (S * 16);
             const uint32_t slot = staged ? s_slot[r] : a.slot_of[(size_t)q * P + r];
             s_tab[e] = slot == kInvalid ? 0.0f : a.lutq[((size_t)(slot >> 2) * S * 16 + sc) * 4 + (slot & 3u)];
@@ -1293,13 +1301,13 @@ __global__ __launch_bounds__(256) void adc_refine_kernel(TxhIndexDev ix, RefineA
     }
     uint64_t *out = a.cand + (size_t)q * a.cap;
     const uint32_t *list = a.cand32 + (size_t)q * a.cap32;
-    constexpr int U = 4;   // entries per thread per pass: their dependent loads (position -> codes) overlap
-    for (uint32_t b0 = 0; b0 < cnt; b0 += 256 * U) {
+    constexpr int U = SCANN_REFINE_U;   // entries per thread per pass: their dependent loads (position -> codes) overlap
+    for (uint32_t b0 = 0; b0 < cnt; b0 += kRefineThreads * U) {
         uint32_t vpos[U], csr[U], lo_[U];
         uint32_t w[U][NW];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t e = b0 + tid + 256u * u;
+            const uint32_t e = b0 + tid + kRefineThreads * u;
             vpos[u] = e < cnt ? list[e] : 0xFFFFFFFFu;
         }
 #pragma unroll
@@ -2562,7 +2570,7 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
             ra.allow = w.allow; ra.allow_bits = w.allow_bits;
             const size_t lds_rf = w.P <= kRefineTablesMax ? (size_t)w.P * C::S * 16 * sizeof(float) : 16;
             SCANN_TRY(set_dyn_lds(adc_refine_kernel<C>, lds_rf));
-            hipLaunchKernelGGL(adc_refine_kernel<C>, dim3(w.nq), dim3(256), lds_rf, st, ix, ra);
+            hipLaunchKernelGGL(adc_refine_kernel<C>, dim3(w.nq), dim3(kRefineThreads), lds_rf, st, ix, ra);
             LAUNCH_CHECK();
             return SCANN_HIP_OK;
         }
