@@ -40,7 +40,7 @@ struct TxhWorkspace {
     DevBuf queries, cdist, tokens, token_dists, vbase, leaf_cnt, leaf_cursor, pair_off, tile_off,
         counters, pair_q, pair_leaf, pair_vbase, pair_thr, slot_of, lutq, thr, cand_cnt, cand, cand_key,
         cand_idx, cand_dist, cand_exact, cand_row, cand_count, out_idx, out_dist, out_count, allow,
-        sbase, pair_sbase, stile_off, samp, lut8, lut8_meta, cand32, cand32_cnt, mfma_thr1;
+        sbase, pair_sbase, stile_off, samp, lut8, lut8_meta, cand32, cand32_cnt, mfma_thr1, rr_lb, rr_ub;
 };
 
 // An extra stream + workspaces: host-side searches of concurrent caller threads (Searcher: Send +
@@ -85,7 +85,7 @@ struct scann_hip_index {
 
     // ---- tree-x-hybrid / AH ----
     TxhIndexDev tx{};
-    DevBuf d_centers, d_leaf_off, d_leaf_gsize, d_leaf_ids, d_codes, d_rows, d_codebook;
+    DevBuf d_centers, d_leaf_off, d_leaf_gsize, d_leaf_ids, d_codes, d_rows, d_codebook, d_rows8, d_rows8_meta;
     std::vector<uint32_t> local_sizes_desc;  // local leaf sizes, descending, prefix-summed
     uint32_t default_P = 0;
     float multiplier = 3.0f;
@@ -426,6 +426,26 @@ int scann::txh_create_checked(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, s
     t.measure = d->distance_measure;
     t.exact_scan = exact ? 1 : 0;
     t.rows = d->data ? ix->d_rows.as<float>() : nullptr;
+    t.rows8 = nullptr;
+    t.rows8_meta = nullptr;
+    // int8 copy of the rows for the re-rank filter (txh.hip K8b): +25 % of the row bytes.  Large indexes
+    // only (the filter pays for long candidate lists); SCANN_HIP_RERANK_I8 = 0 never, 2 always.
+    {
+        int mode = 1;
+        if (const char *e = std::getenv("SCANN_HIP_RERANK_I8")) mode = std::atoi(e);
+        const bool want = d->data && !exact && d->distance_measure == SCANN_HIP_SQUARED_L2 && (d->dim & 15u) == 0 &&
+                          (mode == 2 || (mode == 1 && d->n_rows >= 65536));
+        if (want) {
+            if ((s = ix->d_rows8.ensure((size_t)d->n_rows * d->dim)) != SCANN_HIP_OK) return bail(s);
+            if ((s = ix->d_rows8_meta.ensure((size_t)d->n_rows * 8)) != SCANN_HIP_OK) return bail(s);
+            if ((s = launch_rows_i8_build(ix->d_rows.as<float>(), d->n_rows, d->dim, d->stride, ix->d_rows8.as<int8_t>(),
+                                          ix->d_rows8_meta.p, ix->stream)) != SCANN_HIP_OK)
+                return bail(s);
+            if (hipStreamSynchronize(ix->stream) != hipSuccess) return bail(fail(SCANN_HIP_INTERNAL, "int8 row build failed"));
+            t.rows8 = ix->d_rows8.as<int8_t>();
+            t.rows8_meta = ix->d_rows8_meta.p;
+        }
+    }
     // AH mode: CSR row == datapoint index.  Sharded: rows arrive in CSR order.
     t.rows_csr = (ah || d->data_is_csr_order) ? 1 : 0;
     t.codebook = exact ? nullptr : ix->d_codebook.as<float>();
@@ -631,6 +651,19 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
             if (v == 2) w->mfma = (t.code_bits == 4 && !p.no_threshold && !t.exact_scan) ? 1u : 0u;
         }
         if (w->mfma) w->resident = 0u;
+    }
+    // int8 re-rank filter: lists of a few hundred candidates and more (SCANN_HIP_RERANK_I8_MIN overrides)
+    {
+        uint32_t min_m = 512;
+        if (const char *e = std::getenv("SCANN_HIP_RERANK_I8_MIN")) min_m = (uint32_t)std::max(1, std::atoi(e));
+        w->use_i8 = (t.rows8 && p.exact_reorder && p.m >= min_m && p.m > 4 * p.k) ? 1u : 0u;
+        w->rr_lb = w->rr_ub = nullptr;
+        if (w->use_i8) {
+            SCANN_TRY(s.rr_lb.ensure((size_t)nq * m * 4));
+            SCANN_TRY(s.rr_ub.ensure((size_t)nq * m * 4));
+            w->rr_lb = s.rr_lb.as<uint32_t>();
+            w->rr_ub = s.rr_ub.as<uint32_t>();
+        }
     }
     w->lut8 = nullptr;
     w->lut8_meta = nullptr;

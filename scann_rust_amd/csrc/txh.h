@@ -89,6 +89,8 @@ struct TxhIndexDev {
     const uint32_t *leaf_ids;     // [n_local] datapoint index of CSR row; nullptr = identity
     const uint32_t *codes;        // [n_local][nw] packed 4-bit codes, 8 subspaces per word
     const float *rows;            // re-rank rows; CSR order if rows_csr else by datapoint idx
+    const int8_t *rows8;          // the same rows as int8 (per-row scale) for the re-rank filter, or nullptr
+    const void *rows8_meta;       // [n_rows] float2 {scale, ||x - s q||}
     int rows_csr;
     const float *codebook;        // [S][K][dsub]
     int use_residuals;
@@ -128,6 +130,8 @@ struct TxhWork {
     uint32_t st, scap, sqpt;   // sample stride, per-query sample capacity, quads per sample tile
     uint32_t qpt;              // quads per scan tile
     uint32_t resident, res_cl; // resident-table scan kernel (long leaves) and its chunks per tile
+    uint32_t use_i8;           // int8 row filter in front of the exact re-rank (needs ix.rows8)
+    uint32_t *rr_lb, *rr_ub;   // [nq][m] ordered lower / upper bounds of the candidates' exact distances
     uint32_t mfma;             // integer-MFMA prefilter + exact refine instead of the f32 LDS-gather scan
     int8_t *lut8;              // [max_slots][S][16] quantised tables (value - 128)
     void *lut8_meta;           // [max_slots] {f64 bias_sum, f64 scale}
@@ -193,6 +197,10 @@ int launch_lut16_u8_batch(const uint8_t *d_packed, const uint8_t *d_lut8, uint32
                           hipStream_t stream);
 
 // Lut16SimdTables::from_float_tables (hashes/lut16_simd.rs:39-90); d_bias_mult = {bias, multiplier}
+// int8 copy of n rows (per-row scale = max|x| / 127) + {scale, error norm} per row
+int launch_rows_i8_build(const float *d_rows, uint64_t n, uint32_t dim, uint32_t stride, int8_t *d_rows8,
+                         void *d_meta, hipStream_t stream);
+
 int launch_lut16_quantize(const float *d_tables, uint32_t S, uint8_t *d_lut8, float *d_bias_mult,
                           hipStream_t stream);
 

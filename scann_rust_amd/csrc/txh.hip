@@ -2106,6 +2106,7 @@ __global__ __launch_bounds__(NT) void final_topk_kernel(
     __shared__ uint32_t s_sl[NWV * kTopkMaxK];
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t nsel = cand_count[q];
+    if (nsel & 0x80000000u) return;   // rerank_short_kernel already wrote this query's rows (block-uniform)
     const uint32_t nout = min(k, nsel);
     uint32_t eb[E];
     uint64_t kk[E];
@@ -2186,6 +2187,254 @@ __global__ __launch_bounds__(NT) void final_topk_kernel(
         out_dist[(size_t)q * k + i] = __builtin_inff();
     }
     if (tid == 0) out_count[q] = nout;
+}
+
+// =====================================================================================
+// K8b: exact re-rank behind an int8 row filter (low-precision row stores as
+// shortlist filters; the reference's int8 rows: distance_measures/one_to_many_asymmetric.rs:25-377,
+// brute_force/scalar_quantized.rs:168-260).
+//
+// reorder_results (tree_x_hybrid/mod.rs:342-364) scores ALL m candidates exactly and keeps k of
+// them; at m = 5000 that is 2.6 GB of random 512-byte row gathers per 1024 queries, as long as the
+// scan.  Here every row also exists as int8 (per-row scale s = max|x| / 127, q = round(x / s),
+// x~ = s q) with its quantisation error E = ||x - x~|| stored beside it.  For a query q:
+//     d~ = ||q - x~||^2,   | ||q - x||^2 - d~ |  <=  2 sqrt(d~) E + E^2
+// so [L, U] = d~ -+ (2 sqrt(d~) E + E^2 + slack) brackets the reference's f32 distance (slack covers
+// the f32 rounding of both sums).  With tau = the k-th smallest U, at least k candidates lie at or
+// under tau, so a candidate with L > tau can neither enter the top k nor tie with it: only the
+// shortlist {L <= tau} (tens of rows) is scored with the reference's arithmetic, and the result --
+// indices, distances, tie order -- is the one the full re-rank gives.
+//   rerank_i8_kernel     L, U of every candidate (128-byte int8 rows instead of 512-byte f32 rows)
+//   rerank_short_kernel  block per query: tau, shortlist, exact distances (rerank_kernel's
+//                        arithmetic), the k best by (exact, merge key), output rows
+// =====================================================================================
+__global__ __launch_bounds__(256) void rows_i8_build_kernel(const float *__restrict__ rows, uint64_t n, uint32_t dim,
+                                                            uint32_t stride, int8_t *__restrict__ rows8,
+                                                            float2 *__restrict__ meta) {
+    // 8 lanes per row
+    const uint64_t r = (uint64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const uint32_t l8 = threadIdx.x & 7u;
+    const bool act = r < n;
+    const float *row = rows + (act ? r : 0) * stride;
+    float mx = 0.0f;
+    for (uint32_t j = l8; j < dim; j += 8) mx = fmaxf(mx, fabsf(row[j]));
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 8));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 8));
+    mx = fmaxf(mx, __shfl_xor(mx, 4, 8));
+    const bool finite = mx < __builtin_inff();      // (NaN rows: mx stays finite-or-NaN; the error below turns NaN)
+    const float sc = (mx > 0.0f && finite) ? mx / 127.0f : 1.0f;
+    float err = 0.0f;
+    for (uint32_t j = l8; j < dim; j += 8) {
+        const float x = row[j];
+        float t = rintf(x / sc);
+        t = fminf(fmaxf(t, -127.0f), 127.0f);
+        if (act) rows8[r * dim + j] = (int8_t)(t == t ? (int)t : 0);
+        const float e = x - sc * (t == t ? t : 0.0f);
+        err = err + e * e;
+    }
+    err += __shfl_xor(err, 1, 8);
+    err += __shfl_xor(err, 2, 8);
+    err += __shfl_xor(err, 4, 8);
+    if (act && l8 == 0) {
+        // E rounded up a little (the sum above is f32); a NaN / infinite row gets E = +inf: never filtered out
+        float E = sqrtf(err) * 1.0001f + 1e-30f;
+        if (!(E == E) || !finite) E = __builtin_inff();
+        meta[r] = make_float2(sc, E);
+    }
+}
+
+struct I8RerankArgs {
+    const int8_t *rows8;      // [n_rows][dim]
+    const float2 *meta;       // [n_rows] {scale, error norm}
+    const float *queries;
+    uint32_t q_stride, m;
+    const uint32_t *cand_row, *cand_count;
+    uint32_t *lb, *ub;        // [nq][m] ordered(L), ordered(U)
+};
+
+__global__ __launch_bounds__(256) void rerank_i8_kernel(uint32_t dim, I8RerankArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_q[];   // [dim]
+    const uint32_t q = blockIdx.y, tid = threadIdx.x;
+    const uint32_t nsel = a.cand_count[q];
+    const uint32_t c0 = blockIdx.x * 32u;
+    if (c0 >= nsel) return;   // uniform
+    for (uint32_t j = tid; j < dim; j += 256) s_q[j] = a.queries[(size_t)q * a.q_stride + j];
+    __syncthreads();
+    const uint32_t l8 = tid & 7u, c = c0 + (tid >> 3);
+    const bool act = c < nsel;
+    const uint32_t row = act ? a.cand_row[(size_t)q * a.m + c] : 0u;
+    const float2 me = a.meta[row];
+    const int8_t *r8 = a.rows8 + (size_t)row * dim;
+    float acc = 0.0f;
+    for (uint32_t j0 = l8 * 16u; j0 < dim; j0 += 128u) {   // 16 dims per lane per pass (dim % 16 == 0)
+        const uint4 v = *reinterpret_cast<const uint4 *>(r8 + j0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float x = me.x * (float)(int)(int8_t)(w[i >> 2] >> (8 * (i & 3)));
+            const float d = s_q[j0 + i] - x;
+            acc = fmaf(d, d, acc);
+        }
+    }
+    acc += __shfl_xor(acc, 1, 8);
+    acc += __shfl_xor(acc, 2, 8);
+    acc += __shfl_xor(acc, 4, 8);
+    if (act && l8 == 0) {
+        const float E = me.y;
+        // | d_f32 - d~ | <= 2 sqrt(d~) E + E^2 (triangle inequality on the real values) + the f32 rounding of
+        // the two dim-term sums (each <= (dim + 4) 2^-24 relative) + one ulp of slack on the bound itself
+        const float slack = (2.0f * sqrtf(acc) * E + E * E) * 1.0001f + acc * ((float)(dim + 8) * 1.2e-7f) + 1e-30f;
+        float L = acc - slack, U = acc + slack;
+        if (!(slack == slack) || !(acc == acc)) {   // NaN anywhere: never filtered out, never a bound for others
+            L = -__builtin_inff();
+            U = __builtin_inff();
+        }
+        a.lb[(size_t)q * a.m + c] = f32_to_ordered(L);
+        a.ub[(size_t)q * a.m + c] = f32_to_ordered(U);
+    }
+}
+
+constexpr uint32_t kShortMaxFast = 1024;   // shortlists up to this size finish inside rerank_short_kernel
+
+struct ShortArgs {
+    uint32_t m, k;
+    const float *queries;
+    uint32_t q_stride;
+    const uint32_t *lb, *ub;
+    const uint32_t *cand_row, *cand_idx;
+    const uint64_t *cand_key;
+    uint32_t *cand_count;     // fallback: left as is; fast path: top bit set so that final_topk skips the query
+    float *cand_exact;        // fallback: exact of the shortlist, +inf elsewhere
+    uint32_t *out_idx;
+    float *out_dist;
+    uint32_t *out_count;
+};
+
+__global__ __launch_bounds__(256) void rerank_short_kernel(TxhIndexDev ix, ShortArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
+    // layout: s_u[m4] | hist[bins] | list[list] | red (u64 x 48) | s_pos[kShortMaxFast] | s_eb[..] | s_kk u64[..] | s_q[dim]
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = 256;
+    const uint32_t m = a.m, k = a.k;
+    const uint32_t nsel = a.cand_count[q];
+    const uint32_t m4 = (m + 3u) & ~3u;
+    const SelCfg cfg = sel_cfg(m4);
+    uint32_t *s_u = s_mem;
+    uint32_t *s_hist = s_u + m4;
+    uint32_t *s_list = s_hist + cfg.bins;
+    uint64_t *s_red = reinterpret_cast<uint64_t *>(s_list + cfg.list + ((cfg.bins + cfg.list + m4) & 1u));
+    uint32_t *s_pos = reinterpret_cast<uint32_t *>(s_red + 48);
+    uint32_t *s_eb = s_pos + kShortMaxFast;
+    uint64_t *s_kk = reinterpret_cast<uint64_t *>(s_eb + kShortMaxFast);
+    float *s_q = reinterpret_cast<float *>(s_kk + kShortMaxFast);
+    __shared__ uint32_t s_ns;
+    const uint32_t nout = min(k, nsel);
+    for (uint32_t i = tid; i < m4; i += nt) s_u[i] = i < nsel ? a.ub[(size_t)q * m + i] : 0xFFFFFFFFu;
+    for (uint32_t j = tid; j < ix.dim; j += nt) s_q[j] = a.queries[(size_t)q * a.q_stride + j];
+    if (tid == 0) s_ns = 0;
+    __syncthreads();
+    // tau = k-th smallest upper bound (everything is shortlisted when there are at most k candidates)
+    uint32_t tau = 0xFFFFFFFFu;
+    if (nsel > k) tau = block_select<uint32_t>(s_u, m4, k, cfg, s_hist, s_list, s_red);
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nsel; b0 += nt) {
+        const uint32_t i = b0 + tid;
+        const bool keep = i < nsel && a.lb[(size_t)q * m + i] <= tau;
+        uint32_t wtot;
+        const uint32_t wpre = wave_prefix_count(keep, &wtot);
+        uint32_t base = 0;
+        if ((tid & 63u) == 0 && wtot) base = atomicAdd(&s_ns, wtot);
+        base = (uint32_t)__shfl((int)base, 0);
+        if (keep && base + wpre < kShortMaxFast) s_pos[base + wpre] = i;
+    }
+    __syncthreads();
+    const uint32_t ns = s_ns;
+    const bool fast = ns <= kShortMaxFast;
+    // exact distances of the shortlist: rerank_kernel's arithmetic (8 FMA lane chains, fixed hsum tree,
+    // unfused tail: simd/x86.rs:139-165, 31-44)
+    const uint32_t chunks = ix.dim >> 3, lane8 = tid & 7u;
+    const uint32_t total = fast ? ns : nsel;
+    for (uint32_t b0 = 0; b0 < total; b0 += nt / 8) {
+        const uint32_t jx = b0 + (tid >> 3);
+        const bool act = jx < total;
+        uint32_t i = 0;
+        bool listed = false;
+        if (act) {
+            i = fast ? s_pos[jx] : jx;
+            listed = fast || a.lb[(size_t)q * m + i] <= tau;
+        }
+        float r = __builtin_inff();
+        if (listed) {   // (divergence is by groups of 8 lanes)
+            const float *row = ix.rows + (size_t)a.cand_row[(size_t)q * m + i] * ix.stride;
+            float accv = 0.0f;
+            for (uint32_t c = 0; c < chunks; ++c) {
+                const float diff = s_q[8 * c + lane8] - row[8 * c + lane8];
+                accv = fmaf(diff, diff, accv);
+            }
+            const float s1 = accv + __shfl_down(accv, 4, 8);
+            const float t1 = s1 + __shfl_down(s1, 1, 8);
+            r = t1 + __shfl_down(t1, 2, 8);
+            if (lane8 == 0)
+                for (uint32_t j = chunks * 8; j < ix.dim; ++j) {
+                    const float diff = s_q[j] - row[j];
+                    r = r + diff * diff;
+                }
+        }
+        if (act && lane8 == 0) {
+            if (fast) {
+                s_eb[jx] = f32_to_ordered(r);
+                s_kk[jx] = a.cand_key[(size_t)q * m + i];
+            } else {
+                a.cand_exact[(size_t)q * m + i] = r;   // +inf outside the shortlist: final_topk orders the rest
+            }
+        }
+    }
+    if (!fast) return;   // block-uniform: final_topk_kernel finishes this query from cand_exact
+    __syncthreads();
+    // the k best of the shortlist by (exact, merge key) = the stable sort's first k: wave 0 runs k arg-min
+    // rounds over its lanes' strided entries (ns <= 1024: <= 16 per lane)
+    if (tid < 64) {
+        constexpr int E = kShortMaxFast / 64;
+        uint32_t eb[E];
+        uint64_t kk[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t j = (uint32_t)e * 64u + tid;
+            eb[e] = j < ns ? s_eb[j] : 0xFFFFFFFFu;
+            kk[e] = j < ns ? s_kk[j] : SCANN_KEY_MAX;
+        }
+        for (uint32_t r0 = 0; r0 < nout; ++r0) {
+            uint32_t b_eb = 0xFFFFFFFFu, b_sl = 0xFFFFFFFFu;
+            uint64_t b_kk = SCANN_KEY_MAX;
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if ((uint32_t)e * 64u < ns && (eb[e] < b_eb || (eb[e] == b_eb && kk[e] < b_kk))) {
+                    b_eb = eb[e];
+                    b_kk = kk[e];
+                    b_sl = (uint32_t)e * 64u + tid;
+                }
+            wave_argmin96(b_eb, b_kk, b_sl);
+            if (b_sl != 0xFFFFFFFFu && (b_sl & 63u) == tid) {
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if ((uint32_t)e == (b_sl >> 6)) {
+                        eb[e] = 0xFFFFFFFFu;
+                        kk[e] = SCANN_KEY_MAX;
+                    }
+            }
+            if (tid == 0) {
+                a.out_idx[(size_t)q * k + r0] = a.cand_idx[(size_t)q * m + s_pos[b_sl]];
+                a.out_dist[(size_t)q * k + r0] = ordered_to_f32(b_eb);
+            }
+        }
+    }
+    for (uint32_t i = nout + tid; i < k; i += nt) {
+        a.out_idx[(size_t)q * k + i] = kInvalid;
+        a.out_dist[(size_t)q * k + i] = __builtin_inff();
+    }
+    if (tid == 0) {
+        a.out_count[q] = nout;
+        a.cand_count[q] = 0x80000000u;   // final_topk_kernel has nothing left to do for this query
+    }
 }
 
 // =====================================================================================
@@ -2720,10 +2969,34 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
     LAUNCH_CHECK();
     if (!w.exact_reorder) return SCANN_HIP_OK;
     const size_t lds_rr = (size_t)ix.dim * 4;
-    SCANN_TRY(set_dyn_lds(rerank_kernel, lds_rr));
-    hipLaunchKernelGGL(rerank_kernel, dim3(ceil_div_u32(w.m, 32), w.nq), dim3(256), lds_rr, st, ix,
-                       w.queries, w.q_stride, w.m, w.cand_row, w.cand_count, w.cand_exact);
-    LAUNCH_CHECK();
+    // int8 row filter in front of the exact re-rank (K8b): single-GPU final stage, squared L2, lists long
+    // enough for the two extra kernels to pay
+    const bool i8 = unsorted && w.use_i8 && ix.rows8 && ix.measure == SCANN_HIP_SQUARED_L2 && (ix.dim & 15u) == 0;
+    if (i8) {
+        I8RerankArgs ia;
+        ia.rows8 = ix.rows8; ia.meta = reinterpret_cast<const float2 *>(ix.rows8_meta); ia.queries = w.queries;
+        ia.q_stride = w.q_stride; ia.m = w.m; ia.cand_row = w.cand_row; ia.cand_count = w.cand_count;
+        ia.lb = w.rr_lb; ia.ub = w.rr_ub;
+        SCANN_TRY(set_dyn_lds(rerank_i8_kernel, lds_rr));
+        hipLaunchKernelGGL(rerank_i8_kernel, dim3(ceil_div_u32(w.m, 32), w.nq), dim3(256), lds_rr, st, ix.dim, ia);
+        LAUNCH_CHECK();
+        ShortArgs sa;
+        sa.m = w.m; sa.k = w.k; sa.queries = w.queries; sa.q_stride = w.q_stride; sa.lb = w.rr_lb; sa.ub = w.rr_ub;
+        sa.cand_row = w.cand_row; sa.cand_idx = w.cand_idx; sa.cand_key = w.cand_key; sa.cand_count = w.cand_count;
+        sa.cand_exact = w.cand_exact; sa.out_idx = w.out_idx; sa.out_dist = w.out_dist; sa.out_count = w.out_count;
+        const uint32_t m4 = (w.m + 3u) & ~3u;
+        const SelCfg scf = sel_cfg(m4);
+        const size_t lds_sh = (size_t)(m4 + scf.bins + scf.list + 2) * 4 + 48 * 8 + (size_t)kShortMaxFast * 16 +
+                              (size_t)ix.dim * 4 + 16;
+        SCANN_TRY(set_dyn_lds(rerank_short_kernel, lds_sh));
+        hipLaunchKernelGGL(rerank_short_kernel, dim3(w.nq), dim3(256), lds_sh, st, ix, sa);
+        LAUNCH_CHECK();
+    } else {
+        SCANN_TRY(set_dyn_lds(rerank_kernel, lds_rr));
+        hipLaunchKernelGGL(rerank_kernel, dim3(ceil_div_u32(w.m, 32), w.nq), dim3(256), lds_rr, st, ix,
+                           w.queries, w.q_stride, w.m, w.cand_row, w.cand_count, w.cand_exact);
+        LAUNCH_CHECK();
+    }
     if (local_only) return SCANN_HIP_OK;
     if (unsorted) {
         if (w.m <= 2048) {
@@ -2835,6 +3108,15 @@ int launch_lut16_u8_batch(const uint8_t *d_packed, const uint8_t *d_lut8, uint32
     const uint32_t gx = (uint32_t)std::min<uint64_t>(ceil_div_u64(n, 256), 8192);
     hipLaunchKernelGGL(lut16_u8_batch_kernel, dim3(gx), dim3(256), (size_t)S * 16, st, d_packed, d_lut8,
                        S, n, bias, mult, d_out);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+int launch_rows_i8_build(const float *d_rows, uint64_t n, uint32_t dim, uint32_t stride, int8_t *d_rows8,
+                         void *d_meta, hipStream_t st) {
+    if (n == 0) return SCANN_HIP_OK;
+    hipLaunchKernelGGL(rows_i8_build_kernel, dim3((uint32_t)ceil_div_u64(n, 32)), dim3(256), 0, st, d_rows, n, dim,
+                       stride, d_rows8, reinterpret_cast<float2 *>(d_meta));
     LAUNCH_CHECK();
     return SCANN_HIP_OK;
 }

@@ -1153,3 +1153,53 @@ def test_scan_paths_agree(mode, monkeypatch):
             assert sorted(ci[i, :cc[i]].tolist()) == sorted(rci[i, :rcc[i]].tolist()), name + ": candidate set"
         assert np.array_equal(filt[0], ref_filt[0]) and np.array_equal(bits(filt[1]), bits(ref_filt[1])), name + " filtered"
     assert np.all(np.isin(ref_filt[0][ref_filt[0] != 0xFFFFFFFF], np.arange(0, n, 3)))
+
+
+# ---- int8 row filter in front of the exact re-rank (txh.hip K8b) -------------------------------------------
+@pytest.mark.parametrize("case", ["uniform", "duplicates", "scales", "txh"])
+def test_rerank_i8_filter_matches_full_rerank(case, monkeypatch):
+    """The int8 filter shortlists candidates by a proven bracket of their exact distances; rows, distances
+    and tie order must equal the full re-rank's (and the oracle's), also with duplicated rows (exact ties
+    at the k-th place), rows of wildly different magnitude, a zero row and m barely above k."""
+    n, dim, S = 30000, 64, 16
+    rng = np.random.default_rng(11)
+    if case == "txh":
+        rows, data, stride, ix, oix, kw = H.make_txh_case(40000, 96, 12, 24, seed=41, P=5, kmeans_iters=3, pq_iters=3)
+        q = synth.uniform_f32(48, 96, 78)
+        o = hip.default_opts()
+        o.partitions_to_search, o.pre_reorder_k = 5, 700
+    else:
+        rows = synth.uniform_f32(n, dim, 5)
+        if case == "duplicates":
+            rows[1::3] = rows[0::3][: rows[1::3].shape[0]]          # every third row repeats its neighbour
+        if case == "scales":
+            rows = (rows * np.exp(rng.uniform(-4, 4, (n, 1))).astype(np.float32)).astype(np.float32)
+            rows[7] = 0.0
+        data, stride = orc.to_strided(rows)
+        ixa = trainer.build_ah_index(rows, S, K=16, seed=3, pq_iters=3)
+        kw = dict(data=data, n_rows=n, dim=dim, stride=stride, centers=None, leaf_offsets=None, leaf_ids=None,
+                  codebook=ixa["codebook"], codes=ixa["codes"], codes_packed4=False, use_residuals=False,
+                  partitions_to_search=1, pre_reorder_multiplier=1.0)
+        q = synth.uniform_f32(48, dim, 79)
+        if case == "scales":
+            q = (q * np.float32(3.0)).astype(np.float32)
+        o = hip.default_opts()
+        o.pre_reorder_k = 900
+    monkeypatch.setenv("SCANN_HIP_RERANK_I8", "0")
+    plain = hip.txh_create(**kw)
+    monkeypatch.setenv("SCANN_HIP_RERANK_I8", "2")
+    monkeypatch.setenv("SCANN_HIP_RERANK_I8_MIN", "1")
+    filt = hip.txh_create(**kw)
+    for k, mm in ((10, o.pre_reorder_k), (10, 45), (1, 300), (40, 170)):
+        o.pre_reorder_k = mm
+        a = plain.search_batched(q, k, o)
+        b = filt.search_batched(q, k, o)
+        assert np.array_equal(a[2], b[2]), (case, k, mm)
+        assert np.array_equal(bits(a[1]), bits(b[1])), (case, k, mm)
+        assert np.array_equal(a[0], b[0]), (case, k, mm)
+    if case == "uniform":
+        o.pre_reorder_k = 900
+        gi, gd, gc = filt.search_batched(q[:6], 10, o)
+        for i in range(6):
+            oi, od = orc.ah_search_with_reordering(kw["codebook"], kw["codes"], data, stride, q[i], 10, 900)
+            H.assert_topk_equal_up_to_ties(gi[i], gd[i], oi, od, what="i8 filter vs oracle q%d" % i)
