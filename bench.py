@@ -45,7 +45,9 @@ LDS_PEAK_GBPS = 157286.4        # ds_read_b128: 256 B/clk/CU x 256 CUs x 2.4 GHz
 LDS_MEASURED_GBPS = 150000.0    # "Aggregate with every CU streaming: ~150 TB/s for ds_read_b64/b128"
 F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # bf16 MFMA, dense (no sparsity)
-I8_MFMA_PEAK_TOPS = 5000.0      # i8 MFMA: 2x the bf16 rate per clock, dense
+I8_MFMA_PEAK_TOPS = 5000.0      # i8 MFMA: 2x the bf16 rate per clock, dense (v_mfma_i32_32x32x32_i8: 32 cycles/SIMD)
+I8_MFMA_MEASURED_TOPS = 3500.0  # tools/micro/mfma_rate.hip on this pool: 1.5-1.75 PMAC/s sustained on random
+                                # operands (the chip lowers its clock under MFMA load), 2.3 PMAC/s on zeros
 
 METRIC = "QPS @ recall10@10 + achieved HBM GB/s, 1M x 128 f32"
 
@@ -299,15 +301,30 @@ def scan_roofline(hip, workload, kernel_name, kernel_ms, scanned_points, S, K, Q
     it is not physical traffic and is not a fraction of the HBM roof."""
     code_bytes = S // 2 if K <= 16 else S
     algo_bytes = scanned_points * code_bytes + pairs_per_query * S * (16 if K <= 16 else 256) * 4 + k * 8
-    lds_bytes = scanned_points * S * 4.0 * Q
     t = kernel_ms * 1e-3
-    ach = lds_bytes / t / 1e9 if t else 0.0
-    roof = {"bound": "lds", "achieved": ach, "peak": LDS_PEAK_GBPS, "unit": "GB/s", "frac": ach / LDS_PEAK_GBPS,
-            "frac_of_measured_peak": ach / LDS_MEASURED_GBPS, "peak_measured": LDS_MEASURED_GBPS,
-            "traffic": None, "kernel": kernel_name, "kernel_ms": kernel_ms,
-            "algorithmic": "LDS gather: scanned points (%.0f) x S (%d) x 16 B per quad of 4 queries x %d queries "
-                           "per launch = %.4g B; peak = ds_read_b128 256 B/clk/CU x 256 CUs x 2.4 GHz"
-                           % (scanned_points, S, Q, lds_bytes)}
+    if kernel_name == "adc_mfma_kernel":
+        # integer-MFMA prefilter: one-hot(codes) [points x S*16] x u8 tables [S*16 x queries]; every
+        # (point, query) costs S*16 multiply-adds on the matrix cores (16x the useful table adds: the price
+        # of turning a gather into a product).  Bound: the i8 MFMA rate.
+        ops = 2.0 * scanned_points * S * 16.0 * Q
+        ach = ops / t / 1e12 if t else 0.0
+        roof = {"bound": "mfma", "achieved": ach, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
+                "frac": ach / I8_MFMA_PEAK_TOPS, "frac_of_measured_peak": ach / I8_MFMA_MEASURED_TOPS,
+                "peak_measured": I8_MFMA_MEASURED_TOPS, "traffic": None, "kernel": kernel_name,
+                "kernel_ms": kernel_ms,
+                "algorithmic": "one-hot product: 2 x scanned points (%.0f) x S*16 (%d) x %d queries per launch = "
+                               "%.4g integer op; peak = dense i8 MFMA (2 x the 2.5 PFLOP/s bf16 rate); "
+                               "peak_measured = sustained v_mfma_i32_32x32x32_i8 rate on random operands "
+                               "(tools/micro/mfma_rate.hip)" % (scanned_points, S * 16, Q, ops)}
+    else:
+        lds_bytes = scanned_points * S * 4.0 * Q
+        ach = lds_bytes / t / 1e9 if t else 0.0
+        roof = {"bound": "lds", "achieved": ach, "peak": LDS_PEAK_GBPS, "unit": "GB/s", "frac": ach / LDS_PEAK_GBPS,
+                "frac_of_measured_peak": ach / LDS_MEASURED_GBPS, "peak_measured": LDS_MEASURED_GBPS,
+                "traffic": None, "kernel": kernel_name, "kernel_ms": kernel_ms,
+                "algorithmic": "LDS gather: scanned points (%.0f) x S (%d) x 16 B per quad of 4 queries x %d queries "
+                               "per launch = %.4g B; peak = ds_read_b128 256 B/clk/CU x 256 CUs x 2.4 GHz"
+                               % (scanned_points, S, Q, lds_bytes)}
     tr = traffic_for(hip, workload, kernel_name)
     if tr:
         roof["traffic"] = tr["bytes"]

@@ -2252,45 +2252,57 @@ struct I8RerankArgs {
     uint32_t *lb, *ub;        // [nq][m] ordered(L), ordered(U)
 };
 
+constexpr uint32_t kI8PerBlock = 256;   // candidates per block (8 lanes each, 8 rounds): amortises the query staging
+
 __global__ __launch_bounds__(256) void rerank_i8_kernel(uint32_t dim, I8RerankArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_q[];   // [dim]
     const uint32_t q = blockIdx.y, tid = threadIdx.x;
     const uint32_t nsel = a.cand_count[q];
-    const uint32_t c0 = blockIdx.x * 32u;
+    const uint32_t c0 = blockIdx.x * kI8PerBlock;
     if (c0 >= nsel) return;   // uniform
     for (uint32_t j = tid; j < dim; j += 256) s_q[j] = a.queries[(size_t)q * a.q_stride + j];
     __syncthreads();
-    const uint32_t l8 = tid & 7u, c = c0 + (tid >> 3);
-    const bool act = c < nsel;
-    const uint32_t row = act ? a.cand_row[(size_t)q * a.m + c] : 0u;
-    const float2 me = a.meta[row];
-    const int8_t *r8 = a.rows8 + (size_t)row * dim;
-    float acc = 0.0f;
-    for (uint32_t j0 = l8 * 16u; j0 < dim; j0 += 128u) {   // 16 dims per lane per pass (dim % 16 == 0)
-        const uint4 v = *reinterpret_cast<const uint4 *>(r8 + j0);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t l8 = tid & 7u;
+    constexpr int R = kI8PerBlock / 32;
+    uint32_t row[R];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float x = me.x * (float)(int)(int8_t)(w[i >> 2] >> (8 * (i & 3)));
-            const float d = s_q[j0 + i] - x;
-            acc = fmaf(d, d, acc);
-        }
+    for (int it = 0; it < R; ++it) {   // the rounds' row ids first: their gathers then overlap
+        const uint32_t c = c0 + (uint32_t)it * 32u + (tid >> 3);
+        row[it] = c < nsel ? a.cand_row[(size_t)q * a.m + c] : 0u;
     }
-    acc += __shfl_xor(acc, 1, 8);
-    acc += __shfl_xor(acc, 2, 8);
-    acc += __shfl_xor(acc, 4, 8);
-    if (act && l8 == 0) {
-        const float E = me.y;
-        // | d_f32 - d~ | <= 2 sqrt(d~) E + E^2 (triangle inequality on the real values) + the f32 rounding of
-        // the two dim-term sums (each <= (dim + 4) 2^-24 relative) + one ulp of slack on the bound itself
-        const float slack = (2.0f * sqrtf(acc) * E + E * E) * 1.0001f + acc * ((float)(dim + 8) * 1.2e-7f) + 1e-30f;
-        float L = acc - slack, U = acc + slack;
-        if (!(slack == slack) || !(acc == acc)) {   // NaN anywhere: never filtered out, never a bound for others
-            L = -__builtin_inff();
-            U = __builtin_inff();
+#pragma unroll
+    for (int it = 0; it < R; ++it) {
+        const uint32_t c = c0 + (uint32_t)it * 32u + (tid >> 3);
+        const bool act = c < nsel;
+        const float2 me = a.meta[row[it]];
+        const int8_t *r8 = a.rows8 + (size_t)row[it] * dim;
+        float acc = 0.0f;
+        for (uint32_t j0 = l8 * 16u; j0 < dim; j0 += 128u) {   // 16 dims per lane per pass (dim % 16 == 0)
+            const uint4 v = *reinterpret_cast<const uint4 *>(r8 + j0);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float x = me.x * (float)(int)(int8_t)(w[i >> 2] >> (8 * (i & 3)));
+                const float d = s_q[j0 + i] - x;
+                acc = fmaf(d, d, acc);
+            }
         }
-        a.lb[(size_t)q * a.m + c] = f32_to_ordered(L);
-        a.ub[(size_t)q * a.m + c] = f32_to_ordered(U);
+        acc += __shfl_xor(acc, 1, 8);
+        acc += __shfl_xor(acc, 2, 8);
+        acc += __shfl_xor(acc, 4, 8);
+        if (act && l8 == 0) {
+            const float E = me.y;
+            // | d_f32 - d~ | <= 2 sqrt(d~) E + E^2 (triangle inequality on the real values) + the f32 rounding
+            // of the two dim-term sums (each <= (dim + 4) 2^-24 relative) + slack on the bound itself
+            const float slack = (2.0f * sqrtf(acc) * E + E * E) * 1.0001f + acc * ((float)(dim + 8) * 1.2e-7f) + 1e-30f;
+            float L = acc - slack, U = acc + slack;
+            if (!(slack == slack) || !(acc == acc)) {   // NaN anywhere: never filtered out, never a bound for others
+                L = -__builtin_inff();
+                U = __builtin_inff();
+            }
+            a.lb[(size_t)q * a.m + c] = f32_to_ordered(L);
+            a.ub[(size_t)q * a.m + c] = f32_to_ordered(U);
+        }
     }
 }
 
@@ -2978,7 +2990,7 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
         ia.q_stride = w.q_stride; ia.m = w.m; ia.cand_row = w.cand_row; ia.cand_count = w.cand_count;
         ia.lb = w.rr_lb; ia.ub = w.rr_ub;
         SCANN_TRY(set_dyn_lds(rerank_i8_kernel, lds_rr));
-        hipLaunchKernelGGL(rerank_i8_kernel, dim3(ceil_div_u32(w.m, 32), w.nq), dim3(256), lds_rr, st, ix.dim, ia);
+        hipLaunchKernelGGL(rerank_i8_kernel, dim3(ceil_div_u32(w.m, kI8PerBlock), w.nq), dim3(256), lds_rr, st, ix.dim, ia);
         LAUNCH_CHECK();
         ShortArgs sa;
         sa.m = w.m; sa.k = w.k; sa.queries = w.queries; sa.q_stride = w.q_stride; sa.lb = w.rr_lb; sa.ub = w.rr_ub;

@@ -5,7 +5,7 @@
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-r02_a}
-KERNEL=${2:-adc_scan_res_kernel}
+KERNEL=${2:-adc_mfma_kernel}
 O=gpurun_out/$TAG
 mkdir -p $O
 B="--no-cpu-baseline --no-recall --no-batch-sweep"
@@ -17,7 +17,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done &&
 python3 tools/make_traffic.py ah $KERNEL $O/${TAG}_pmc_ah_FETCH_SIZE.csv $O/${TAG}_pmc_ah_WRITE_SIZE.csv &&
 cp profiles/traffic.json $O/traffic.json &&
-rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 3 --warmup 1 $B > $O/pmc_sq.log 2>&1 &&
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 3 --warmup 1 $B > $O/pmc_sq.log 2>&1 &&
 grep -E "Counter_Name|$KERNEL" $(find $O/pmc_sq -name "*counter_collection.csv" | head -1) > $O/${TAG}_pmc_ah_sq.csv &&
 python3 tools/pmc_summary.py $O/${TAG}_pmc_ah_sq.csv $KERNEL > $O/${TAG}_pmc_ah_sq_summary.txt
 python3 bench.py > $O/${TAG}_bench_ah.json 2> $O/bench_ah.err
