@@ -274,6 +274,74 @@ __device__ static T block_select(const T *vals, uint32_t n, uint32_t rank, SelCf
     }
 }
 
+// =====================================================================================
+// block_tail_select: value of 1-based rank `rank` among the block's values (VPT per thread through
+// load(i), ~0 = absent), for ranks in the low tail (rank <= blockDim.x / 2).
+//   1. every thread takes the minimum of its values: nt minima, each an element of the set, so the
+//      rank-th smallest minimum is >= the rank-th smallest value (the rank smallest minima are rank
+//      distinct elements) -- a pivot a few percent above the answer;
+//   2. the values <= pivot (a little over `rank` of them) are compacted into `list`;
+//   3. the rank-th smallest of the list is the answer.
+// If the list overflows `list_cap` (heavy ties at the pivot) the pivot itself is returned: still an
+// upper bound of the answer, and *exact_out = false.  No histogram over the whole input, no staging of
+// the input in LDS.  mins: LDS u32[blockDim.x]; list: LDS u32[list_cap]; hist/slist/red: block_select's
+// scratch for sel_cfg(max(blockDim.x, list_cap)); cnt: LDS u32.  All threads must call.
+// =====================================================================================
+template <int VPT, typename Load>
+__device__ static uint32_t block_tail_select(Load load, uint32_t rank, uint32_t *mins, uint32_t *list,
+                                             uint32_t list_cap, uint32_t *hist, uint32_t *slist, uint64_t *red,
+                                             uint32_t *cnt, bool *exact_out) {
+    // load(i), i < VPT: this thread's i-th value (called twice per i: the values are re-read from
+    // L2-hot memory rather than held in VPT registers, so that several blocks fit a CU)
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const uint32_t x = load(i);
+        mn = x < mn ? x : mn;
+    }
+    mins[tid] = mn;
+    if (tid == 0) *cnt = 0;
+    __syncthreads();
+    const SelCfg cfg = sel_cfg(nt > list_cap ? nt : list_cap);
+    uint32_t pivot = block_select<uint32_t>(mins, nt, rank, cfg, hist, slist, red);
+    __syncthreads();
+    if (pivot == 0xFFFFFFFFu) pivot = 0xFFFFFFFEu;   // fewer than `rank` threads hold a value: list every value
+    // one LDS atomic per wave: lanes count their own values under the pivot, a wave scan places them
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) mine += load(i) <= pivot ? 1u : 0u;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+        if ((int)(tid & 63u) >= o) incl += up;
+    }
+    uint32_t base = 0;
+    if ((tid & 63u) == 63u && incl) base = atomicAdd(cnt, incl);
+    uint32_t pos = (uint32_t)__shfl((int)base, 63) + incl - mine;
+    if (mine) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const uint32_t x = load(i);
+            if (x <= pivot) {
+                if (pos < list_cap) list[pos] = x;
+                ++pos;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t c = *cnt;
+    if (c > list_cap) {
+        *exact_out = false;
+        return pivot;
+    }
+    *exact_out = true;
+    const uint32_t r = block_select<uint32_t>(list, c, rank, cfg, hist, slist, red);
+    __syncthreads();
+    return r;
+}
+
 #endif
 
 }  // namespace scann

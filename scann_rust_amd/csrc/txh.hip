@@ -2322,31 +2322,36 @@ struct ShortArgs {
     uint32_t *out_count;
 };
 
+constexpr uint32_t kShortVPT = kMaxPreReorderK / 256;   // upper bounds per thread (registers)
+
 __global__ __launch_bounds__(256) void rerank_short_kernel(TxhIndexDev ix, ShortArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
-    // layout: s_u[m4] | hist[bins] | list[list] | red (u64 x 48) | s_pos[kShortMaxFast] | s_eb[..] | s_kk u64[..] | s_q[dim]
+    extern __shared__ __attribute__((aligned(16))) float s_q[];   // [dim]
+    __shared__ uint32_t s_mins[256], s_tlist[1024], s_hist[1024], s_slist[256], s_tcnt;
+    __shared__ uint64_t s_red[48];
+    __shared__ uint32_t s_pos[kShortMaxFast], s_eb[kShortMaxFast];
+    __shared__ uint64_t s_kk[kShortMaxFast];
+    __shared__ uint32_t s_ns;
     const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = 256;
     const uint32_t m = a.m, k = a.k;
     const uint32_t nsel = a.cand_count[q];
-    const uint32_t m4 = (m + 3u) & ~3u;
-    const SelCfg cfg = sel_cfg(m4);
-    uint32_t *s_u = s_mem;
-    uint32_t *s_hist = s_u + m4;
-    uint32_t *s_list = s_hist + cfg.bins;
-    uint64_t *s_red = reinterpret_cast<uint64_t *>(s_list + cfg.list + ((cfg.bins + cfg.list + m4) & 1u));
-    uint32_t *s_pos = reinterpret_cast<uint32_t *>(s_red + 48);
-    uint32_t *s_eb = s_pos + kShortMaxFast;
-    uint64_t *s_kk = reinterpret_cast<uint64_t *>(s_eb + kShortMaxFast);
-    float *s_q = reinterpret_cast<float *>(s_kk + kShortMaxFast);
-    __shared__ uint32_t s_ns;
     const uint32_t nout = min(k, nsel);
-    for (uint32_t i = tid; i < m4; i += nt) s_u[i] = i < nsel ? a.ub[(size_t)q * m + i] : 0xFFFFFFFFu;
     for (uint32_t j = tid; j < ix.dim; j += nt) s_q[j] = a.queries[(size_t)q * a.q_stride + j];
     if (tid == 0) s_ns = 0;
-    __syncthreads();
-    // tau = k-th smallest upper bound (everything is shortlisted when there are at most k candidates)
+    // tau = k-th smallest upper bound (everything is shortlisted when there are at most k candidates): a
+    // tail rank, so the bounds stay in registers and only those under a pivot are ranked
+    // (block_tail_select; an inexact result is the pivot, >= tau: a larger shortlist, still complete)
     uint32_t tau = 0xFFFFFFFFu;
-    if (nsel > k) tau = block_select<uint32_t>(s_u, m4, k, cfg, s_hist, s_list, s_red);
+    if (nsel > k) {   // block-uniform
+        uint32_t ubv[kShortVPT];   // (registers: 256 threads leave room, and the bounds are read once)
+#pragma unroll
+        for (int u = 0; u < (int)kShortVPT; ++u) {
+            const uint32_t i = (uint32_t)u * nt + tid;
+            ubv[u] = i < nsel ? a.ub[(size_t)q * m + i] : 0xFFFFFFFFu;
+        }
+        auto v = [&](int u) -> uint32_t { return ubv[u]; };
+        bool exact;
+        tau = block_tail_select<(int)kShortVPT>(v, k, s_mins, s_tlist, 1024, s_hist, s_slist, s_red, &s_tcnt, &exact);
+    }
     __syncthreads();
     for (uint32_t b0 = 0; b0 < nsel; b0 += nt) {
         const uint32_t i = b0 + tid;
@@ -2996,10 +3001,7 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
         sa.m = w.m; sa.k = w.k; sa.queries = w.queries; sa.q_stride = w.q_stride; sa.lb = w.rr_lb; sa.ub = w.rr_ub;
         sa.cand_row = w.cand_row; sa.cand_idx = w.cand_idx; sa.cand_key = w.cand_key; sa.cand_count = w.cand_count;
         sa.cand_exact = w.cand_exact; sa.out_idx = w.out_idx; sa.out_dist = w.out_dist; sa.out_count = w.out_count;
-        const uint32_t m4 = (w.m + 3u) & ~3u;
-        const SelCfg scf = sel_cfg(m4);
-        const size_t lds_sh = (size_t)(m4 + scf.bins + scf.list + 2) * 4 + 48 * 8 + (size_t)kShortMaxFast * 16 +
-                              (size_t)ix.dim * 4 + 16;
+        const size_t lds_sh = (size_t)ix.dim * 4;
         SCANN_TRY(set_dyn_lds(rerank_short_kernel, lds_sh));
         hipLaunchKernelGGL(rerank_short_kernel, dim3(w.nq), dim3(256), lds_sh, st, ix, sa);
         LAUNCH_CHECK();

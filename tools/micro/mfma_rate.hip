@@ -61,6 +61,13 @@ int main() {
     v4i h[1024];
     srand(1);
     for (int i = 0; i < 512; ++i) h[i] = v4i{rand(), rand(), rand(), rand()};
+    if (getenv("ONEHOT"))   // A operand as in the LUT16 prefilter: one byte of 16 set to 1
+        for (int i = 0; i < 256; ++i) {
+            int c = rand() & 15;
+            int w[4] = {0, 0, 0, 0};
+            w[c >> 2] = 1 << (8 * (c & 3));
+            h[i] = v4i{w[0], w[1], w[2], w[3]};
+        }
     for (int i = 512; i < 1024; ++i) h[i] = v4i{0, 0, 0, 0};
     hipMemcpy(din, h, sizeof(h), hipMemcpyHostToDevice);
     for (int z = 0; z < 2; ++z)
