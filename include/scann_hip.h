@@ -62,7 +62,15 @@ typedef enum {
 typedef enum {
     SCANN_HIP_SQUARED_L2 = 0,
     SCANN_HIP_L2 = 1,
-    SCANN_HIP_DOT_PRODUCT = 2 /* distance = -dot (simd/x86.rs:247-250) */
+    SCANN_HIP_DOT_PRODUCT = 2, /* distance = -dot (simd/x86.rs:247-250) */
+    /* The two measures below go through DistanceMeasure::distance one pair at a time in the reference
+     * (brute_force/searcher.rs:131-137, scann.rs:238-246, utils/reordering.rs:35-44).  They are valid for
+     * brute-force handles and as the distance_measure of Scann-facade indexes (SearchMode::Partitioned,
+     * exact reordering); TreeXHybridSearcher / AsymmetricHasher re-rank by squared L2 regardless. */
+    SCANN_HIP_L1 = 3,          /* l1_distance_avx2, simd/x86.rs:103-132 */
+    SCANN_HIP_COSINE = 4       /* 1 - cosine similarity, one_to_one.rs:559-612; its horizontal sums are the
+                                * third-party wide::f32x8::reduce_add (wide 0.7, non-AVX build): restated,
+                                * parity unpinned by the reference */
 } scann_hip_measure;
 
 typedef struct scann_hip_ctx scann_hip_ctx;     /* one device + stream/workspace pool */
@@ -117,7 +125,7 @@ int scann_hip_bf_create(scann_hip_ctx *ctx, const float *data, uint64_t n, uint3
  *   SearchMode::Partitioned  codebook == NULL && codes == NULL && num_subspaces == 0: every row
  *                            of the selected leaves is scored exactly with distance_measure
  *                            (search_partitioned, scann.rs:213-252); needs data, unsharded.
- * distance_measure (SCANN_HIP_SQUARED_L2 = 0 / L2 / DOT_PRODUCT) is the measure of the exact
+ * distance_measure (SCANN_HIP_SQUARED_L2 = 0 / L2 / DOT_PRODUCT / L1 / COSINE) is the measure of the exact
  * re-ordering (ReorderingHelper, utils/reordering.rs:23-54) and of the Partitioned scan;
  * TreeXHybridSearcher and AsymmetricHasher always re-rank by squared L2 (mod.rs:350-358). */
 typedef struct {

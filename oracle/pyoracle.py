@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libscann_oracle.so")
 
-SQUARED_L2, L2, DOT_PRODUCT = 0, 1, 2
+SQUARED_L2, L2, DOT_PRODUCT, L1, COSINE = 0, 1, 2, 3, 4
 
 
 def build(force=False):
@@ -119,6 +119,10 @@ def lib():
                                             u32p, f32p, u32p, C.c_int]
         L.or_reorder.restype = sz
         L.or_reorder.argtypes = [f32p, sz, sz, f32p, u32p, sz, sz, u32p, f32p]
+        L.or_l1_avx2.restype = C.c_float
+        L.or_l1_avx2.argtypes = [f32p, f32p, sz]
+        L.or_cosine_distance.restype = C.c_float
+        L.or_cosine_distance.argtypes = [f32p, f32p, sz]
         L.or_measure_distance.restype = C.c_float
         L.or_measure_distance.argtypes = [C.c_int, f32p, f32p, sz]
         L.or_reorder_measure.restype = sz
@@ -184,13 +188,23 @@ def one_to_many(q, db, stride, n, measure):
     q, pq = _f(q); db, pdb = _f(db)
     out = np.empty(n, np.float32)
     po = out.ctypes.data_as(f32p)
-    if measure == DOT_PRODUCT:
+    if measure in (L1, COSINE):   # brute_force/searcher.rs:131-137: DistanceMeasure::distance one by one
+        flat = db.reshape(-1)
+        for i in range(n):
+            out[i] = measure_distance(measure, q, flat[i * stride:i * stride + q.size])
+    elif measure == DOT_PRODUCT:
         lib().or_one_to_many_dot_product(pq, q.size, pdb, stride, n, po)
     else:
         lib().or_one_to_many_squared_l2(pq, q.size, pdb, stride, n, po)
         if measure == L2:
             out = np.sqrt(out)
     return out
+
+
+def measure_distance(measure, a, b):
+    """DistanceMeasure::distance (distance_measures/mod.rs:70-81) for the measures of the hot path."""
+    a, pa = _f(a); b, pb = _f(b)
+    return float(np.float32(lib().or_measure_distance(measure, pa, pb, a.size)))
 
 
 def compute_stride(dim):

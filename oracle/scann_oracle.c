@@ -435,6 +435,49 @@ size_t or_fast_top_neighbors_push_batch(size_t cap, const uint32_t *idx,
     return r;
 }
 
+/* l1_distance_avx2: simd/x86.rs:103-132 */
+float or_l1_avx2(const float *a, const float *b, size_t n) {
+    size_t chunks = n / 8;
+    float lane[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < chunks; ++i)
+        for (int j = 0; j < 8; ++j) lane[j] = lane[j] + fabsf(a[8 * i + j] - b[8 * i + j]);
+    /* horizontal_sum_f32_avx2 x86.rs:31-44: (lo + hi), + movehdup, + movehl */
+    float s0 = lane[0] + lane[4], s1 = lane[1] + lane[5], s2 = lane[2] + lane[6], s3 = lane[3] + lane[7];
+    float r = (s0 + s1) + (s2 + s3);
+    for (size_t i = chunks * 8; i < n; ++i) r += fabsf(a[i] - b[i]);
+    return r;
+}
+
+/* wide 0.7 f32x8::reduce_add without target_feature = "avx" (see scann_oracle.h): two f32x4 halves,
+ * each summed sequentially */
+static float wide07_reduce_add(const float *v) {
+    float lo = ((v[0] + v[1]) + v[2]) + v[3];
+    float hi = ((v[4] + v[5]) + v[6]) + v[7];
+    return lo + hi;
+}
+
+/* cosine_similarity_f32_simd one_to_one.rs:559-604, cosine_distance :607-612 */
+float or_cosine_distance(const float *a, const float *b, size_t n) {
+    size_t chunks = n / 8;
+    float ab[8] = {0}, aa[8] = {0}, bb[8] = {0};
+    for (size_t i = 0; i < chunks; ++i)
+        for (int j = 0; j < 8; ++j) {
+            float x = a[8 * i + j], y = b[8 * i + j];
+            ab[j] = ab[j] + x * y; /* add(mul): two roundings */
+            aa[j] = aa[j] + x * x;
+            bb[j] = bb[j] + y * y;
+        }
+    float sab = wide07_reduce_add(ab), saa = wide07_reduce_add(aa), sbb = wide07_reduce_add(bb);
+    for (size_t i = chunks * 8; i < n; ++i) {
+        sab += a[i] * b[i];
+        saa += a[i] * a[i];
+        sbb += b[i] * b[i];
+    }
+    float na = sqrtf(saa), nb = sqrtf(sbb);
+    float sim = (na == 0.0f || nb == 0.0f) ? 0.0f : sab / (na * nb);
+    return 1.0f - sim;
+}
+
 /* ------------------------------------------------------------------------ */
 /* brute force: brute_force/searcher.rs:77-208                              */
 /* ------------------------------------------------------------------------ */
@@ -447,8 +490,10 @@ static void bf_compute_distances(const float *data, size_t n, size_t dim,
         or_one_to_many_squared_l2(q, dim, data, stride, n, dist);
         if (measure == OR_L2)
             for (size_t i = 0; i < n; ++i) dist[i] = sqrtf(dist[i]);
-    } else {
+    } else if (measure == OR_DOT_PRODUCT) {
         or_one_to_many_dot_product(q, dim, data, stride, n, dist);
+    } else { /* :131-137 fallback: DistanceMeasure::distance one by one */
+        for (size_t i = 0; i < n; ++i) dist[i] = or_measure_distance(measure, q, data + i * stride, dim);
     }
 }
 
@@ -908,6 +953,8 @@ int or_txh_search_batched(const or_txh_index *ix, const float *queries, size_t n
 /* ------------------------------------------------------------------------ */
 float or_measure_distance(int measure, const float *a, const float *b, size_t dim) {
     if (measure == OR_DOT_PRODUCT) return -or_dot_product_avx2(a, b, dim); /* one_to_one.rs:464-469 */
+    if (measure == OR_L1) return or_l1_avx2(a, b, dim);                    /* distance_measures/mod.rs:71 */
+    if (measure == OR_COSINE) return or_cosine_distance(a, b, dim);        /* :74 */
     float d = or_squared_l2_avx2(a, b, dim);                               /* :162-171 */
     return measure == OR_L2 ? sqrtf(d) : d;                                /* :156-158 */
 }

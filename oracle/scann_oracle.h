@@ -30,7 +30,19 @@ extern "C" {
 #endif
 
 /* DistanceMeasure discriminants used on this path (distance_measures/mod.rs:32-66). */
-enum { OR_SQUARED_L2 = 0, OR_L2 = 1, OR_DOT_PRODUCT = 2 };
+enum { OR_SQUARED_L2 = 0, OR_L2 = 1, OR_DOT_PRODUCT = 2, OR_L1 = 3, OR_COSINE = 4 };
+
+/* l1_distance_avx2 simd/x86.rs:103-132: 8 lane chains of |a - b| (no FMA), the fixed horizontal-sum
+ * tree (x86.rs:31-44), unfused scalar tail. */
+float or_l1_avx2(const float *a, const float *b, size_t n);
+/* cosine_distance one_to_one.rs:559-612: 1 - dot/(|a| |b|), 0 similarity when a norm is 0.  The three
+ * sums run as 8-lane PortableF32x8 chains (mul then add, not fused) and are reduced by the THIRD-PARTY
+ * wide::f32x8::reduce_add (crate `wide` = "0.7", Cargo.toml:49; no Cargo.lock pins the patch version).
+ * The reference is built without -C target-feature=+avx (no .cargo/config), so wide takes its
+ * non-AVX path: f32x8 is two f32x4 halves, reduce_add = a.reduce_add() + b.reduce_add(), each half
+ * the sequential sum ((v0 + v1) + v2) + v3.  That order is restated here from the published crate
+ * source; nothing in the reference pins it (its cosine tests use axis vectors): PARITY UNPINNED. */
+float or_cosine_distance(const float *a, const float *b, size_t n);
 
 /* ---- L1 kernels -------------------------------------------------------- */
 

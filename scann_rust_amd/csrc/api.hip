@@ -217,10 +217,9 @@ int scann_hip_bf_create(scann_hip_ctx *ctx, const float *data, uint64_t n, uint3
     if (n > 0 && !data) return fail(SCANN_HIP_INVALID_ARGUMENT, "data is null");
     if (n > 0 && (dim == 0 || stride < dim))
         return fail(SCANN_HIP_INVALID_ARGUMENT, "bad dim/stride");
-    if (measure != SCANN_HIP_SQUARED_L2 && measure != SCANN_HIP_L2 &&
-        measure != SCANN_HIP_DOT_PRODUCT)
+    if (measure < SCANN_HIP_SQUARED_L2 || measure > SCANN_HIP_COSINE)
         return fail(SCANN_HIP_UNIMPLEMENTED,
-                    "brute force supports SquaredL2, L2 and DotProduct on the GPU path");
+                    "brute force supports SquaredL2, L2, DotProduct, L1 and Cosine on the GPU path");
     if (n >= 0xFFFFFFFFull) return fail(SCANN_HIP_OUT_OF_RANGE, "DatapointIndex is u32");
     SCANN_TRY(set_device(ctx));
     auto *ix = new scann_hip_index();
@@ -275,8 +274,8 @@ int scann::txh_create_checked(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, s
     // SearchMode::Partitioned (scann.rs:213-252): no codebook, the selected leaves are scored exactly
     const bool exact = !d->codebook && !d->codes && d->num_subspaces == 0;
     if (!exact && (!d->codebook || !d->codes)) return fail(SCANN_HIP_INVALID_ARGUMENT, "codebook/codes null");
-    if (d->distance_measure < SCANN_HIP_SQUARED_L2 || d->distance_measure > SCANN_HIP_DOT_PRODUCT)
-        return fail(SCANN_HIP_UNIMPLEMENTED, "distance_measure must be SquaredL2, L2 or DotProduct");
+    if (d->distance_measure < SCANN_HIP_SQUARED_L2 || d->distance_measure > SCANN_HIP_COSINE)
+        return fail(SCANN_HIP_UNIMPLEMENTED, "distance_measure must be SquaredL2, L2, DotProduct, L1 or Cosine");
     const uint32_t S = d->num_subspaces, K = exact ? 16u : d->num_codes, dsub = d->dims_per_subspace;
     if (d->dim == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "dim is 0");
     if (exact) {

@@ -72,9 +72,18 @@ __device__ __forceinline__ float bf_thr_float(uint64_t T) {
 // =====================================================================================
 constexpr int kBfGenQT = 8;
 
+// wide 0.7 f32x8::reduce_add in a build without target_feature = "avx" (the reference has no RUSTFLAGS):
+// two f32x4 halves, each summed sequentially -- the horizontal sum of cosine_similarity_f32_simd
+// (one_to_one.rs:559-604).  Third-party order, restated; see scann_hip.h.
+__device__ __forceinline__ float wide07_reduce_add(const float (&v)[8]) {
+    const float lo = ((v[0] + v[1]) + v[2]) + v[3];
+    const float hi = ((v[4] + v[5]) + v[6]) + v[7];
+    return lo + hi;
+}
+
 template <int MEASURE>
 __global__ __launch_bounds__(256) void bf_generic_kernel(BfIndexDev ix, BfPass p) {
-    extern __shared__ __attribute__((aligned(16))) float qs[];  // [kBfGenQT][dimp]
+    extern __shared__ __attribute__((aligned(16))) float qs[];  // [kBfGenQT][dimp] (+ [kBfGenQT] query norms)
     const uint32_t dim = ix.dim, dimp = (dim + 3u) & ~3u;
     const uint32_t q0 = blockIdx.y * kBfGenQT;
     for (uint32_t i = threadIdx.x; i < kBfGenQT * dimp; i += blockDim.x) {
@@ -82,15 +91,30 @@ __global__ __launch_bounds__(256) void bf_generic_kernel(BfIndexDev ix, BfPass p
         qs[i] = (q0 + qi < p.nq && j < dim) ? p.queries[(size_t)(q0 + qi) * p.q_stride + j] : 0.0f;
     }
     __syncthreads();
+    const uint32_t chunks = dim >> 3;
+    float *s_qn = qs + kBfGenQT * dimp;   // Cosine: sum of squares of every query, in the pair kernel's order
+    if (MEASURE == SCANN_HIP_COSINE) {
+        if (threadIdx.x < (uint32_t)kBfGenQT) {
+            const float *qv = qs + threadIdx.x * dimp;
+            float aa[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            for (uint32_t c = 0; c < chunks; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) aa[j] = aa[j] + qv[8 * c + j] * qv[8 * c + j];
+            float saa = wide07_reduce_add(aa);
+            for (uint32_t j = chunks * 8; j < dim; ++j) saa = saa + qv[j] * qv[j];
+            s_qn[threadIdx.x] = saa;
+        }
+        __syncthreads();
+    }
     const uint32_t vrow = blockIdx.x * blockDim.x + threadIdx.x;
     if (vrow >= p.nrows) return;
     const float *row = ix.rows + (size_t)vrow * p.row_mult * ix.stride;
-    const uint32_t chunks = dim >> 3;
     // The 8 AVX2 lane chains of a (query, row) pair are independent accumulators: pairs of
     // them go through the packed-f32 pipe (v_pk_add_f32 / v_pk_fma_f32: two IEEE operations per
     // instruction, same results as the scalar ones).
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 accv[kBfGenQT][4];
+    f32x2 bbv[4] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};   // Cosine: row norm chains
 #pragma unroll
     for (int qi = 0; qi < kBfGenQT; ++qi)
 #pragma unroll
@@ -107,6 +131,9 @@ __global__ __launch_bounds__(256) void bf_generic_kernel(BfIndexDev ix, BfPass p
 #pragma unroll
             for (int j = 0; j < 4; ++j) x[j] = f32x2{row[8 * c + 2 * j], row[8 * c + 2 * j + 1]};
         }
+        if (MEASURE == SCANN_HIP_COSINE)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bbv[j] = bbv[j] + x[j] * x[j];   // add(mul): not fused
 #pragma unroll
         for (int qi = 0; qi < kBfGenQT; ++qi) {
             const float4 qa = *reinterpret_cast<const float4 *>(qs + qi * dimp + 8 * c);
@@ -117,6 +144,10 @@ __global__ __launch_bounds__(256) void bf_generic_kernel(BfIndexDev ix, BfPass p
             for (int j = 0; j < 4; ++j) {
                 if (MEASURE == SCANN_HIP_DOT_PRODUCT) {
                     accv[qi][j] = __builtin_elementwise_fma(qv[j], x[j], accv[qi][j]);
+                } else if (MEASURE == SCANN_HIP_L1) {          // _mm256_add_ps(sum, andnot(sign, a - b))
+                    accv[qi][j] = accv[qi][j] + __builtin_elementwise_abs(qv[j] - x[j]);
+                } else if (MEASURE == SCANN_HIP_COSINE) {      // dot_ab.add(va.mul(vb)): two roundings
+                    accv[qi][j] = accv[qi][j] + qv[j] * x[j];
                 } else {
                     const f32x2 d = qv[j] - x[j];
                     accv[qi][j] = __builtin_elementwise_fma(d, d, accv[qi][j]);
@@ -132,16 +163,29 @@ __global__ __launch_bounds__(256) void bf_generic_kernel(BfIndexDev ix, BfPass p
             acc[qi][2 * j] = accv[qi][j].x;
             acc[qi][2 * j + 1] = accv[qi][j].y;
         }
+    float sbb = 0.0f;
+    if (MEASURE == SCANN_HIP_COSINE) {
+        const float bb[8] = {bbv[0].x, bbv[0].y, bbv[1].x, bbv[1].y, bbv[2].x, bbv[2].y, bbv[3].x, bbv[3].y};
+        sbb = wide07_reduce_add(bb);
+        for (uint32_t j = chunks * 8; j < dim; ++j) sbb = sbb + row[j] * row[j];
+    }
 #pragma unroll
     for (int qi = 0; qi < kBfGenQT; ++qi) {
         if (q0 + qi >= p.nq) continue;
-        const float s0 = acc[qi][0] + acc[qi][4], s1 = acc[qi][1] + acc[qi][5];
-        const float s2 = acc[qi][2] + acc[qi][6], s3 = acc[qi][3] + acc[qi][7];
-        float r = (s0 + s1) + (s2 + s3);
+        float r;
+        if (MEASURE == SCANN_HIP_COSINE) {
+            r = wide07_reduce_add(acc[qi]);
+        } else {   // horizontal_sum_f32_avx2 (x86.rs:31-44)
+            const float s0 = acc[qi][0] + acc[qi][4], s1 = acc[qi][1] + acc[qi][5];
+            const float s2 = acc[qi][2] + acc[qi][6], s3 = acc[qi][3] + acc[qi][7];
+            r = (s0 + s1) + (s2 + s3);
+        }
         for (uint32_t j = chunks * 8; j < dim; ++j) {
             const float qv = qs[qi * dimp + j];
-            if (MEASURE == SCANN_HIP_DOT_PRODUCT) {
+            if (MEASURE == SCANN_HIP_DOT_PRODUCT || MEASURE == SCANN_HIP_COSINE) {
                 r = r + qv * row[j];
+            } else if (MEASURE == SCANN_HIP_L1) {
+                r = r + fabsf(qv - row[j]);
             } else {
                 const float d = qv - row[j];
                 r = r + d * d;
@@ -150,6 +194,11 @@ __global__ __launch_bounds__(256) void bf_generic_kernel(BfIndexDev ix, BfPass p
         float dist = r;
         if (MEASURE == SCANN_HIP_DOT_PRODUCT) dist = -r;
         if (MEASURE == SCANN_HIP_L2) dist = sqrtf(r);
+        if (MEASURE == SCANN_HIP_COSINE) {   // one_to_one.rs:596-612
+            const float na = sqrtf(s_qn[qi]), nb = sqrtf(sbb);
+            const float sim = (na == 0.0f || nb == 0.0f) ? 0.0f : r / (na * nb);
+            dist = 1.0f - sim;
+        }
         uint64_t T = 0;
         float Tf = 0.0f;
         if (p.filter) {
@@ -1315,6 +1364,7 @@ static bool vq_eligible(const BfIndexDev &ix, const BfPass &p) {
 
 // streaming kernel: a few queries (one database pass per 8), 16-byte-loadable rows
 static bool stream_eligible(const BfIndexDev &ix, const BfPass &p) {
+    if (ix.measure > SCANN_HIP_DOT_PRODUCT) return false;   // L1 / Cosine: the pair-at-a-time kernel
     if ((ix.stride & 3u) || (reinterpret_cast<uintptr_t>(ix.rows) & 15u) || ix.dim < 8) return false;
     static const uint32_t max_q = [] {
         const char *e = std::getenv("SCANN_HIP_BF_STREAM_MAX_QUERIES");
@@ -1387,9 +1437,17 @@ static int launch_pass(const BfIndexDev &ix, const BfPass &p, hipStream_t st) {
         return SCANN_HIP_OK;
     }
     const uint32_t dimp = (ix.dim + 3u) & ~3u;
-    const size_t lds = (size_t)kBfGenQT * dimp * sizeof(float);
+    const size_t lds = ((size_t)kBfGenQT * dimp + kBfGenQT) * sizeof(float);
     dim3 grid(ceil_div_u32(p.nrows, 256), ceil_div_u32(p.nq, kBfGenQT));
     switch (ix.measure) {
+        case SCANN_HIP_L1:
+            SCANN_TRY(set_dyn_lds(bf_generic_kernel<SCANN_HIP_L1>, lds));
+            hipLaunchKernelGGL(bf_generic_kernel<SCANN_HIP_L1>, grid, dim3(256), lds, st, ix, p);
+            break;
+        case SCANN_HIP_COSINE:
+            SCANN_TRY(set_dyn_lds(bf_generic_kernel<SCANN_HIP_COSINE>, lds));
+            hipLaunchKernelGGL(bf_generic_kernel<SCANN_HIP_COSINE>, grid, dim3(256), lds, st, ix, p);
+            break;
         case SCANN_HIP_SQUARED_L2:
             SCANN_TRY(set_dyn_lds(bf_generic_kernel<SCANN_HIP_SQUARED_L2>, lds));
             hipLaunchKernelGGL(bf_generic_kernel<SCANN_HIP_SQUARED_L2>, grid, dim3(256), lds, st, ix, p);
@@ -1521,6 +1579,7 @@ int bf_build_shortlist_data(const BfIndexDev &ix, DevBuf &rows_b, DevBuf &rows_b
     if (ix.n == 0 || !shortlist_dims_ok(ix.dim)) return SCANN_HIP_OK;
     // SCANN_HIP_BF_SHORTLIST_MIN_ROWS: below this the exact kernels are fast enough (tests set 1)
     if (ix.n < env_u32("SCANN_HIP_BF_SHORTLIST_MIN_ROWS", 65536)) return SCANN_HIP_OK;
+    if (ix.measure > SCANN_HIP_DOT_PRODUCT) return SCANN_HIP_OK;   // L1 / Cosine: no bf16 bound is derived for them
     SCANN_TRY(rows_b.ensure((size_t)ix.n * ix.dim * 2));
     SCANN_TRY(rows_bl.ensure((size_t)ix.n * ix.dim * 2));
     SCANN_TRY(norm2.ensure((size_t)ix.n * 4));

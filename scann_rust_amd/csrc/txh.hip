@@ -1661,10 +1661,17 @@ __global__ __launch_bounds__(256) void leaf_exact_scan_kernel(TxhIndexDev ix, Ex
             const float *qs = qs_all + sg * dimp;
             const uint32_t *s_pq = s_pq_all + sg, *s_vb = s_vb_all + sg;
             f32x2 accv[kExactQT][4];
+            // Cosine (one_to_one.rs:559-604) also sums a.a and b.b lane by lane; the query's chains are
+            // recomputed per row like the reference does (same operations, same value every time)
+            f32x2 aav[MEASURE == SCANN_HIP_COSINE ? kExactQT : 1][4];
+            f32x2 bbv[4] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
 #pragma unroll
             for (int qi = 0; qi < kExactQT; ++qi)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) accv[qi][u] = f32x2{0.0f, 0.0f};
+                for (int u = 0; u < 4; ++u) {
+                    accv[qi][u] = f32x2{0.0f, 0.0f};
+                    if (MEASURE == SCANN_HIP_COSINE) aav[MEASURE == SCANN_HIP_COSINE ? qi : 0][u] = f32x2{0.0f, 0.0f};
+                }
             // the row streams through registers four 8-dim chunks at a time, the next group in
             // flight while this one computes (a chunk-at-a-time loop exposed one global-load latency
             // per 8 dims)
@@ -1704,6 +1711,12 @@ __global__ __launch_bounds__(256) void leaf_exact_scan_kernel(TxhIndexDev ix, Ex
                         for (int u = 0; u < 4; ++u) {
                             if (MEASURE == SCANN_HIP_DOT_PRODUCT) {
                                 accv[qi][u] = __builtin_elementwise_fma(qv[u], x[u], accv[qi][u]);
+                            } else if (MEASURE == SCANN_HIP_L1) {       // l1_distance_avx2: add |a - b|, no FMA
+                                accv[qi][u] = accv[qi][u] + __builtin_elementwise_abs(qv[u] - x[u]);
+                            } else if (MEASURE == SCANN_HIP_COSINE) {   // add(mul): two roundings
+                                accv[qi][u] = accv[qi][u] + qv[u] * x[u];
+                                if (qi == 0) bbv[u] = bbv[u] + x[u] * x[u];
+                                aav[MEASURE == SCANN_HIP_COSINE ? qi : 0][u] = aav[MEASURE == SCANN_HIP_COSINE ? qi : 0][u] + qv[u] * qv[u];
                             } else {
                                 const f32x2 d = qv[u] - x[u];
                                 accv[qi][u] = __builtin_elementwise_fma(d, d, accv[qi][u]);
@@ -1724,10 +1737,24 @@ __global__ __launch_bounds__(256) void leaf_exact_scan_kernel(TxhIndexDev ix, Ex
                 // hsum tree (x86.rs:31-44): lanes (0+4, 1+5), (2+6, 3+7) -> (s0+s1) + (s2+s3)
                 const f32x2 s01 = accv[qi][0] + accv[qi][2], s23 = accv[qi][1] + accv[qi][3];
                 float r = (s01.x + s01.y) + (s23.x + s23.y);
+                float saa = 0.0f, sbb = 0.0f;
+                if (MEASURE == SCANN_HIP_COSINE) {   // wide 0.7 reduce_add (non-AVX build): ((v0+v1)+v2)+v3 per half
+                    const f32x2 *av = aav[MEASURE == SCANN_HIP_COSINE ? qi : 0];
+                    r = (((accv[qi][0].x + accv[qi][0].y) + accv[qi][1].x) + accv[qi][1].y) +
+                        (((accv[qi][2].x + accv[qi][2].y) + accv[qi][3].x) + accv[qi][3].y);
+                    saa = (((av[0].x + av[0].y) + av[1].x) + av[1].y) + (((av[2].x + av[2].y) + av[3].x) + av[3].y);
+                    sbb = (((bbv[0].x + bbv[0].y) + bbv[1].x) + bbv[1].y) + (((bbv[2].x + bbv[2].y) + bbv[3].x) + bbv[3].y);
+                }
                 for (uint32_t jj = chunks * 8; jj < dim; ++jj) {   // scalar tail, not fused
                     const float qv = qs[qi * dimp + jj];
                     if (MEASURE == SCANN_HIP_DOT_PRODUCT) {
                         r = r + qv * row[jj];
+                    } else if (MEASURE == SCANN_HIP_L1) {
+                        r = r + fabsf(qv - row[jj]);
+                    } else if (MEASURE == SCANN_HIP_COSINE) {
+                        r = r + qv * row[jj];
+                        saa = saa + qv * qv;
+                        sbb = sbb + row[jj] * row[jj];
                     } else {
                         const float d = qv - row[jj];
                         r = r + d * d;
@@ -1736,6 +1763,10 @@ __global__ __launch_bounds__(256) void leaf_exact_scan_kernel(TxhIndexDev ix, Ex
                 float dist = r;
                 if (MEASURE == SCANN_HIP_DOT_PRODUCT) dist = -r;
                 if (MEASURE == SCANN_HIP_L2) dist = sqrtf(r);
+                if (MEASURE == SCANN_HIP_COSINE) {   // one_to_one.rs:596-612
+                    const float na = sqrtf(saa), nb = sqrtf(sbb);
+                    dist = 1.0f - ((na == 0.0f || nb == 0.0f) ? 0.0f : r / (na * nb));
+                }
                 if (valid) {
                     const uint32_t vpos = s_vb[qi] + j;
                     if (vpos < a.cap) a.cand[(size_t)pq * a.cap + vpos] = make_key(dist, vpos);
@@ -1987,7 +2018,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(TxhIndexDev ix, const float
     const uint32_t chunks = dim >> 3, lane8 = tid & 7u;
     const uint32_t c = c0 + (tid >> 3);
     const bool act = c < nsel;
-    float accv = 0.0f;
+    float accv = 0.0f, aav = 0.0f, bbv = 0.0f;   // (aa / bb: Cosine's two extra lane chains)
     const float *row = ix.rows;
     if (act) row = ix.rows + (size_t)cand_row[(size_t)q * m + c] * ix.stride;
     for (uint32_t i0 = 0; i0 < chunks; i0 += 8) {   // 8 independent loads in flight per lane
@@ -1997,23 +2028,52 @@ __global__ __launch_bounds__(256) void rerank_kernel(TxhIndexDev ix, const float
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (i0 + u < chunks) {
+                const float qv = s_q[8 * (i0 + u) + lane8];
                 if (ix.measure == SCANN_HIP_DOT_PRODUCT) {   // dot_product_avx2, x86.rs:72-96
-                    accv = fmaf(s_q[8 * (i0 + u) + lane8], xv[u], accv);
+                    accv = fmaf(qv, xv[u], accv);
+                } else if (ix.measure == SCANN_HIP_L1) {     // l1_distance_avx2, x86.rs:103-132
+                    accv = accv + fabsf(qv - xv[u]);
+                } else if (ix.measure == SCANN_HIP_COSINE) { // cosine_similarity_f32_simd: add(mul), not fused
+                    accv = accv + qv * xv[u];
+                    aav = aav + qv * qv;
+                    bbv = bbv + xv[u] * xv[u];
                 } else {
-                    const float diff = s_q[8 * (i0 + u) + lane8] - xv[u];
+                    const float diff = qv - xv[u];
                     accv = fmaf(diff, diff, accv);        // _mm256_fmadd_ps(diff, diff, sum)
                 }
             }
         }
     }
-    // horizontal_sum_f32_avx2: (lo+hi) -> +movehdup -> +movehl
-    float s = accv + __shfl_down(accv, 4, 8);     // lanes 0..3: v[j] + v[j+4]
-    float t = s + __shfl_down(s, 1, 8);           // lane 0: s0+s1, lane 2: s2+s3
-    float r = t + __shfl_down(t, 2, 8);           // lane 0: (s0+s1) + (s2+s3)
+    float r;
+    float saa = 0.0f, sbb = 0.0f;
+    if (ix.measure == SCANN_HIP_COSINE) {
+        // wide 0.7 f32x8::reduce_add (non-AVX build): ((v0 + v1) + v2) + v3 per half, then lo + hi;
+        // lane 0 of each half runs the chain with values shuffled in
+        auto half_sum = [&](float v) {
+            float h = v + __shfl_down(v, 1, 8);     // lanes 0, 4: v0 + v1
+            h = h + __shfl_down(v, 2, 8);           // + v2
+            h = h + __shfl_down(v, 3, 8);           // + v3
+            return h + __shfl_down(h, 4, 8);        // lane 0: lo + hi
+        };
+        r = half_sum(accv);
+        saa = half_sum(aav);
+        sbb = half_sum(bbv);
+    } else {
+        // horizontal_sum_f32_avx2: (lo+hi) -> +movehdup -> +movehl
+        const float s = accv + __shfl_down(accv, 4, 8);     // lanes 0..3: v[j] + v[j+4]
+        const float t = s + __shfl_down(s, 1, 8);           // lane 0: s0+s1, lane 2: s2+s3
+        r = t + __shfl_down(t, 2, 8);                       // lane 0: (s0+s1) + (s2+s3)
+    }
     if (act && lane8 == 0) {
         for (uint32_t j = chunks * 8; j < dim; ++j) {   // scalar tail, not fused
             if (ix.measure == SCANN_HIP_DOT_PRODUCT) {
                 r = r + s_q[j] * row[j];
+            } else if (ix.measure == SCANN_HIP_L1) {
+                r = r + fabsf(s_q[j] - row[j]);
+            } else if (ix.measure == SCANN_HIP_COSINE) {
+                r = r + s_q[j] * row[j];
+                saa = saa + s_q[j] * s_q[j];
+                sbb = sbb + row[j] * row[j];
             } else {
                 const float diff = s_q[j] - row[j];
                 r = r + diff * diff;
@@ -2022,6 +2082,10 @@ __global__ __launch_bounds__(256) void rerank_kernel(TxhIndexDev ix, const float
         // ReorderingHelper with the configured measure (utils/reordering.rs:35-44)
         if (ix.measure == SCANN_HIP_DOT_PRODUCT) r = -r;
         if (ix.measure == SCANN_HIP_L2) r = sqrtf(r);
+        if (ix.measure == SCANN_HIP_COSINE) {
+            const float na = sqrtf(saa), nb = sqrtf(sbb);
+            r = 1.0f - ((na == 0.0f || nb == 0.0f) ? 0.0f : r / (na * nb));
+        }
         cand_exact[(size_t)q * m + c] = r;
     }
 }
@@ -2898,6 +2962,14 @@ static int launch_exact_scan(const TxhIndexDev &ix, const TxhWork &w, hipStream_
         case SCANN_HIP_L2:
             SCANN_TRY(set_dyn_lds(leaf_exact_scan_kernel<SCANN_HIP_L2>, lds));
             hipLaunchKernelGGL(leaf_exact_scan_kernel<SCANN_HIP_L2>, grid, block, lds, st, ix, a);
+            break;
+        case SCANN_HIP_L1:
+            SCANN_TRY(set_dyn_lds(leaf_exact_scan_kernel<SCANN_HIP_L1>, lds));
+            hipLaunchKernelGGL(leaf_exact_scan_kernel<SCANN_HIP_L1>, grid, block, lds, st, ix, a);
+            break;
+        case SCANN_HIP_COSINE:
+            SCANN_TRY(set_dyn_lds(leaf_exact_scan_kernel<SCANN_HIP_COSINE>, lds));
+            hipLaunchKernelGGL(leaf_exact_scan_kernel<SCANN_HIP_COSINE>, grid, block, lds, st, ix, a);
             break;
         default:
             SCANN_TRY(set_dyn_lds(leaf_exact_scan_kernel<SCANN_HIP_DOT_PRODUCT>, lds));

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SCANN_HIP_LIB") or os.path.join(_HERE, "libscann_hip.
 
 OK, INVALID_ARGUMENT, RESOURCE_EXHAUSTED, FAILED_PRECONDITION = 0, 3, 8, 9
 OUT_OF_RANGE, UNIMPLEMENTED, INTERNAL, UNAVAILABLE = 11, 12, 13, 14
-SQUARED_L2, L2, DOT_PRODUCT = 0, 1, 2
+SQUARED_L2, L2, DOT_PRODUCT, L1, COSINE = 0, 1, 2, 3, 4
 
 _CODE_NAMES = {
     0: "Ok", 1: "Cancelled", 2: "Unknown", 3: "InvalidArgument", 4: "DeadlineExceeded",

@@ -9,8 +9,9 @@
 //  * the per-query loop of the reference (:172-178) is timed as `search_seconds` / `qps`; the same
 //    queries are then sent as ONE batch (Scann::search_batched) and reported as
 //    `batched_search_seconds` / `batched_qps` -- the GPU's natural operating point;
-//  * --distance l1 / cosine parse as in the reference but the GPU library implements
-//    SquaredL2 / L2 / DotProduct only: building such an index fails with Unimplemented.
+//  * --distance l1 / cosine run DistanceMeasure::distance's arithmetic (l1_distance_avx2; the cosine of
+//    one_to_one.rs:559-612, whose horizontal sums are the third-party wide 0.7 reduce_add: restated,
+//    parity unpinned) in brute-force / partitioned searches and exact reordering;
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -366,12 +367,10 @@ double seconds_since(std::chrono::steady_clock::time_point t0) {
 int main(int argc, char **argv) {
     const Args args = parse_args(argc, argv);
     try {
-        if (args.distance == DistanceArg::L1 || args.distance == DistanceArg::Cosine)
-            throw ScannError(ErrorCode::Unimplemented,
-                             std::string("distance ") + distance_debug(args.distance) +
-                                 " is not implemented by the GPU library (SquaredL2, L2, DotProduct)");
         const DistanceMeasure distance = args.distance == DistanceArg::L2           ? DistanceMeasure::L2
                                          : args.distance == DistanceArg::DotProduct ? DistanceMeasure::DotProduct
+                                         : args.distance == DistanceArg::L1         ? DistanceMeasure::L1
+                                         : args.distance == DistanceArg::Cosine     ? DistanceMeasure::Cosine
                                                                                     : DistanceMeasure::SquaredL2;
         const BenchmarkData data = args.data_json.empty() ? generate_synthetic_dataset(args) : load_json_dataset(args);
 

@@ -48,7 +48,7 @@ inline void check(int status) {
     if (status != SCANN_HIP_OK) throw ScannError(static_cast<ErrorCode>(status), scann_hip_last_error());
 }
 
-enum class DistanceMeasure : int { SquaredL2 = 0, L2 = 1, DotProduct = 2 };  // distance_measures/mod.rs:32-66
+enum class DistanceMeasure : int { SquaredL2 = 0, L2 = 1, DotProduct = 2, L1 = 3, Cosine = 4 };  // distance_measures/mod.rs:32-66 (the dense measures of the hot path)
 
 using DatapointIndex = uint32_t;                                   // types.rs:10
 using NNResultsVector = std::vector<std::pair<DatapointIndex, float>>;  // types.rs:17-20

@@ -903,7 +903,7 @@ def _partition_case(n, dim, L, seed):
     return rows, data, stride, centers, leaf_off, order
 
 
-@pytest.mark.parametrize("measure", [hip.SQUARED_L2, hip.L2, hip.DOT_PRODUCT])
+@pytest.mark.parametrize("measure", [hip.SQUARED_L2, hip.L2, hip.DOT_PRODUCT, hip.L1, hip.COSINE])
 @pytest.mark.parametrize("n,dim,L,P,k", [(3000, 64, 20, 5, 10), (5000, 100, 37, 37, 25), (800, 33, 8, 3, 900),
                                          (20000, 128, 16, 4, 10)])
 def test_scann_partitioned_mode(measure, n, dim, L, P, k):
@@ -943,7 +943,8 @@ def test_scann_partitioned_mode_duplicates():
 
 
 @pytest.mark.parametrize("measure,reorder", [(hip.SQUARED_L2, False), (hip.SQUARED_L2, True),
-                                             (hip.DOT_PRODUCT, True), (hip.L2, True)])
+                                             (hip.DOT_PRODUCT, True), (hip.L2, True), (hip.L1, True),
+                                             (hip.COSINE, True)])
 @pytest.mark.parametrize("K,S", [(256, 8), (16, 16)])
 def test_scann_tree_ah_mode(measure, reorder, K, S):
     """search_tree_ah (scann.rs:255-294): one non-residual table per query, stable sort of every
@@ -1203,3 +1204,39 @@ def test_rerank_i8_filter_matches_full_rerank(case, monkeypatch):
         for i in range(6):
             oi, od = orc.ah_search_with_reordering(kw["codebook"], kw["codes"], data, stride, q[i], 10, 900)
             H.assert_topk_equal_up_to_ties(gi[i], gd[i], oi, od, what="i8 filter vs oracle q%d" % i)
+
+
+# ---- L1 / Cosine: DistanceMeasure::distance one pair at a time (brute_force/searcher.rs:131-137) ---------
+@pytest.mark.parametrize("measure", [hip.L1, hip.COSINE])
+@pytest.mark.parametrize("n,dim,nq", [(3000, 64, 5), (2000, 100, 40), (900, 33, 300), (5000, 128, 64), (700, 7, 3)])
+def test_bf_l1_cosine(measure, n, dim, nq):
+    """Brute force with the measures the reference scores through DistanceMeasure::distance: all-pairs
+    distances bitwise against the oracle (l1_distance_avx2; the cosine kernel with wide 0.7's reduce_add
+    order -- parity unpinned by the reference, see scann_hip.h), exact top-k, a zero row and a zero query."""
+    rows = synth.uniform_f32(n, dim, 42) - np.float32(0.3)
+    rows[11] = 0.0
+    data, stride = orc.to_strided(rows)
+    index = hip.bf_create(data, n, dim, stride, measure)
+    q = synth.uniform_f32(nq, dim, 50 + nq) - np.float32(0.5)
+    q[min(2, nq - 1)] = 0.0
+    d = hip.bf_distances(index, q)
+    for i in range(min(nq, 6)):
+        assert np.array_equal(bits(d[i]), bits(orc.one_to_many(q[i], data, stride, n, measure))), i
+    idx, dist, cnt = index.search_batched(q, 10)
+    for i in range(min(nq, 12)):
+        oi, od = orc.bf_search(data, n, dim, stride, measure, q[i], 10)
+        assert cnt[i] == oi.size
+        H.assert_topk_equal_up_to_ties(idx[i, :oi.size], dist[i, :oi.size], oi, od, what="bf measure %d q%d" % (measure, i))
+
+
+def test_l1_cosine_reference_known_answers_on_gpu():
+    """distance_measures/one_to_one.rs:664-718 through the GPU brute force: L1 (1,2,3)-(4,5,6) = 9;
+    cosine distance 0 for equal axis vectors, 1 for orthogonal ones, 1 when a norm is zero."""
+    rows = np.array([[4, 5, 6]], np.float32)
+    data, stride = orc.to_strided(rows)
+    d = hip.bf_distances(hip.bf_create(data, 1, 3, stride, hip.L1), np.array([[1, 2, 3]], np.float32))
+    assert d[0, 0] == np.float32(9.0)
+    rows = np.array([[1, 0], [0, 1], [0, 0]], np.float32)
+    data, stride = orc.to_strided(rows)
+    d = hip.bf_distances(hip.bf_create(data, 3, 2, stride, hip.COSINE), np.array([[1, 0]], np.float32))
+    assert abs(d[0, 0]) < 1e-6 and abs(d[0, 1] - 1.0) < 1e-6 and d[0, 2] == np.float32(1.0)

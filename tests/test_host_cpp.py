@@ -112,5 +112,8 @@ def test_ann_benchmark_cli_json_dataset(tmp_path):
     assert rep["train_size"] == 100 and rep["test_size"] == 5 and rep["distance"] == "l2"
     r = _run_cli("--data-json", path, "--k", 11)
     assert r.returncode != 0 and "neighbors rows must have at least 11 entries" in r.stderr
-    r = _run_cli("--data-json", path, "--distance", "cosine")
-    assert r.returncode != 0 and "not implemented" in r.stderr
+    for dist_name in ("cosine", "l1"):      # DistanceMeasure::distance's measures run too
+        r = _run_cli("--data-json", path, "--algorithm", "partitioned", "--num-partitions", 4,
+                     "--partitions-to-search", 4, "--distance", dist_name)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert _report(r.stdout)["distance"] == dist_name

@@ -371,3 +371,43 @@ def test_kmeans_lloyd_empty_cluster_reseeds_from_row():  # trees/kmeans.rs:405-4
     init = np.array([[0, 0], [10, 10], [1000, 1000]], np.float32)   # third centre attracts nothing
     c, a, sizes, inertia, iters, conv = orc.kmeans_lloyd(x, 30, 2, 2, init, max_iterations=1)
     assert np.array_equal(c[2], x[2 % 30])
+
+
+def test_l1_and_cosine_known_answers():
+    """distance_measures/one_to_one.rs:664-670 (L1 = 9), :697-718 (cosine similarity / distance of axis
+    vectors), plus the structure of the restated kernels: l1 = 8 lane chains + the AVX2 hsum tree + tail;
+    cosine = add(mul) lane chains reduced as wide 0.7 does without AVX (two sequential halves)."""
+    assert orc.measure_distance(orc.L1, np.array([1, 2, 3], np.float32), np.array([4, 5, 6], np.float32)) == 9.0
+    e0, e1 = np.array([1, 0], np.float32), np.array([0, 1], np.float32)
+    assert abs(orc.measure_distance(orc.COSINE, e0, e0)) < 1e-6
+    assert abs(orc.measure_distance(orc.COSINE, e0, e1) - 1.0) < 1e-6
+    assert orc.measure_distance(orc.COSINE, np.zeros(2, np.float32), e1) == 1.0       # a zero norm: similarity 0
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal(29).astype(np.float32)
+    b = rng.standard_normal(29).astype(np.float32)
+    lanes = np.zeros(8, np.float32)
+    for c in range(3):
+        lanes = (lanes + np.abs(a[8 * c:8 * c + 8] - b[8 * c:8 * c + 8])).astype(np.float32)
+    s = [np.float32(lanes[j] + lanes[j + 4]) for j in range(4)]
+    r = np.float32(np.float32(s[0] + s[1]) + np.float32(s[2] + s[3]))
+    for j in range(24, 29):
+        r = np.float32(r + np.float32(abs(np.float32(a[j] - b[j]))))
+    assert np.float32(orc.measure_distance(orc.L1, a, b)) == r
+
+    def wide(v):
+        lo = np.float32(np.float32(np.float32(v[0] + v[1]) + v[2]) + v[3])
+        hi = np.float32(np.float32(np.float32(v[4] + v[5]) + v[6]) + v[7])
+        return np.float32(lo + hi)
+    ab = np.zeros(8, np.float32); aa = np.zeros(8, np.float32); bb = np.zeros(8, np.float32)
+    for c in range(3):
+        x, y = a[8 * c:8 * c + 8], b[8 * c:8 * c + 8]
+        ab = (ab + (x * y).astype(np.float32)).astype(np.float32)
+        aa = (aa + (x * x).astype(np.float32)).astype(np.float32)
+        bb = (bb + (y * y).astype(np.float32)).astype(np.float32)
+    sab, saa, sbb = wide(ab), wide(aa), wide(bb)
+    for j in range(24, 29):
+        sab = np.float32(sab + np.float32(a[j] * b[j]))
+        saa = np.float32(saa + np.float32(a[j] * a[j]))
+        sbb = np.float32(sbb + np.float32(b[j] * b[j]))
+    want = np.float32(1.0) - np.float32(sab / np.float32(np.sqrt(saa) * np.sqrt(sbb)))
+    assert np.float32(orc.measure_distance(orc.COSINE, a, b)) == np.float32(want)
