@@ -195,7 +195,7 @@ def build_txh_single(args, torch, hip, device, local_rank, stride):
     leaf_of_row = np.repeat(np.arange(L, dtype=np.uint32), sizes)
     codes = hip.encode(codebook, rows_csr, stride=stride, centers=centers, leaf_of_row=leaf_of_row, device=local_rank)
     index = hip.txh_create(data=rows_csr, n_rows=n, dim=dim, stride=stride, centers=centers, leaf_offsets=leaf_off,
-                           leaf_ids=order_np.astype(np.uint32), leaf_sizes_global=sizes, codebook=codebook,
+                           leaf_ids=order_np.astype(np.uint32), codebook=codebook,
                            codes=codes, use_residuals=True, partitions_to_search=args.partitions_to_search,
                            pre_reorder_multiplier=float(args.pre_reorder_k) / k, data_is_csr_order=True,
                            device=local_rank)

@@ -43,6 +43,34 @@ struct TxhWorkspace {
         sbase, pair_sbase, stile_off, samp, lut8, lut8_meta, cand32, cand32_cnt, mfma_thr1, rr_lb, rr_ub;
 };
 
+// Pinned host memory the GPU reads and writes in place (grow-only).  Small host-side searches keep
+// their queries and result rows here: the kernels load the queries over the host link and store the
+// rows straight into host memory, so a call is launches + ONE stream sync, with no copy commands (each
+// hipMemcpyAsync to or from pageable memory costs 5-15 us of host time: five of them were most of a
+// single-query call).
+struct PinBuf {
+    void *host = nullptr, *dev = nullptr;
+    size_t bytes = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+    ~PinBuf() { release(); }
+    void release() {
+        if (host) (void)hipHostFree(host);
+        host = dev = nullptr;
+        bytes = 0;
+    }
+    int ensure(size_t need) {
+        if (need <= bytes && host) return SCANN_HIP_OK;
+        release();
+        need = (need + 4095) & ~(size_t)4095;
+        SCANN_HIP_CHECK(hipHostMalloc(&host, need, hipHostMallocMapped));
+        SCANN_HIP_CHECK(hipHostGetDevicePointer(&dev, host, 0));
+        bytes = need;
+        return SCANN_HIP_OK;
+    }
+};
+
 // An extra stream + workspaces: host-side searches of concurrent caller threads (Searcher: Send +
 // Sync, tests/stress_tests.rs:256-297) run side by side instead of queueing on one mutex.
 struct SearchSlot {
@@ -50,6 +78,7 @@ struct SearchSlot {
     hipStream_t stream = nullptr;
     TxhWorkspace ws;
     BfWorkspace bfw;
+    PinBuf pin;
 };
 
 struct scann_hip_index {
@@ -80,8 +109,9 @@ struct scann_hip_index {
 
     // ---- brute force ----
     BfIndexDev bf{};
-    DevBuf bf_rows, bf_rows_b, bf_rows_bl, bf_norm2;
+    DevBuf bf_rows, bf_rows_b, bf_rows_bl, bf_norm2, bf_leaf;
     BfWorkspace bfw;
+    TxhIndexDev bfx{};        // the same rows as a one-leaf exact-scan index: the small-batch pipeline's view
 
     // ---- tree-x-hybrid / AH ----
     TxhIndexDev tx{};
@@ -90,7 +120,9 @@ struct scann_hip_index {
     uint32_t default_P = 0;
     float multiplier = 3.0f;
     TxhWorkspace ws;
+    PinBuf pin;               // primary slot's pinned staging
     TxhWork last_work{};
+    bool sharded = false;     // created with leaf_sizes_global: local leaves are a subset of the global stream
 };
 
 static int set_device(const scann_hip_ctx *ctx) {
@@ -240,6 +272,20 @@ int scann_hip_bf_create(scann_hip_ctx *ctx, const float *data, uint64_t n, uint3
     ix->bf.rows_bl = nullptr;
     ix->bf.norm2 = nullptr;
     ix->bf.max_norm = 0.0f;
+    if (n > 0 && n <= kSmallMaxStream) {   // view for the three-launch small-batch pipeline (txh.hip)
+        const uint32_t leaf[3] = {0u, (uint32_t)n, (uint32_t)n};   // leaf_off[0..1], leaf_gsize[0]
+        s = upload(ix->bf_leaf, leaf, sizeof(leaf));
+        if (s != SCANN_HIP_OK) {
+            scann_hip_index_destroy(ix);
+            return s;
+        }
+        TxhIndexDev &t = ix->bfx;
+        t.dim = dim; t.stride = stride; t.L = 1; t.S = 0; t.K = 16; t.dsub = 0; t.nw = 0; t.code_bits = 4; t.kp = 16;
+        t.n_local = n; t.centers = nullptr; t.leaf_off = ix->bf_leaf.as<uint32_t>();
+        t.leaf_gsize = ix->bf_leaf.as<uint32_t>() + 2; t.leaf_ids = nullptr; t.codes = nullptr;
+        t.rows = ix->bf_rows.as<float>(); t.rows8 = nullptr; t.rows8_meta = nullptr; t.rows_csr = 1;
+        t.codebook = nullptr; t.use_residuals = 0; t.ah_mode = 1; t.measure = measure; t.exact_scan = 1;
+    }
     if ((stride & 3u) == 0) {   // bf16 copy + norms for the shortlist path (big indexes only)
         s = bf_build_shortlist_data(ix->bf, ix->bf_rows_b, ix->bf_rows_bl, ix->bf_norm2, &ix->bf.max_norm,
                                     ix->stream);
@@ -450,6 +496,7 @@ int scann::txh_create_checked(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, s
     t.codebook = exact ? nullptr : ix->d_codebook.as<float>();
     t.use_residuals = (!ah && d->use_residuals) ? 1 : 0;
     t.ah_mode = ah ? 1 : 0;
+    ix->sharded = d->leaf_sizes_global != nullptr;
     ix->default_P = ah ? 1u : std::max(1u, d->partitions_to_search);
     ix->multiplier = d->pre_reorder_multiplier;
     *out = ix;
@@ -462,11 +509,18 @@ int scann_hip_txh_create(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, scann_
     return scann::txh_create_checked(ctx, d, out, SCANN_HIP_INVALID_ARGUMENT);
 }
 
+// SCANN_HIP_SMALL=0 turns the small-batch pipeline off (read per call: tests flip it)
+static bool small_batch_enabled() {
+    const char *e = std::getenv("SCANN_HIP_SMALL");
+    return !(e && std::atoi(e) == 0);
+}
+
 // ---- per-call parameter resolution --------------------------------------------------
 struct TxhCallParams {
     uint32_t P, m, k, cap, st, scap;
     int exact_reorder;
     int no_threshold;
+    int small;   // small-batch pipeline (txh.hip "Small batches")
 };
 
 static uint64_t max_stream(const scann_hip_index *ix, uint32_t P) {
@@ -476,7 +530,7 @@ static uint64_t max_stream(const scann_hip_index *ix, uint32_t P) {
 }
 
 static int resolve_params(const scann_hip_index *ix, uint32_t k, const scann_hip_search_opts *o,
-                          bool full_cap, TxhCallParams *out) {
+                          bool full_cap, TxhCallParams *out, uint32_t nq = 0xFFFFFFFFu) {
     scann_hip_search_opts def;
     scann_hip_search_opts_default(&def);
     if (!o) o = &def;
@@ -508,6 +562,13 @@ static int resolve_params(const scann_hip_index *ix, uint32_t k, const scann_hip
     const uint64_t ms = std::min<uint64_t>(std::max<uint64_t>(1, max_stream(ix, P)), 0xFFFFFFFFull);
     uint32_t st, scap;
     sample_plan(ms, P, &st, &scap);
+    // A handful of queries over a short stream: three launches with dense candidate lists instead of
+    // the batched pipeline (SCANN_HIP_SMALL=0 disables).  Unsharded indexes only: stream positions are
+    // list slots, and a shard's local leaves leave holes in them.
+    const bool small_on = small_batch_enabled();
+    out->small = (small_on && nq <= kSmallBatch && !ix->sharded && m <= kSmallMaxCandidates &&
+                  k <= 64 && ms <= kSmallMaxStream && ix->tx.L <= 4096) ? 1 : 0;
+    if (out->small) full_cap = true;
     uint64_t cap = ms;
     if (!full_cap) {
         // upper bound of the survivors of the sampled threshold (rank j of a stride-st sample)
@@ -593,6 +654,8 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
     w->cap = p.cap;
     w->exact_reorder = p.exact_reorder;
     w->no_threshold = p.no_threshold;
+    w->small = (uint32_t)p.small;
+    w->small_max_leaf = ix->local_sizes_desc.empty() ? 0u : ix->local_sizes_desc[0];
     w->need_sorted_cands = 0;
     w->allow = nullptr;
     w->allow_bits = 0;
@@ -735,6 +798,7 @@ struct SlotLock {
     hipStream_t stream = nullptr;
     TxhWorkspace *ws = nullptr;
     BfWorkspace *bfw = nullptr;
+    PinBuf *pin = nullptr;
     bool primary = false;
 };
 
@@ -773,6 +837,7 @@ static int acquire_slot(scann_hip_index *ix, SlotLock *out) {
             out->stream = slot->stream;
             out->ws = &slot->ws;
             out->bfw = &slot->bfw;
+            out->pin = &slot->pin;
             out->primary = false;
             return SCANN_HIP_OK;
         }
@@ -782,6 +847,7 @@ static int acquire_slot(scann_hip_index *ix, SlotLock *out) {
     out->stream = ix->stream;
     out->ws = &ix->ws;
     out->bfw = &ix->bfw;
+    out->pin = &ix->pin;
     out->primary = true;
     return SCANN_HIP_OK;
 }
@@ -796,7 +862,7 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
     SCANN_TRY(set_device(ix->ctx));
     for (int attempt = 0; attempt < 2; ++attempt) {
         TxhCallParams p;
-        SCANN_TRY(resolve_params(ix, k, opts, /*full_cap=*/attempt == 1, &p));
+        SCANN_TRY(resolve_params(ix, k, opts, /*full_cap=*/attempt == 1, &p, nq));
         if (p.m == 0) {  // nothing can be kept (reference panics on FastTopNeighbors::new(0))
             fill_empty(nq, k, out_idx, out_dist, out_count);
             if (opts && opts->cand_count) std::memset(opts->cand_count, 0, (size_t)nq * 4);
@@ -805,6 +871,33 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
         TxhWork w;
         SCANN_TRY(ensure_txh_workspace(ix, ws, nq, p, true, q_stride, true, &w));
         w.need_sorted_cands = (opts && (opts->cand_idx || opts->cand_dist)) ? 1 : 0;
+        const bool stage_outputs = opts && (opts->tokens || opts->token_dists || opts->cand_idx || opts->cand_dist ||
+                                            opts->cand_count);
+        if (w.small && !stage_outputs && !(opts && opts->allow_bitmap)) {
+            // small batch: queries and result rows live in pinned host memory the kernels access in place
+            const size_t qb = (size_t)nq * q_stride * 4, ob = (size_t)nq * k * 4;
+            const size_t off_idx = (qb + 255) & ~(size_t)255, off_dist = off_idx + ((ob + 255) & ~(size_t)255),
+                         off_cnt = off_dist + ((ob + 255) & ~(size_t)255);
+            SCANN_TRY(sl.pin->ensure(off_cnt + (size_t)nq * 4 + 256));
+            char *hp = static_cast<char *>(sl.pin->host), *dp = static_cast<char *>(sl.pin->dev);
+            std::memcpy(hp, queries, qb);
+            w.queries = reinterpret_cast<const float *>(dp);
+            w.out_idx = reinterpret_cast<uint32_t *>(dp + off_idx);
+            w.out_dist = reinterpret_cast<float *>(dp + off_dist);
+            w.out_count = reinterpret_cast<uint32_t *>(dp + off_cnt);
+            if (sl.primary) ix->next_events();
+            SCANN_TRY(txh_launch_search(ix->tx, w, false, stream, sl.primary ? ix->ev0 : nullptr,
+                                        sl.primary ? ix->ev1 : nullptr));
+            if (sl.primary) {
+                ix->timing_valid = ix->timing;
+                ix->timed_kernel = "small_scan_kernel";
+            }
+            SCANN_HIP_CHECK(hipStreamSynchronize(stream));
+            std::memcpy(out_idx, hp + off_idx, ob);
+            std::memcpy(out_dist, hp + off_dist, ob);
+            std::memcpy(out_count, hp + off_cnt, (size_t)nq * 4);
+            return SCANN_HIP_OK;   // (dense candidate lists: this pipeline has no overflow / retry case)
+        }
         if (opts && opts->allow_bitmap) {   // search_with_filter(Some(allow-list))
             const size_t words = (size_t)((opts->allow_bitmap_bits + 63) / 64);
             SCANN_TRY(ws.allow.ensure(words * 8));
@@ -857,6 +950,50 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
     return fail(SCANN_HIP_INTERNAL, "unreachable");
 }
 
+}  // extern "C"
+
+// BruteForceSearcher::search for a handful of queries over a small dataset: the three-launch pipeline of
+// txh.hip ("Small batches") on the one-leaf exact-scan view of the rows -- every distance with the
+// one-to-many kernels' arithmetic, the k smallest (distance, index) keys = TopK -- with queries and result
+// rows in pinned host memory (no copy commands).
+static int bf_small_search_host(scann_hip_index *ix, SlotLock &sl, const float *queries, uint32_t nq,
+                                uint32_t q_stride, uint32_t k, uint32_t *out_idx, float *out_dist,
+                                uint32_t *out_count) {
+    TxhWorkspace &ws = *sl.ws;
+    const uint32_t n = (uint32_t)ix->bf.n, kk = std::min(k, n);
+    SCANN_TRY(ws.tokens.ensure((size_t)nq * 4));
+    SCANN_TRY(ws.token_dists.ensure((size_t)nq * 4));
+    SCANN_TRY(ws.vbase.ensure((size_t)nq * 2 * 4));
+    SCANN_TRY(ws.sbase.ensure((size_t)nq * 3 * 4));
+    SCANN_TRY(ws.counters.ensure(CNT_WORDS * 4));
+    SCANN_TRY(ws.cand.ensure((size_t)nq * n * 8));
+    const size_t qb = (size_t)nq * q_stride * 4, ob = (size_t)nq * k * 4;
+    const size_t off_idx = (qb + 255) & ~(size_t)255, off_dist = off_idx + ((ob + 255) & ~(size_t)255),
+                 off_cnt = off_dist + ((ob + 255) & ~(size_t)255);
+    SCANN_TRY(sl.pin->ensure(off_cnt + (size_t)nq * 4 + 256));
+    char *hp = static_cast<char *>(sl.pin->host), *dp = static_cast<char *>(sl.pin->dev);
+    std::memcpy(hp, queries, qb);
+    TxhWork w{};
+    w.nq = nq; w.q_stride = q_stride; w.P = 1; w.m = kk; w.k = k; w.cap = n; w.exact_reorder = 0;
+    w.no_threshold = 1; w.need_sorted_cands = 0; w.allow = nullptr; w.allow_bits = 0;
+    w.queries = reinterpret_cast<const float *>(dp);
+    w.tokens = ws.tokens.as<uint32_t>(); w.token_dists = ws.token_dists.as<float>();
+    w.vbase = ws.vbase.as<uint32_t>(); w.sbase = ws.sbase.as<uint32_t>(); w.st = 1;
+    w.counters = ws.counters.as<uint32_t>(); w.cand = ws.cand.as<uint64_t>();
+    w.out_idx = reinterpret_cast<uint32_t *>(dp + off_idx);
+    w.out_dist = reinterpret_cast<float *>(dp + off_dist);
+    w.out_count = reinterpret_cast<uint32_t *>(dp + off_cnt);
+    w.small = 1; w.small_max_leaf = n;
+    SCANN_TRY(txh_launch_search(ix->bfx, w, false, sl.stream, nullptr, nullptr));
+    SCANN_HIP_CHECK(hipStreamSynchronize(sl.stream));
+    std::memcpy(out_idx, hp + off_idx, ob);
+    std::memcpy(out_dist, hp + off_dist, ob);
+    std::memcpy(out_count, hp + off_cnt, (size_t)nq * 4);
+    return SCANN_HIP_OK;
+}
+
+extern "C" {
+
 int scann_hip_search_batched(scann_hip_index *ix, const float *queries, uint32_t nq,
                              uint32_t q_stride, uint32_t q_dim, uint32_t k,
                              const scann_hip_search_opts *opts, uint32_t *out_idx, float *out_dist,
@@ -882,6 +1019,9 @@ int scann_hip_search_batched(scann_hip_index *ix, const float *queries, uint32_t
         SlotLock sl;
         SCANN_TRY(acquire_slot(ix, &sl));
         SCANN_TRY(set_device(ix->ctx));
+        const bool small_on = small_batch_enabled();
+        if (small_on && ix->bfx.rows && nq <= kSmallBatch && k <= 64)
+            return bf_small_search_host(ix, sl, queries, nq, q_stride, k, out_idx, out_dist, out_count);
         if (sl.primary) ix->next_events();
         int s = bf_search_host(ix->bf, *sl.bfw, queries, nq, q_stride, k, opts && opts->bf_exact, out_idx,
                                out_dist, out_count, sl.stream, sl.primary ? ix->ev0 : nullptr,
@@ -936,7 +1076,7 @@ int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries,
         return s;
     }
     TxhCallParams p;
-    SCANN_TRY(resolve_params(ix, k, opts, false, &p));
+    SCANN_TRY(resolve_params(ix, k, opts, false, &p, nq));
     if (p.m == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "pre-reorder candidate count is 0");
     TxhWork w;
     SCANN_TRY(ensure_txh_workspace(ix, ix->ws, nq, p, false, q_stride, false, &w));

@@ -36,6 +36,9 @@ constexpr uint32_t kMaxPartitionsToSearch = 4096;
 constexpr uint32_t kMaxLeavesSelect = 16384;              // L limit of the LDS leaf sort
 constexpr uint32_t kSelectThreads = 1024;
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+constexpr uint32_t kSmallBatch = 16;                      // queries per call the small-batch pipeline takes
+constexpr uint32_t kSmallMaxStream = 262144;              // ... longest candidate stream (points) it takes
+constexpr uint32_t kSmallMaxCandidates = 1024;            // ... largest pre_reorder_k
 
 // ---- threshold sampling plan (shared by host buffer sizing and the device kernels) ----
 // Every st-th point of each selected leaf is scored ahead of the scan (adc_sample_kernel,
@@ -130,6 +133,8 @@ struct TxhWork {
     uint32_t st, scap, sqpt;   // sample stride, per-query sample capacity, quads per sample tile
     uint32_t qpt;              // quads per scan tile
     uint32_t resident, res_cl; // resident-table scan kernel (long leaves) and its chunks per tile
+    uint32_t small;            // small-batch pipeline (three launches; dense candidate lists: cap = the stream)
+    uint32_t small_max_leaf;   // longest local leaf (grid of the small scan)
     uint32_t use_i8;           // int8 row filter in front of the exact re-rank (needs ix.rows8)
     uint32_t *rr_lb, *rr_ub;   // [nq][m] ordered lower / upper bounds of the candidates' exact distances
     uint32_t mfma;             // integer-MFMA prefilter + exact refine instead of the f32 LDS-gather scan

@@ -73,11 +73,15 @@ __global__ __launch_bounds__(64) void centroid_scores_kernel(
 // OrderedFloat(dist), take the first P.  Key = (ordered(dist) << 32 | id) makes the
 // stable order explicit; NaN sorts last as OrderedFloat does.
 // =====================================================================================
+// centers_inline != nullptr (small batches): the block scores the centroids itself first, with
+// centroid_scores_kernel's arithmetic (sequential scalar sum of (q_j - c_j)^2, no FMA), instead of reading
+// a matrix another launch produced.
 __global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
-    const float *__restrict__ cdist, uint32_t L, uint32_t n_pow2, uint32_t P, uint32_t p_pow2,
+    float *__restrict__ cdist, uint32_t L, uint32_t n_pow2, uint32_t P, uint32_t p_pow2,
     const uint32_t *__restrict__ leaf_gsize, const uint32_t *__restrict__ leaf_off, uint32_t st,
     uint32_t *__restrict__ tokens, float *__restrict__ token_dists, uint32_t *__restrict__ vbase,
-    uint32_t *__restrict__ sbase) {
+    uint32_t *__restrict__ sbase, const float *__restrict__ centers_inline, const float *__restrict__ queries,
+    uint32_t q_stride, uint32_t dim) {
     extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];    // [n_pow2]
     uint64_t *s_top = skeys + n_pow2;                                   // [p_pow2] (select path)
     const SelCfg cfg = sel_cfg(L);
@@ -89,6 +93,35 @@ __global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
     const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = nt >> 6;
     const bool select_path = p_pow2 != 0;
     const uint32_t nfill = select_path ? L : n_pow2;
+    if (centers_inline) {
+        float *s_qv = reinterpret_cast<float *>(skeys);   // (skeys is filled only after this block)
+        for (uint32_t j = tid; j < dim; j += nt) s_qv[j] = queries[(size_t)q * q_stride + j];
+        __syncthreads();
+        const bool vec = (dim & 3u) == 0 && (reinterpret_cast<uintptr_t>(centers_inline) & 15u) == 0;
+        for (uint32_t c = tid; c < L; c += nt) {
+            const float *crow = centers_inline + (size_t)c * dim;
+            float acc = 0.0f;
+            if (vec) {
+#pragma unroll 8
+                for (uint32_t j = 0; j < dim; j += 4) {   // 16-byte loads, the same sequential sum
+                    const float4 cv = *reinterpret_cast<const float4 *>(crow + j);
+                    const float4 qv = *reinterpret_cast<const float4 *>(s_qv + j);
+                    const float d0 = qv.x - cv.x, d1 = qv.y - cv.y, d2 = qv.z - cv.z, d3 = qv.w - cv.w;
+                    acc = acc + d0 * d0;
+                    acc = acc + d1 * d1;
+                    acc = acc + d2 * d2;
+                    acc = acc + d3 * d3;
+                }
+            } else {
+                for (uint32_t j = 0; j < dim; ++j) {
+                    const float d = s_qv[j] - crow[j];
+                    acc = acc + d * d;
+                }
+            }
+            cdist[(size_t)q * L + c] = acc;   // read back below after the barrier
+        }
+        __syncthreads();
+    }
     for (uint32_t i = tid; i < nfill; i += nt) {
         uint64_t key = SCANN_KEY_MAX;
         if (i < L) {
@@ -2002,25 +2035,14 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
 // non-fused scalar tail.  32 candidates per 256-thread block, grid over (candidates,
 // queries): the random row gathers are spread over the whole chip.
 // =====================================================================================
-__global__ __launch_bounds__(256) void rerank_kernel(TxhIndexDev ix, const float *__restrict__ queries,
-                                                     uint32_t q_stride, uint32_t m,
-                                                     const uint32_t *__restrict__ cand_row,
-                                                     const uint32_t *__restrict__ cand_count,
-                                                     float *__restrict__ cand_exact) {
-    extern __shared__ __attribute__((aligned(16))) float s_q[];   // [dim]
-    const uint32_t q = blockIdx.y, tid = threadIdx.x;
-    const uint32_t nsel = cand_count[q];
-    const uint32_t c0 = blockIdx.x * 32u;
-    if (c0 >= nsel) return;   // uniform
-    const uint32_t dim = ix.dim;
-    for (uint32_t j = tid; j < dim; j += blockDim.x) s_q[j] = queries[(size_t)q * q_stride + j];
-    __syncthreads();
-    const uint32_t chunks = dim >> 3, lane8 = tid & 7u;
-    const uint32_t c = c0 + (tid >> 3);
-    const bool act = c < nsel;
+// Exact distance of one (query, row) pair by a group of 8 lanes (lane8 = the AVX2 lane chain), with the
+// measure of the re-ordering (utils/reordering.rs:35-44): squared_l2_avx2 / dot_product_avx2 /
+// l1_distance_avx2 (simd/x86.rs) or the cosine of one_to_one.rs:559-612.  The result is valid in the
+// group's lane 0 (act must be uniform over the group).
+__device__ __forceinline__ float exact_pair_8lanes(const TxhIndexDev &ix, const float *s_q, const float *row, bool act,
+                                                  uint32_t lane8) {
+    const uint32_t dim = ix.dim, chunks = dim >> 3;
     float accv = 0.0f, aav = 0.0f, bbv = 0.0f;   // (aa / bb: Cosine's two extra lane chains)
-    const float *row = ix.rows;
-    if (act) row = ix.rows + (size_t)cand_row[(size_t)q * m + c] * ix.stride;
     for (uint32_t i0 = 0; i0 < chunks; i0 += 8) {   // 8 independent loads in flight per lane
         float xv[8];
 #pragma unroll
@@ -2086,6 +2108,30 @@ __global__ __launch_bounds__(256) void rerank_kernel(TxhIndexDev ix, const float
             const float na = sqrtf(saa), nb = sqrtf(sbb);
             r = 1.0f - ((na == 0.0f || nb == 0.0f) ? 0.0f : r / (na * nb));
         }
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void rerank_kernel(TxhIndexDev ix, const float *__restrict__ queries,
+                                                     uint32_t q_stride, uint32_t m,
+                                                     const uint32_t *__restrict__ cand_row,
+                                                     const uint32_t *__restrict__ cand_count,
+                                                     float *__restrict__ cand_exact) {
+    extern __shared__ __attribute__((aligned(16))) float s_q[];   // [dim]
+    const uint32_t q = blockIdx.y, tid = threadIdx.x;
+    const uint32_t nsel = cand_count[q];
+    const uint32_t c0 = blockIdx.x * 32u;
+    if (c0 >= nsel) return;   // uniform
+    const uint32_t dim = ix.dim;
+    for (uint32_t j = tid; j < dim; j += blockDim.x) s_q[j] = queries[(size_t)q * q_stride + j];
+    __syncthreads();
+    const uint32_t lane8 = tid & 7u;
+    const uint32_t c = c0 + (tid >> 3);
+    const bool act = c < nsel;
+    const float *row = ix.rows;
+    if (act) row = ix.rows + (size_t)cand_row[(size_t)q * m + c] * ix.stride;
+    const float r = exact_pair_8lanes(ix, s_q, row, act, lane8);
+    if (act && lane8 == 0) {
         cand_exact[(size_t)q * m + c] = r;
     }
 }
@@ -2519,6 +2565,326 @@ __global__ __launch_bounds__(256) void rerank_short_kernel(TxhIndexDev ix, Short
 }
 
 // =====================================================================================
+// Small batches (nq <= 16, short candidate streams): the search as THREE launches.
+//
+// The batched pipeline above groups (query, leaf) pairs by leaf, samples a filter bound and scans
+// through tile queues: ~12 dependent launches, each ~5 us of dispatch on its own -- ~115-150 us of
+// device time for ONE query, of which the scan is 15-40.  For a handful of queries none of that
+// machinery pays:
+//   1. select_leaves_kernel with inline centroid scoring            TreePartitioner::partition
+//   2. small_scan_kernel: one workgroup per (query, leaf, 1024-point chunk) builds the pair's table
+//      in LDS (lut_build_kernel's arithmetic) and writes EVERY point's merge key at its stream
+//      position (dense list, no bound, no atomics)                  mod.rs:297-339
+//   3. small_finish_kernel: block per query: the m smallest keys (rank select), decode, exact
+//      distances (exact_pair_8lanes), the k best by (exact, merge key)   mod.rs:283-293, 342-364
+// Same keys, same arithmetic, same order: rows identical to the batched pipeline's.
+// =====================================================================================
+constexpr uint32_t kSmallChunk = 1024;      // points per workgroup of the scan
+constexpr uint32_t kSmallMaxM = 1024;       // candidates the finish kernel keeps in LDS
+constexpr uint32_t kFinGroups = 4096;       // sub-stream minima of the finish kernel's tail select
+
+// Exact distance of one (query, row) pair by ONE thread: the 8 AVX2 lane chains in registers, combined as
+// the reference combines them (exact_pair_8lanes spreads the same chains over 8 lanes).  DistanceMeasure::
+// distance (distance_measures/mod.rs:70-81) = the one-to-many kernels' per-row arithmetic (simd/x86.rs).
+__device__ __forceinline__ float exact_pair_thread(int measure, uint32_t dim, const float *sq, const float *row) {
+    const uint32_t chunks = dim >> 3;
+    float ac[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, aa[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f},
+          bb[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (uint32_t c = 0; c < chunks; ++c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float qv = sq[8 * c + j], x = row[8 * c + j];
+            if (measure == SCANN_HIP_DOT_PRODUCT) {
+                ac[j] = fmaf(qv, x, ac[j]);
+            } else if (measure == SCANN_HIP_L1) {
+                ac[j] = ac[j] + fabsf(qv - x);
+            } else if (measure == SCANN_HIP_COSINE) {
+                ac[j] = ac[j] + qv * x;
+                aa[j] = aa[j] + qv * qv;
+                bb[j] = bb[j] + x * x;
+            } else {
+                const float d = qv - x;
+                ac[j] = fmaf(d, d, ac[j]);
+            }
+        }
+    }
+    float r, saa = 0.0f, sbb = 0.0f;
+    if (measure == SCANN_HIP_COSINE) {   // wide 0.7 reduce_add, non-AVX build
+        r = (((ac[0] + ac[1]) + ac[2]) + ac[3]) + (((ac[4] + ac[5]) + ac[6]) + ac[7]);
+        saa = (((aa[0] + aa[1]) + aa[2]) + aa[3]) + (((aa[4] + aa[5]) + aa[6]) + aa[7]);
+        sbb = (((bb[0] + bb[1]) + bb[2]) + bb[3]) + (((bb[4] + bb[5]) + bb[6]) + bb[7]);
+    } else {                             // horizontal_sum_f32_avx2
+        r = ((ac[0] + ac[4]) + (ac[1] + ac[5])) + ((ac[2] + ac[6]) + (ac[3] + ac[7]));
+    }
+    for (uint32_t j = chunks * 8; j < dim; ++j) {   // scalar tail, not fused
+        const float qv = sq[j], x = row[j];
+        if (measure == SCANN_HIP_DOT_PRODUCT) {
+            r = r + qv * x;
+        } else if (measure == SCANN_HIP_L1) {
+            r = r + fabsf(qv - x);
+        } else if (measure == SCANN_HIP_COSINE) {
+            r = r + qv * x;
+            saa = saa + qv * qv;
+            sbb = sbb + x * x;
+        } else {
+            const float d = qv - x;
+            r = r + d * d;
+        }
+    }
+    if (measure == SCANN_HIP_DOT_PRODUCT) r = -r;
+    if (measure == SCANN_HIP_L2) r = sqrtf(r);
+    if (measure == SCANN_HIP_COSINE) {
+        const float na = sqrtf(saa), nb = sqrtf(sbb);
+        r = 1.0f - ((na == 0.0f || nb == 0.0f) ? 0.0f : r / (na * nb));
+    }
+    return r;
+}
+
+struct SmallArgs {
+    uint32_t nq, P, m, k, cap, q_stride;
+    int exact_reorder;
+    const float *queries;
+    const uint32_t *tokens, *vbase;
+    uint64_t *cand;           // [nq][cap] dense: key of stream position v at cand[q][v]
+    uint32_t *counters;
+    const uint64_t *allow;
+    uint64_t allow_bits;
+    uint32_t *out_idx;
+    float *out_dist;
+    uint32_t *out_count;
+};
+
+__global__ __launch_bounds__(256) void small_scan_kernel(TxhIndexDev ix, SmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_lut[];   // [S][kp] then [dim] residual query
+    const uint32_t pair = blockIdx.y, q = pair / a.P, r = pair - q * a.P, chunk = blockIdx.x, tid = threadIdx.x;
+    if (pair == 0 && chunk == 0 && tid == 0) a.counters[CNT_STATUS] = 0;
+    const uint32_t leaf = a.tokens[(size_t)q * a.P + r];
+    const uint32_t lb = ix.leaf_off[leaf], size = ix.leaf_off[leaf + 1] - lb;
+    const uint32_t c0 = chunk * kSmallChunk;
+    if (c0 >= size) return;   // block-uniform
+    const uint32_t S = ix.S, K = ix.K, dsub = ix.dsub, kp = ix.kp, dim = ix.dim;
+    if (ix.exact_scan) {
+        // SearchMode::Partitioned (scann.rs:213-252) and brute force: every row scored exactly; the dense
+        // key list is then the whole result stream and the finish kernel takes its k smallest keys
+        float *s_qe = s_lut;
+        for (uint32_t j = tid; j < dim; j += 256) s_qe[j] = a.queries[(size_t)q * a.q_stride + j];
+        __syncthreads();
+        const uint32_t vbe = a.vbase[(size_t)q * (a.P + 1) + r];
+        uint64_t *oute = a.cand + (size_t)q * a.cap;
+        for (uint32_t j = c0 + tid; j < min(size, c0 + kSmallChunk); j += 256) {
+            const uint32_t csr = lb + j;
+            const float *row = ix.rows + (size_t)(ix.rows_csr ? csr : ix.leaf_ids[csr]) * ix.stride;
+            const float dist = exact_pair_thread(ix.measure, dim, s_qe, row);
+            const uint32_t vpos = vbe + j;
+            if (vpos < a.cap) oute[vpos] = make_key(dist, vpos);
+        }
+        return;
+    }
+    float *s_qr = s_lut + S * kp;
+    for (uint32_t j = tid; j < dim; j += 256) {   // residual q - centroid (mod.rs:309-316)
+        float v = a.queries[(size_t)q * a.q_stride + j];
+        if (ix.use_residuals) v = v - ix.centers[(size_t)leaf * dim + j];
+        s_qr[j] = v;
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < S * kp; e += 256) {   // LookupTable::from_query (lut.rs:47-70, codebook.rs:98-115)
+        const uint32_t sub = e / kp, c = e - sub * kp;
+        float acc = 0.0f;
+        if (c < K) {
+            const float *cb = ix.codebook + ((size_t)sub * K + c) * dsub;
+            for (uint32_t j = 0; j < dsub; ++j) {
+                const float d = s_qr[sub * dsub + j] - cb[j];
+                acc = acc + d * d;
+            }
+        }
+        s_lut[e] = acc;
+    }
+    __syncthreads();
+    const uint32_t vb = a.vbase[(size_t)q * (a.P + 1) + r];
+    const uint32_t bits = ix.code_bits, per = 32u / bits, mask = (1u << bits) - 1u, nw = ix.nw;
+    uint64_t *out = a.cand + (size_t)q * a.cap;
+    for (uint32_t j = c0 + tid; j < min(size, c0 + kSmallChunk); j += 256) {
+        const uint32_t *w = ix.codes + (size_t)(lb + j) * nw;
+        float acc = 0.0f;   // LookupTable::compute_distance (lut.rs:74-82): 0.0 + lut[0][c0] + lut[1][c1] ...
+        for (uint32_t sub = 0; sub < S; ++sub) {
+            const uint32_t code = (w[sub / per] >> (bits * (sub % per))) & mask;
+            const float tv = s_lut[sub * kp + code];
+            acc = sub == 0 ? tv : acc + tv;
+        }
+        const uint32_t vpos = vb + j;
+        if (vpos < a.cap)
+            out[vpos] = row_allowed(ix, a.allow, a.allow_bits, lb + j) ? make_key(acc, vpos) : SCANN_KEY_MAX;
+    }
+}
+
+__global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDev ix, SmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_q[];   // [dim]
+    __shared__ uint64_t s_keys[kSmallMaxM], s_slist[kSelListMax], s_red[48], s_fin[kFinGroups];
+    __shared__ uint32_t s_hist[kSelBinsMax], s_eb[kSmallMaxM], s_idx[kSmallMaxM], s_n;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = kSelectThreads;
+    const uint32_t P = a.P, m = a.m, k = a.k;
+    const uint32_t *vbq = a.vbase + (size_t)q * (P + 1);
+    const uint32_t cnt = min(vbq[P], a.cap);
+    const uint64_t *list = a.cand + (size_t)q * a.cap;
+    for (uint32_t j = tid; j < ix.dim; j += nt) s_q[j] = a.queries[(size_t)q * a.q_stride + j];
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    // the m smallest keys (keys are unique; SCANN_KEY_MAX = a point the restrict filter rejected).  m is
+    // far down the stream's tail (1000 of 100 k), so: minima of kFinGroups interleaved sub-streams -> the
+    // m-th smallest minimum is a pivot just above the m-th smallest key (the m smallest minima are m
+    // distinct keys) -> only the keys under the pivot are ranked.  Two passes over the list instead of
+    // the histogram select's five; the histogram select remains for m close to cnt.
+    uint64_t T = SCANN_KEY_MAX - 1;
+    if (cnt > m) {
+        bool done = false;
+        if ((uint64_t)m * 4 <= kFinGroups && cnt >= 4 * kFinGroups) {
+            constexpr int G = kFinGroups / kSelectThreads;   // sub-streams per thread
+            uint64_t mn[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) mn[g] = SCANN_KEY_MAX;
+            for (uint32_t i0 = 0; i0 < cnt; i0 += nt * G) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const uint32_t i = i0 + (uint32_t)g * nt + tid;
+                    const uint64_t key = i < cnt ? list[i] : SCANN_KEY_MAX;
+                    mn[g] = key < mn[g] ? key : mn[g];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) s_fin[(uint32_t)g * nt + tid] = mn[g];
+            __syncthreads();
+            const SelCfg gcfg = sel_cfg(kFinGroups);
+            const uint64_t pivot = block_select<uint64_t>(s_fin, kFinGroups, m, gcfg, s_hist, s_slist, s_red);
+            __syncthreads();
+            if (pivot != SCANN_KEY_MAX) {
+                if (tid == 0) s_n = 0;
+                __syncthreads();
+                for (uint32_t b0 = 0; b0 < cnt; b0 += nt) {   // keys under the pivot -> s_fin (reused)
+                    const uint32_t i = b0 + tid;
+                    const uint64_t key = i < cnt ? list[i] : SCANN_KEY_MAX;
+                    const bool keep = key <= pivot;
+                    uint32_t wtot;
+                    const uint32_t wpre = wave_prefix_count(keep, &wtot);
+                    uint32_t base = 0;
+                    if ((tid & 63u) == 0 && wtot) base = atomicAdd(&s_n, wtot);
+                    base = (uint32_t)__shfl((int)base, 0);
+                    if (keep && base + wpre < kFinGroups) s_fin[base + wpre] = key;
+                }
+                __syncthreads();
+                const uint32_t c2 = s_n;
+                __syncthreads();
+                if (c2 <= kFinGroups) {   // (>= m by construction)
+                    const uint64_t t = block_select<uint64_t>(s_fin, c2, m, sel_cfg(c2), s_hist, s_slist, s_red);
+                    if (t != SCANN_KEY_MAX) T = t;
+                    done = true;
+                    __syncthreads();
+                }
+                if (tid == 0) s_n = 0;
+                __syncthreads();
+            }
+        }
+        if (!done) {
+            const SelCfg cfg = sel_cfg(cnt);
+            const uint64_t t = block_select<uint64_t>(list, cnt, m, cfg, s_hist, s_slist, s_red);
+            if (t != SCANN_KEY_MAX) T = t;   // fewer than m allowed points: keep them all
+            __syncthreads();
+        }
+    }
+    for (uint32_t b0 = 0; b0 < cnt; b0 += nt) {
+        const uint32_t i = b0 + tid;
+        uint64_t key = SCANN_KEY_MAX;
+        if (i < cnt) key = list[i];
+        const bool keep = key <= T;
+        uint32_t wtot;
+        const uint32_t wpre = wave_prefix_count(keep, &wtot);
+        uint32_t base = 0;
+        if ((tid & 63u) == 0 && wtot) base = atomicAdd(&s_n, wtot);
+        base = (uint32_t)__shfl((int)base, 0);
+        if (keep && base + wpre < kSmallMaxM) s_keys[base + wpre] = key;
+    }
+    __syncthreads();
+    const uint32_t nsel = min(s_n, min(m, kSmallMaxM));
+    // decode tables of this query (key base and first CSR row of each selected leaf) in LDS: the
+    // per-candidate chain vbase -> token -> leaf_off is otherwise three dependent global loads per pass
+    uint32_t *s_dvb = reinterpret_cast<uint32_t *>(s_fin), *s_drow = s_dvb + kDecodeStage;   // (s_fin is free now)
+    const bool staged = P <= kDecodeStage;
+    if (staged)
+        for (uint32_t r = tid; r < P; r += nt) {
+            s_dvb[r] = vbq[r];
+            s_drow[r] = ix.leaf_off[a.tokens[(size_t)q * P + r]];
+        }
+    __syncthreads();
+    // decode + exact distance: 8 lanes per candidate
+    const uint32_t lane8 = tid & 7u;
+    for (uint32_t b0 = 0; b0 < nsel; b0 += nt / 8) {
+        const uint32_t c = b0 + (tid >> 3);
+        const bool act = c < nsel;
+        uint32_t idx = 0, rowi = 0;
+        if (act) {
+            const uint32_t vpos = (uint32_t)s_keys[c];
+            uint32_t lo = 0, hi = P;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((staged ? s_dvb[mid] : vbq[mid]) <= vpos) lo = mid; else hi = mid;
+            }
+            const uint32_t csr = staged ? s_drow[lo] + (vpos - s_dvb[lo])
+                                        : ix.leaf_off[a.tokens[(size_t)q * P + lo]] + (vpos - vbq[lo]);
+            idx = ix.leaf_ids ? ix.leaf_ids[csr] : csr;
+            rowi = ix.rows_csr ? csr : idx;
+        }
+        float r = 0.0f;
+        if (a.exact_reorder) r = exact_pair_8lanes(ix, s_q, ix.rows + (size_t)rowi * ix.stride, act, lane8);
+        if (act && lane8 == 0) {
+            s_idx[c] = idx;
+            // without re-ordering the k best by approximate distance are wanted: order by the key itself
+            s_eb[c] = a.exact_reorder ? f32_to_ordered(r) : (uint32_t)(s_keys[c] >> 32);
+        }
+    }
+    __syncthreads();
+    const uint32_t nout = min(k, nsel);
+    if (tid < 64) {   // the k best by (exact, merge key): wave 0, strided entries, k arg-min rounds
+        constexpr int E = kSmallMaxM / 64;
+        uint32_t eb[E];
+        uint64_t kk[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t j = (uint32_t)e * 64u + tid;
+            eb[e] = j < nsel ? s_eb[j] : 0xFFFFFFFFu;
+            kk[e] = j < nsel ? s_keys[j] : SCANN_KEY_MAX;
+        }
+        for (uint32_t r0 = 0; r0 < nout; ++r0) {
+            uint32_t b_eb = 0xFFFFFFFFu, b_sl = 0xFFFFFFFFu;
+            uint64_t b_kk = SCANN_KEY_MAX;
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if ((uint32_t)e * 64u < nsel && (eb[e] < b_eb || (eb[e] == b_eb && kk[e] < b_kk))) {
+                    b_eb = eb[e];
+                    b_kk = kk[e];
+                    b_sl = (uint32_t)e * 64u + tid;
+                }
+            wave_argmin96(b_eb, b_kk, b_sl);
+            if (b_sl != 0xFFFFFFFFu && (b_sl & 63u) == tid) {
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if ((uint32_t)e == (b_sl >> 6)) {
+                        eb[e] = 0xFFFFFFFFu;
+                        kk[e] = SCANN_KEY_MAX;
+                    }
+            }
+            if (tid == 0) {
+                a.out_idx[(size_t)q * k + r0] = s_idx[b_sl];
+                a.out_dist[(size_t)q * k + r0] = ordered_to_f32(b_eb);
+            }
+        }
+    }
+    for (uint32_t i = nout + tid; i < k; i += nt) {
+        a.out_idx[(size_t)q * k + i] = kInvalid;
+        a.out_dist[(size_t)q * k + i] = __builtin_inff();
+    }
+    if (tid == 0) a.out_count[q] = nout;
+}
+
+// =====================================================================================
 // Multi-GPU merge of gathered (key, idx, exact) triples [world][nq][m].  Every rank's
 // list is sorted by key and keys are unique per query, so an element's position in the
 // merged order is the number of smaller keys over all lists (binary searches); no sort
@@ -2839,7 +3205,7 @@ static int launch_partition_stage(const TxhIndexDev &ix, const TxhWork &w, hipSt
     SCANN_TRY(set_dyn_lds(select_leaves_kernel, lds2));
     hipLaunchKernelGGL(select_leaves_kernel, dim3(w.nq), dim3(p2 && ix.L <= 4096 ? 256u : kSelectThreads), lds2, st,
                        w.cdist, ix.L, n2, w.P, p2, ix.leaf_gsize, ix.leaf_off, w.st, w.tokens, w.token_dists,
-                       w.vbase, w.sbase);
+                       w.vbase, w.sbase, (const float *)nullptr, (const float *)nullptr, 0u, 0u);
     LAUNCH_CHECK();
     return SCANN_HIP_OK;
 }
@@ -2981,9 +3347,47 @@ static int launch_exact_scan(const TxhIndexDev &ix, const TxhWork &w, hipStream_
     return SCANN_HIP_OK;
 }
 
+// the three-launch pipeline for small batches (see "Small batches" above)
+static int launch_search_small(const TxhIndexDev &ix, const TxhWork &w, hipStream_t st, hipEvent_t ev0,
+                               hipEvent_t ev1) {
+    if (ix.ah_mode) {
+        hipLaunchKernelGGL(ah_tokens_kernel, dim3(ceil_div_u32(w.nq, 256)), dim3(256), 0, st, w.nq,
+                           ix.leaf_gsize, ix.leaf_off, w.st, w.tokens, w.token_dists, w.vbase, w.sbase);
+    } else {
+        const uint32_t n2 = next_pow2_u32(ix.L);
+        const uint32_t p2 = (w.P * 4u <= n2) ? next_pow2_u32(std::max(1u, w.P)) : 0u;
+        const SelCfg lcfg = sel_cfg(ix.L);
+        const size_t lds2 = (size_t)(n2 + p2) * sizeof(uint64_t) + (size_t)lcfg.bins * 4 + (size_t)lcfg.list * 8 +
+                            48 * 8 + 64 * 4;
+        SCANN_TRY(set_dyn_lds(select_leaves_kernel, lds2));
+        hipLaunchKernelGGL(select_leaves_kernel, dim3(w.nq), dim3(kSelectThreads), lds2, st, w.cdist, ix.L, n2, w.P, p2,
+                           ix.leaf_gsize, ix.leaf_off, w.st, w.tokens, w.token_dists, w.vbase, w.sbase, ix.centers,
+                           w.queries, w.q_stride, ix.dim);
+    }
+    LAUNCH_CHECK();
+    SmallArgs a;
+    a.nq = w.nq; a.P = w.P; a.m = w.m; a.k = w.k; a.cap = w.cap; a.q_stride = w.q_stride;
+    a.exact_reorder = w.exact_reorder; a.queries = w.queries; a.tokens = w.tokens; a.vbase = w.vbase;
+    a.cand = w.cand; a.counters = w.counters; a.allow = w.allow; a.allow_bits = w.allow_bits;
+    a.out_idx = w.out_idx; a.out_dist = w.out_dist; a.out_count = w.out_count;
+    const size_t lds_scan = ((size_t)(ix.exact_scan ? 0u : ix.S * ix.kp) + ix.dim) * sizeof(float);
+    SCANN_TRY(set_dyn_lds(small_scan_kernel, lds_scan));
+    if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
+    hipLaunchKernelGGL(small_scan_kernel, dim3(ceil_div_u32(w.small_max_leaf, kSmallChunk), w.nq * w.P), dim3(256),
+                       lds_scan, st, ix, a);
+    LAUNCH_CHECK();
+    if (ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
+    const size_t lds_fin = (size_t)ix.dim * sizeof(float);
+    SCANN_TRY(set_dyn_lds(small_finish_kernel, lds_fin));
+    hipLaunchKernelGGL(small_finish_kernel, dim3(w.nq), dim3(kSelectThreads), lds_fin, st, ix, a);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
 int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, hipStream_t st,
                       hipEvent_t ev0, hipEvent_t ev1) {
     if (w.nq == 0) return SCANN_HIP_OK;
+    if (w.small && !local_only && !w.need_sorted_cands) return launch_search_small(ix, w, st, ev0, ev1);
     {
         const uint32_t work = std::max(std::max(ix.L, w.nq), w.max_slots);
         hipLaunchKernelGGL(txh_init_kernel, dim3(std::min(1024u, ceil_div_u32(work, 256))), dim3(256), 0, st,

@@ -393,6 +393,9 @@ int main(int argc, char **argv) {
         const double recall = average_recall_at_k(retrieved, data.gt, args.k);
         const double qps = search_seconds > 0.0 ? (double)data.test.size() / search_seconds : 0.0;
 
+        // (one untimed call first: the per-query loop above runs on the small-batch pipeline, so the batch
+        // path's workspaces are still unallocated, and a first call would time hipMalloc)
+        (void)index.search_batched(data.test, args.k);
         t0 = std::chrono::steady_clock::now();
         const auto batched = index.search_batched(data.test, args.k);
         const double batched_seconds = seconds_since(t0);

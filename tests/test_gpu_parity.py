@@ -798,6 +798,7 @@ def force_shortlist(monkeypatch):
     small test cases (read at index creation / per search)."""
     monkeypatch.setenv("SCANN_HIP_BF_SHORTLIST_MIN_ROWS", "1")
     monkeypatch.setenv("SCANN_HIP_BF_SHORTLIST_MIN_QUERIES", "1")
+    monkeypatch.setenv("SCANN_HIP_SMALL", "0")      # (batches of <= 16 queries would take the small-batch pipeline)
 
 
 @pytest.mark.parametrize("measure", [hip.DOT_PRODUCT, hip.SQUARED_L2, hip.L2])
