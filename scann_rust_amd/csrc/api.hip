@@ -870,7 +870,8 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
         }
         TxhWork w;
         SCANN_TRY(ensure_txh_workspace(ix, ws, nq, p, true, q_stride, true, &w));
-        w.need_sorted_cands = (opts && (opts->cand_idx || opts->cand_dist)) ? 1 : 0;
+        // (cand_count alone also takes the staged pipeline: the small-batch one keeps no candidate counts)
+        w.need_sorted_cands = (opts && (opts->cand_idx || opts->cand_dist || opts->cand_count)) ? 1 : 0;
         const bool stage_outputs = opts && (opts->tokens || opts->token_dists || opts->cand_idx || opts->cand_dist ||
                                             opts->cand_count);
         if (w.small && !stage_outputs && !(opts && opts->allow_bitmap)) {

@@ -1241,3 +1241,105 @@ def test_l1_cosine_reference_known_answers_on_gpu():
     data, stride = orc.to_strided(rows)
     d = hip.bf_distances(hip.bf_create(data, 3, 2, stride, hip.COSINE), np.array([[1, 0]], np.float32))
     assert abs(d[0, 0]) < 1e-6 and abs(d[0, 1] - 1.0) < 1e-6 and d[0, 2] == np.float32(1.0)
+
+
+# ---- small-batch pipeline (txh.hip "Small batches"): 1..16 queries, three launches ------------------------
+def _small_cases():
+    yield "txh_residual", None
+    yield "txh_byte_codes", None
+    yield "ah_flat", None
+    for m_ in (hip.SQUARED_L2, hip.DOT_PRODUCT, hip.L2, hip.L1, hip.COSINE):
+        yield "partitioned", m_
+    for m_ in (hip.SQUARED_L2, hip.DOT_PRODUCT, hip.L2, hip.L1, hip.COSINE):
+        yield "bf", m_
+
+
+@pytest.mark.parametrize("kind,measure", list(_small_cases()))
+def test_small_batch_pipeline_matches_staged_pipeline(kind, measure, monkeypatch):
+    """Calls of <= 16 queries run select_leaves (inline centroid scoring) -> small_scan -> small_finish with
+    pinned zero-copy staging; SCANN_HIP_SMALL=0 sends the same call down the staged pipeline the batched
+    parity tests pin to the oracle. Rows, distance bits and counts must be identical for every searcher
+    kind and measure, for 1, 7 and 16 queries, for k above the scanned stream (short results), and with an
+    allow-bitmap; a few queries are also checked against the oracle directly."""
+    o = hip.default_opts()
+    oracle = None
+    if kind == "txh_residual":
+        rows, data, stride, ix, oix, kw = H.make_txh_case(9000, 96, 30, 24, seed=61, P=7, mult=12.0, kmeans_iters=3,
+                                                          pq_iters=3)
+        o.partitions_to_search, o.pre_reorder_k = 7, 120
+        n = 9000
+        oracle = lambda qv, k: orc.txh_search(oix, qv, k)
+        oix.partitions_to_search, oix.pre_reorder_multiplier = 7, 12.0
+        index = hip.txh_create(**kw)
+    elif kind == "txh_byte_codes":
+        rows, data, stride, ix, oix, kw = H.make_txh_case(6000, 64, 16, 8, seed=62, K=256, P=4, mult=10.0,
+                                                          kmeans_iters=3, pq_iters=2)
+        o.partitions_to_search, o.pre_reorder_k = 4, 100
+        n = 6000
+        index = hip.txh_create(**kw)
+    elif kind == "ah_flat":
+        rows, data, stride, ix, kw = H.make_ah_case(12000, 128, 32, seed=63, pq_iters=3)
+        o.pre_reorder_k, o.exact_reorder = 150, 1
+        n = 12000
+        oracle = lambda qv, k: orc.ah_search_with_reordering(ix["codebook"], ix["codes"], data, stride, qv, k, 150)
+        index = hip.txh_create(**kw)
+    elif kind == "partitioned":
+        n, dim = 5000, 100
+        rows, data, stride, centers, leaf_off, leaf_ids = _partition_case(n, dim, 23, seed=64)
+        index = hip.txh_create(data=data, n_rows=n, dim=dim, stride=stride, centers=centers, leaf_offsets=leaf_off,
+                               leaf_ids=leaf_ids, codebook=None, codes=None, partitions_to_search=5,
+                               distance_measure=measure)
+        oracle = lambda qv, k: orc.scann_search_partitioned(centers, leaf_off, leaf_ids, data, stride, measure, qv, 5, k)
+    else:
+        n, dim = 7000, 72
+        rows = synth.uniform_f32(n, dim, 65) - np.float32(0.4)
+        rows[5] = 0.0
+        data, stride = orc.to_strided(rows)
+        index = hip.bf_create(data, n, dim, stride, measure)
+        oracle = lambda qv, k: orc.bf_search(data, n, dim, stride, measure, qv, k)
+        o = None
+    dim = index.dimensionality()
+    q = synth.uniform_f32(16, dim, 66) - np.float32(0.2 if kind == "bf" else 0.0)
+    q[4] = rows[123]
+    allow = hip.allow_bitmap(n, np.arange(1, n, 5))
+    for nq in (1, 7, 16):
+        for k in (10, 1, 64):
+            monkeypatch.delenv("SCANN_HIP_SMALL", raising=False)
+            a = index.search_batched(q[:nq], k, o)
+            monkeypatch.setenv("SCANN_HIP_SMALL", "0")
+            b = index.search_batched(q[:nq], k, o)
+            assert np.array_equal(a[2], b[2]), (kind, nq, k)
+            assert np.array_equal(bits(a[1]), bits(b[1])), (kind, nq, k)
+            assert np.array_equal(a[0], b[0]), (kind, nq, k)
+        if oracle is not None:
+            monkeypatch.delenv("SCANN_HIP_SMALL", raising=False)
+            gi, gd, gc = index.search_batched(q[:nq], 10, o)
+            for i in range(min(nq, 3)):
+                oi, od = oracle(q[i], 10)
+                assert gc[i] == oi.size
+                H.assert_topk_equal_up_to_ties(gi[i, :oi.size], gd[i, :oi.size], oi, od, what="%s small q%d" % (kind, i))
+    if kind not in ("bf", "partitioned"):   # search_with_filter through the small pipeline (the partitioned
+        monkeypatch.delenv("SCANN_HIP_SMALL", raising=False)   # and brute-force searchers take no filter)
+        fa = index.search_batched(q[:9], 10, o, allow=allow)
+        o.allow_bitmap, o.allow_bitmap_bits = None, 0
+        monkeypatch.setenv("SCANN_HIP_SMALL", "0")
+        fb = index.search_batched(q[:9], 10, o, allow=allow)
+        o.allow_bitmap, o.allow_bitmap_bits = None, 0
+        assert np.array_equal(fa[0], fb[0]) and np.array_equal(bits(fa[1]), bits(fb[1])) and np.array_equal(fa[2], fb[2])
+        assert np.all(fa[0][fa[0] != 0xFFFFFFFF] % 5 == 1)
+    if kind != "bf":   # the token outputs through the small pipeline
+        if kind != "ah_flat":
+            P = o.partitions_to_search or 5
+            toks = []
+            for env in (None, "0"):
+                if env is None:
+                    monkeypatch.delenv("SCANN_HIP_SMALL", raising=False)
+                else:
+                    monkeypatch.setenv("SCANN_HIP_SMALL", env)
+                tok = np.zeros((9, P), np.uint32); tokd = np.zeros((9, P), np.float32)
+                o2 = hip.default_opts()
+                o2.partitions_to_search, o2.pre_reorder_k, o2.exact_reorder = P, o.pre_reorder_k, o.exact_reorder
+                o2.tokens, o2.token_dists = hip.ptr(tok, hip.u32p), hip.ptr(tokd, hip.f32p)
+                index.search_batched(q[:9], 10, o2)
+                toks.append((tok, tokd))
+            assert np.array_equal(toks[0][0], toks[1][0]) and np.array_equal(bits(toks[0][1]), bits(toks[1][1]))
