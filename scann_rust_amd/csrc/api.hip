@@ -40,7 +40,7 @@ struct TxhWorkspace {
     DevBuf queries, cdist, tokens, token_dists, vbase, leaf_cnt, leaf_cursor, pair_off, tile_off,
         counters, pair_q, pair_leaf, pair_vbase, pair_thr, slot_of, lutq, thr, cand_cnt, cand, cand_key,
         cand_idx, cand_dist, cand_exact, cand_row, cand_count, out_idx, out_dist, out_count, allow,
-        sbase, pair_sbase, stile_off, samp, lut8, lut8_meta, cand32, cand32_cnt, mfma_thr1, rr_lb, rr_ub;
+        sbase, pair_sbase, stile_off, samp, lut8, lut8_meta, cand32, cand32_codes, cand32_cnt, mfma_thr1, rr_lb, rr_ub;
 };
 
 // Pinned host memory the GPU reads and writes in place (grow-only).  Small host-side searches keep
@@ -731,6 +731,7 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
     w->lut8_meta = nullptr;
     w->mfma_thr1 = nullptr;
     w->cand32 = nullptr;
+    w->cand32_codes = nullptr;
     w->cand32_cnt = nullptr;
     w->cap32 = 0;
     if (w->mfma) {
@@ -741,11 +742,13 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
         SCANN_TRY(s.lut8_meta.ensure((size_t)(max_slots + 4) * 16));
         SCANN_TRY(s.mfma_thr1.ensure((size_t)(max_slots + 4) * 4));
         SCANN_TRY(s.cand32.ensure((size_t)nq * cap32 * 4));
+        SCANN_TRY(s.cand32_codes.ensure((size_t)nq * cap32 * (t.S / 8) * 4));   // the survivors' packed codes
         SCANN_TRY(s.cand32_cnt.ensure((size_t)nq * 4));
         w->lut8 = s.lut8.as<int8_t>();
         w->lut8_meta = s.lut8_meta.p;
         w->mfma_thr1 = s.mfma_thr1.as<int>();
         w->cand32 = s.cand32.as<uint32_t>();
+        w->cand32_codes = s.cand32_codes.as<uint32_t>();
         w->cand32_cnt = s.cand32_cnt.as<uint32_t>();
         w->cap32 = (uint32_t)cap32;
     }

@@ -143,6 +143,7 @@ struct TxhWork {
     int *mfma_thr1;            // [max_slots] integer pass bound + 1 of every pair slot
     uint32_t *cand32_cnt;      // [nq]
     uint32_t *cand32;          // [nq][cap32] stream positions of the prefilter's survivors
+    uint32_t *cand32_codes;    // [nq][cap32][S/8] their packed codes (written next to the positions)
     uint32_t cap32;
     uint32_t *sbase;           // [nq][P+2] prefix of per-leaf sample counts; [P]=samples, [P+1]=local points
     uint32_t *pair_sbase;      // [max_slots]

@@ -507,6 +507,16 @@ struct Codec {
             for (int wi = 0; wi < NWORDS; ++wi) w[wi] = src[wi];
         }
     }
+    __device__ static __forceinline__ void store_words(uint32_t *dst, const uint32_t (&w)[NWORDS]) {
+        if constexpr (NWORDS == 4) {
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else if constexpr (NWORDS == 2) {
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(w[0], w[1]);
+        } else {
+#pragma unroll
+            for (int wi = 0; wi < NWORDS; ++wi) dst[wi] = w[wi];
+        }
+    }
 };
 
 // Points G .. G+NP-1 of the lane against the quad's tables.
@@ -1108,6 +1118,7 @@ struct MfmaArgs {
     const uint64_t *pair_thr;
     uint32_t *cand32_cnt;     // [nq]
     uint32_t *cand32;         // [nq][cap32] stream positions of the prefilter's survivors
+    uint32_t *cand32_codes;   // [nq][cap32][S/8] their packed codes: the refine reads them in list order
     uint32_t cap32;
 };
 
@@ -1119,6 +1130,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
     __shared__ __attribute__((aligned(16))) uint32_t s_ident[64];                 // 16 one-hot rows of 16 bytes
     __shared__ uint32_t s_stage[kMfmaWaves][32][kMfmaStage];
     __shared__ uint32_t s_cnt[kMfmaWaves][32];
+    __shared__ uint32_t s_fpre[kMfmaWaves][32], s_fq[kMfmaWaves][32], s_fgb[kMfmaWaves][32], s_fvb[kMfmaWaves][32];   // flush: per pair
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t col = lane & 31u, h = lane >> 5;
     // row c (16 bytes = words 4c .. 4c+3): byte c set to 1  ->  word 4c + (c >> 2) holds 1 << 8*(c & 3)
@@ -1193,13 +1205,39 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
                     s_cnt[wave][lane] = 0;
                 }
             }
-            unsigned long long todo = __ballot(n != 0);
-            while (todo) {
-                const int c = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const uint32_t nc = (uint32_t)__shfl((int)n, c), bc = (uint32_t)__shfl((int)gbase, c);
-                const uint32_t qc = (uint32_t)__shfl((int)pq, c), vc = (uint32_t)__shfl((int)vb, c);
-                if (lane < nc && bc + lane < a.cap32) a.cand32[(size_t)qc * a.cap32 + bc + lane] = vc + s_stage[wave][c][lane];
+            // all flushed pairs as ONE list spread over the 64 lanes: entry e belongs to the pair c with
+            // pre[c] <= e < pre[c] + n[c]; its position and its packed codes (the tile's lines are still in
+            // L2) go to slot gbase[c] + (e - pre[c]) of the query's list
+            uint32_t incl = n;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+                if ((int)lane >= o) incl += up;
+            }
+            const uint32_t total = (uint32_t)__shfl((int)incl, 31);
+            if (total == 0) return;
+            if (lane < 32) {
+                s_fpre[wave][lane] = incl - n;
+                s_fq[wave][lane] = pq == kInvalid ? 0u : pq;
+                s_fgb[wave][lane] = gbase;
+                s_fvb[wave][lane] = vb;
+            }
+            // (per-pair values through LDS, not shuffles: the loop's last pass runs with lanes switched off)
+            for (uint32_t e = lane; e < total; e += 64u) {
+                uint32_t c = 0;
+#pragma unroll
+                for (uint32_t stp = 16; stp; stp >>= 1)
+                    if (s_fpre[wave][c + stp] <= e) c += stp;
+                const uint32_t idx = e - s_fpre[wave][c];
+                const uint32_t j = s_stage[wave][c][idx];
+                const uint32_t dst = s_fgb[wave][c] + idx;
+                if (dst < a.cap32) {
+                    const size_t o = (size_t)s_fq[wave][c] * a.cap32 + dst;
+                    uint32_t cw[NW];
+                    Codec<S, 4>::load_words(ix.codes + (size_t)(lb + j) * NW, cw);
+                    a.cand32[o] = s_fvb[wave][c] + j;
+                    Codec<S, 4>::store_words(a.cand32_codes + o * NW, cw);
+                }
             }
         };
         auto step = [&](v16i &accN, const v16i &accO, uint32_t t) {
@@ -1255,7 +1293,13 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
                         s_stage[wave][col][sl] = j;
                     } else {   // stage full: direct (slow) append
                         const uint32_t pos = atomicAdd(&a.cand32_cnt[pq], 1u);
-                        if (pos < a.cap32) a.cand32[(size_t)pq * a.cap32 + pos] = vb + j;
+                        if (pos < a.cap32) {
+                            const size_t o = (size_t)pq * a.cap32 + pos;
+                            uint32_t cw[NW];
+                            Codec<S, 4>::load_words(ix.codes + (size_t)(lb + j) * NW, cw);
+                            a.cand32[o] = vb + j;
+                            Codec<S, 4>::store_words(a.cand32_codes + o * NW, cw);
+                        }
                     }
                     ++sl;
                 } while (m16);
@@ -1263,10 +1307,13 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
             }
             if (__any(risk)) flush(false);
         };
+        // (tile 0 is peeled: inside the loop t >= 1 is known, so the compiler keeps the mask build between
+        // the MFMAs in BOTH instances instead of sinking it below a `t == 0` branch)
         v16i accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA;
-        for (uint32_t tl = 0; tl <= ntile; tl += 2) {
-            step(accA, accB, tl);
-            if (tl + 1 <= ntile) step(accB, accA, tl + 1);
+        step(accA, accB, 0u);
+        for (uint32_t tl = 1; tl <= ntile; tl += 2) {
+            step(accB, accA, tl);
+            if (tl + 1 <= ntile) step(accA, accB, tl + 1);
         }
         flush(true);
         tile = __builtin_amdgcn_readfirstlane(next_tile);
@@ -1281,7 +1328,7 @@ struct RefineArgs {
     const uint32_t *tokens, *vbase, *slot_of;
     const float *lutq;
     const uint64_t *thr;
-    const uint32_t *cand32_cnt, *cand32;
+    const uint32_t *cand32_cnt, *cand32, *cand32_codes;
     uint32_t *cand_cnt;
     uint64_t *cand;
     uint32_t *counters;
@@ -1334,6 +1381,7 @@ __global__ __launch_bounds__(kRefineThreads) void adc_refine_kernel(TxhIndexDev 
     }
     uint64_t *out = a.cand + (size_t)q * a.cap;
     const uint32_t *list = a.cand32 + (size_t)q * a.cap32;
+    const uint32_t *list_codes = a.cand32_codes + (size_t)q * a.cap32 * NW;
     constexpr int U = SCANN_REFINE_U;   // entries per thread per pass: their dependent loads (position -> codes) overlap
     for (uint32_t b0 = 0; b0 < cnt; b0 += kRefineThreads * U) {
         uint32_t vpos[U], csr[U], lo_[U];
@@ -1342,6 +1390,7 @@ __global__ __launch_bounds__(kRefineThreads) void adc_refine_kernel(TxhIndexDev 
         for (int u = 0; u < U; ++u) {
             const uint32_t e = b0 + tid + kRefineThreads * u;
             vpos[u] = e < cnt ? list[e] : 0xFFFFFFFFu;
+            C::load_words(list_codes + (size_t)(e < cnt ? e : 0u) * NW, w[u]);   // (written with the position)
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1353,7 +1402,6 @@ __global__ __launch_bounds__(kRefineThreads) void adc_refine_kernel(TxhIndexDev 
             }
             lo_[u] = lo;
             csr[u] = (staged ? s_drow[lo] : ix.leaf_off[a.tokens[(size_t)q * P + lo]]) + (vp - (staged ? s_dvb[lo] : vbq[lo]));
-            C::load_words(ix.codes + (size_t)(vpos[u] == 0xFFFFFFFFu ? 0u : csr[u]) * NW, w[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -3252,7 +3300,7 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
             ma.thr1 = w.mfma_thr1;
             ma.pair_off = w.pair_off; ma.tile_off = w.tile_off; ma.pair_q = w.pair_q; ma.pair_vbase = w.pair_vbase;
             ma.counters = w.counters; ma.lut8 = w.lut8; ma.meta = reinterpret_cast<const Lut8Meta *>(w.lut8_meta);
-            ma.pair_thr = w.pair_thr; ma.cand32_cnt = w.cand32_cnt; ma.cand32 = w.cand32; ma.cap32 = w.cap32;
+            ma.pair_thr = w.pair_thr; ma.cand32_cnt = w.cand32_cnt; ma.cand32 = w.cand32; ma.cand32_codes = w.cand32_codes; ma.cap32 = w.cap32;
             if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
             uint32_t mwgs = 4;   // workgroups per CU (4 waves each)
             if (const char *e = std::getenv("SCANN_HIP_MFMA_WGS")) mwgs = (uint32_t)std::max(1, std::atoi(e));
@@ -3262,7 +3310,7 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
             RefineArgs ra;
             ra.P = w.P; ra.cap = w.cap; ra.cap32 = w.cap32; ra.tokens = w.tokens; ra.vbase = w.vbase;
             ra.slot_of = w.slot_of; ra.lutq = w.lutq; ra.thr = w.thr; ra.cand32_cnt = w.cand32_cnt;
-            ra.cand32 = w.cand32; ra.cand_cnt = w.cand_cnt; ra.cand = w.cand; ra.counters = w.counters;
+            ra.cand32 = w.cand32; ra.cand32_codes = w.cand32_codes; ra.cand_cnt = w.cand_cnt; ra.cand = w.cand; ra.counters = w.counters;
             ra.allow = w.allow; ra.allow_bits = w.allow_bits;
             const size_t lds_rf = w.P <= kRefineTablesMax ? (size_t)w.P * C::S * 16 * sizeof(float) : 16;
             SCANN_TRY(set_dyn_lds(adc_refine_kernel<C>, lds_rf));
