@@ -381,6 +381,26 @@ int scann_hip_lut16_distances_batch(scann_hip_ctx *ctx, const uint8_t *packed_co
  * = 1.  S == 0 -> bias 0, multiplier 1, nothing written.  Runs on the device (one workgroup). */
 int scann_hip_lut16_quantize(scann_hip_ctx *ctx, const float *tables, uint32_t num_subspaces,
                              uint8_t *out_lut8, float *out_bias, float *out_multiplier);
+/* The reference's FP8 codec and quantizer (quantization/fp8.rs:80-268) -- its own bit-level conversion,
+ * not a hardware format table: exponent bias 7 (E4M3) / 15 (E5M2); a mantissa carry wraps without bumping
+ * the exponent; the top exponent field only encodes the maximum (0x7E / 0x7C: overflow, infinity, NaN);
+ * values under the smallest normal flush to signed zero.
+ *   quantize:   out[i] = from_f32(values[i] * scale)      (Quantizer::quantize over Fp8Quantizer, :247-255)
+ *   dequantize: out[i] = to_f32(bits[i]) / scale          (:257-264)
+ * (calibrate_scale, :238-244, is fp8_max / max(max_abs, 1e-10) with fp8_max 448 / 57344: a host one-liner.) */
+#define SCANN_HIP_FP8_E4M3 0
+#define SCANN_HIP_FP8_E5M2 1
+int scann_hip_fp8_quantize(scann_hip_ctx *ctx, const float *values, uint64_t n, float scale, int format,
+                           uint8_t *out_bits);
+int scann_hip_fp8_dequantize(scann_hip_ctx *ctx, const uint8_t *bits, uint64_t n, float scale, int format,
+                             float *out_values);
+/* one_to_many_fp8_float_squared_l2 / one_to_many_fp8_float_dot_product
+ * (distance_measures/one_to_many_asymmetric.rs:327-377): f32 query against E4M3 rows [num_points][stride],
+ * one sequential f32 sum per row; measure SCANN_HIP_SQUARED_L2 or SCANN_HIP_DOT_PRODUCT (negated), others
+ * Unimplemented.  Bit-identical to the reference's loops.  The same codec, with a per-row calibrate_scale,
+ * is the optional FP8 row store of the re-rank filter (SCANN_HIP_RERANK_STORE=fp8 at index creation). */
+int scann_hip_fp8_distances(scann_hip_ctx *ctx, const float *query, uint32_t dim, const uint8_t *database,
+                            uint64_t stride, uint64_t num_points, int measure, float *out_distances);
 /* Codebook::encode over rows (hashes/codebook.rs:82-95, 205-215); optional residual
  * against centers[leaf_of_row[i]] (tree_x_hybrid/mod.rs:177-189).  out_codes [n][S]. */
 int scann_hip_encode(scann_hip_ctx *ctx, const float *codebook, uint32_t num_subspaces,

@@ -119,6 +119,15 @@ def lib():
                                             u32p, f32p, u32p, C.c_int]
         L.or_reorder.restype = sz
         L.or_reorder.argtypes = [f32p, sz, sz, f32p, u32p, sz, sz, u32p, f32p]
+        L.or_fp8_from_f32.restype = C.c_uint8
+        L.or_fp8_from_f32.argtypes = [C.c_float, C.c_int]
+        L.or_fp8_to_f32.restype = C.c_float
+        L.or_fp8_to_f32.argtypes = [C.c_uint8, C.c_int]
+        L.or_fp8_calibrate_scale.restype = C.c_float
+        L.or_fp8_calibrate_scale.argtypes = [C.c_float, C.c_int]
+        L.or_fp8_quantize.argtypes = [f32p, sz, C.c_float, C.c_int, u8p]
+        L.or_fp8_dequantize.argtypes = [u8p, sz, C.c_float, C.c_int, f32p]
+        L.or_one_to_many_fp8.argtypes = [f32p, sz, u8p, sz, sz, C.c_int, f32p]
         L.or_l1_avx2.restype = C.c_float
         L.or_l1_avx2.argtypes = [f32p, f32p, sz]
         L.or_cosine_distance.restype = C.c_float
@@ -348,6 +357,44 @@ def lut16_quantize(tables):
     bias = C.c_float(); mult = C.c_float()
     lib().or_lut16_quantize(pt, S, lut8.ctypes.data_as(u8p), C.byref(bias), C.byref(mult))
     return lut8, float(bias.value), float(mult.value)
+
+
+FP8_E4M3, FP8_E5M2 = 0, 1
+
+
+def fp8_from_f32(value, fmt=FP8_E4M3):
+    return int(lib().or_fp8_from_f32(float(np.float32(value)), fmt))
+
+
+def fp8_to_f32(bits, fmt=FP8_E4M3):
+    return np.float32(lib().or_fp8_to_f32(int(bits), fmt))
+
+
+def fp8_calibrate_scale(max_abs, fmt=FP8_E4M3):
+    return np.float32(lib().or_fp8_calibrate_scale(float(np.float32(max_abs)), fmt))
+
+
+def fp8_quantize(values, scale=1.0, fmt=FP8_E4M3):
+    v = np.ascontiguousarray(values, np.float32)
+    out = np.empty(v.shape, np.uint8)
+    lib().or_fp8_quantize(v.ctypes.data_as(f32p), v.size, float(np.float32(scale)), fmt, out.ctypes.data_as(u8p))
+    return out
+
+
+def fp8_dequantize(bits, scale=1.0, fmt=FP8_E4M3):
+    b = np.ascontiguousarray(bits, np.uint8)
+    out = np.empty(b.shape, np.float32)
+    lib().or_fp8_dequantize(b.ctypes.data_as(u8p), b.size, float(np.float32(scale)), fmt, out.ctypes.data_as(f32p))
+    return out
+
+
+def one_to_many_fp8(query, database, stride, n, measure):
+    q = np.ascontiguousarray(query, np.float32)
+    db = np.ascontiguousarray(database, np.uint8)
+    out = np.empty(n, np.float32)
+    lib().or_one_to_many_fp8(q.ctypes.data_as(f32p), q.size, db.ctypes.data_as(u8p), stride, n, measure,
+                             out.ctypes.data_as(f32p))
+    return out
 
 
 def lut16_distances_batch_raw(packed, lut8, S, n):

@@ -1138,3 +1138,74 @@ int or_kmeans_lloyd(const float *data, size_t n, size_t stride, size_t col_offse
     free(counts);
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * quantization/fp8.rs -- the reference's FP8 codec and quantizer, and the FP8 one-to-many kernels
+ * of distance_measures/one_to_many_asymmetric.rs:327-377.
+ * ------------------------------------------------------------------------------------------- */
+uint8_t or_fp8_from_f32(float value, int format) {
+    /* fp8.rs:80-117 (E4M3, bias 7, 3 mantissa bits) / :146-182 (E5M2, bias 15, 2 mantissa bits) */
+    const int mbits = format == OR_FP8_E5M2 ? 2 : 3;
+    const int bias = format == OR_FP8_E5M2 ? 15 : 7;
+    const int emax = format == OR_FP8_E5M2 ? 31 : 15;
+    const uint8_t maxcode = format == OR_FP8_E5M2 ? 0x7C : 0x7E;
+    if (value == 0.0f) return 0;                                  /* :85-87 (also -0.0) */
+    uint32_t bits;
+    memcpy(&bits, &value, 4);
+    const uint32_t sign = (bits >> 31) & 1u;
+    const int exp = (int)((bits >> 23) & 0xFFu);
+    const uint32_t mantissa = bits & 0x7FFFFFu;
+    if (exp == 0xFF) return (uint8_t)((sign << 7) | maxcode);     /* :95-98 infinity or NaN -> max */
+    const int fp8_exp = exp - 127 + bias;                         /* :101 */
+    if (fp8_exp <= 0) return (uint8_t)(sign << 7);                /* :103-106 underflow */
+    if (fp8_exp >= emax) return (uint8_t)((sign << 7) | maxcode); /* :108-111 overflow */
+    const uint32_t m = ((mantissa >> (23 - mbits)) + ((mantissa >> (22 - mbits)) & 1u)) & ((1u << mbits) - 1u); /* :114 */
+    return (uint8_t)((sign << 7) | ((uint32_t)fp8_exp << mbits) | m);
+}
+
+float or_fp8_to_f32(uint8_t b, int format) {
+    /* fp8.rs:120-143 / :185-203 */
+    const int mbits = format == OR_FP8_E5M2 ? 2 : 3;
+    const int bias = format == OR_FP8_E5M2 ? 15 : 7;
+    const uint32_t sign = (b >> 7) & 1u;
+    const int exp = (b >> mbits) & (format == OR_FP8_E5M2 ? 0x1F : 0xF);
+    const uint32_t mantissa = b & ((1u << mbits) - 1u);
+    if (exp == 0 && mantissa == 0) return sign ? -0.0f : 0.0f;
+    const int fp32_exp = exp == 0 ? 126 - bias : exp - bias + 127;   /* (the reference's "subnormal" exponent) */
+    const uint32_t bits = (sign << 31) | ((uint32_t)fp32_exp << 23) | (mantissa << (23 - mbits));
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+float or_fp8_calibrate_scale(float max_abs_value, int format) {
+    const float fp8_max = format == OR_FP8_E5M2 ? 57344.0f : 448.0f;
+    const float d = max_abs_value > 1e-10f ? max_abs_value : 1e-10f;   /* f32::max: NaN operand ignored */
+    return fp8_max / d;
+}
+
+void or_fp8_quantize(const float *values, size_t n, float scale, int format, uint8_t *out) {
+    for (size_t i = 0; i < n; ++i) out[i] = or_fp8_from_f32(values[i] * scale, format);
+}
+
+void or_fp8_dequantize(const uint8_t *bits, size_t n, float scale, int format, float *out) {
+    for (size_t i = 0; i < n; ++i) out[i] = or_fp8_to_f32(bits[i], format) / scale;
+}
+
+void or_one_to_many_fp8(const float *query, size_t dim, const uint8_t *database, size_t stride,
+                        size_t num_points, int measure, float *results) {
+    for (size_t i = 0; i < num_points; ++i) {
+        const uint8_t *row = database + i * stride;
+        float sum = 0.0f;
+        if (measure == OR_DOT_PRODUCT) {
+            for (size_t j = 0; j < dim; ++j) sum += query[j] * or_fp8_to_f32(row[j], OR_FP8_E4M3);
+            results[i] = -sum;
+        } else {
+            for (size_t j = 0; j < dim; ++j) {
+                const float diff = query[j] - or_fp8_to_f32(row[j], OR_FP8_E4M3);
+                sum += diff * diff;
+            }
+            results[i] = sum;
+        }
+    }
+}

@@ -228,6 +228,24 @@ int or_kmeans_lloyd(const float *data, size_t n, size_t stride, size_t col_offse
                     size_t simd_threshold, uint32_t *assign, uint32_t *sizes, double *inertia_out,
                     uint32_t *iterations_out, int *converged_out);
 
+/* quantization/fp8.rs: the reference's own FP8 codec (NOT a hardware format table: its rounding wraps
+ * a mantissa carry without bumping the exponent, exponent field 15 only ever encodes the maximum, and
+ * subnormals flush to zero on encode -- restated bit for bit).  format: 0 = E4M3 (:80-143), 1 = E5M2
+ * (:146-203). */
+#define OR_FP8_E4M3 0
+#define OR_FP8_E5M2 1
+uint8_t or_fp8_from_f32(float value, int format);
+float or_fp8_to_f32(uint8_t bits, int format);
+/* Fp8Quantizer::calibrate_scale (:238-244): fp8_max / max(max_abs, 1e-10). */
+float or_fp8_calibrate_scale(float max_abs_value, int format);
+/* Quantizer::quantize / dequantize over Fp8Quantizer (:247-268): from_f32(value * scale); to_f32 / scale. */
+void or_fp8_quantize(const float *values, size_t n, float scale, int format, uint8_t *out);
+void or_fp8_dequantize(const uint8_t *bits, size_t n, float scale, int format, float *out);
+/* one_to_many_fp8_float_{dot_product, squared_l2} (distance_measures/one_to_many_asymmetric.rs:327-377):
+ * E4M3 rows, sequential f32 sum; measure OR_DOT_PRODUCT (result negated) or OR_SQUARED_L2. */
+void or_one_to_many_fp8(const float *query, size_t dim, const uint8_t *database, size_t stride,
+                        size_t num_points, int measure, float *results);
+
 #ifdef __cplusplus
 }
 #endif

@@ -473,20 +473,41 @@ int scann::txh_create_checked(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, s
     t.rows = d->data ? ix->d_rows.as<float>() : nullptr;
     t.rows8 = nullptr;
     t.rows8_meta = nullptr;
-    // int8 copy of the rows for the re-rank filter (txh.hip K8b): +25 % of the row bytes.  Large indexes
+    // 8-bit copy of the rows for the re-rank filter (txh.hip K8b): +25 % of the row bytes.  Large indexes
     // only (the filter pays for long candidate lists); SCANN_HIP_RERANK_I8 = 0 never, 2 always.
+    // SCANN_HIP_RERANK_STORE = int8 (default: per-row scaled integers, the tighter filter) or fp8 (the
+    // reference's E4M3 codec with a per-row calibrate_scale, quantization/fp8.rs).
+    t.rows8_fmt = 0;
     {
         int mode = 1;
         if (const char *e = std::getenv("SCANN_HIP_RERANK_I8")) mode = std::atoi(e);
+        const char *store = std::getenv("SCANN_HIP_RERANK_STORE");
+        const bool fp8 = store && std::strcmp(store, "fp8") == 0;
         const bool want = d->data && !exact && d->distance_measure == SCANN_HIP_SQUARED_L2 && (d->dim & 15u) == 0 &&
                           (mode == 2 || (mode == 1 && d->n_rows >= 65536));
         if (want) {
             if ((s = ix->d_rows8.ensure((size_t)d->n_rows * d->dim)) != SCANN_HIP_OK) return bail(s);
             if ((s = ix->d_rows8_meta.ensure((size_t)d->n_rows * 8)) != SCANN_HIP_OK) return bail(s);
-            if ((s = launch_rows_i8_build(ix->d_rows.as<float>(), d->n_rows, d->dim, d->stride, ix->d_rows8.as<int8_t>(),
-                                          ix->d_rows8_meta.p, ix->stream)) != SCANN_HIP_OK)
-                return bail(s);
-            if (hipStreamSynchronize(ix->stream) != hipSuccess) return bail(fail(SCANN_HIP_INTERNAL, "int8 row build failed"));
+            if (fp8) {
+                DevBuf mism;
+                if ((s = mism.ensure(4)) != SCANN_HIP_OK) return bail(s);
+                if (hipMemsetAsync(mism.p, 0, 4, ix->stream) != hipSuccess) return bail(fail(SCANN_HIP_INTERNAL, "memset failed"));
+                if ((s = launch_rows_fp8_build(ix->d_rows.as<float>(), d->n_rows, d->dim, d->stride,
+                                               ix->d_rows8.as<uint8_t>(), ix->d_rows8_meta.p, mism.as<uint32_t>(),
+                                               ix->stream)) != SCANN_HIP_OK)
+                    return bail(s);
+                uint32_t bad = 0;
+                if (hipMemcpyAsync(&bad, mism.p, 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+                    hipStreamSynchronize(ix->stream) != hipSuccess)
+                    return bail(fail(SCANN_HIP_INTERNAL, "fp8 row build failed"));
+                if (bad) return bail(fail(SCANN_HIP_INTERNAL, "v_cvt_f32_fp8 decodes the reference's E4M3 codes differently"));
+                t.rows8_fmt = 1;
+            } else {
+                if ((s = launch_rows_i8_build(ix->d_rows.as<float>(), d->n_rows, d->dim, d->stride, ix->d_rows8.as<int8_t>(),
+                                              ix->d_rows8_meta.p, ix->stream)) != SCANN_HIP_OK)
+                    return bail(s);
+                if (hipStreamSynchronize(ix->stream) != hipSuccess) return bail(fail(SCANN_HIP_INTERNAL, "int8 row build failed"));
+            }
             t.rows8 = ix->d_rows8.as<int8_t>();
             t.rows8_meta = ix->d_rows8_meta.p;
         }
@@ -1308,6 +1329,56 @@ int scann_hip_lut16_quantize(scann_hip_ctx *ctx, const float *tables, uint32_t S
     SCANN_HIP_CHECK(hipMemcpy(bm, dp.p, 8, hipMemcpyDeviceToHost));
     *out_bias = bm[0];
     *out_multiplier = bm[1];
+    return SCANN_HIP_OK;
+}
+
+int scann_hip_fp8_quantize(scann_hip_ctx *ctx, const float *values, uint64_t n, float scale, int format,
+                           uint8_t *out_bits) {
+    if (!ctx) return fail(SCANN_HIP_INVALID_ARGUMENT, "ctx is null");
+    if (format != SCANN_HIP_FP8_E4M3 && format != SCANN_HIP_FP8_E5M2) return fail(SCANN_HIP_INVALID_ARGUMENT, "unknown FP8 format");
+    if (n == 0) return SCANN_HIP_OK;
+    if (!values || !out_bits) return fail(SCANN_HIP_INVALID_ARGUMENT, "null values/output");
+    SCANN_TRY(set_device(ctx));
+    DevBuf dv, dout;
+    SCANN_TRY(upload(dv, values, (size_t)n * 4));
+    SCANN_TRY(dout.ensure((size_t)n));
+    SCANN_TRY(launch_fp8_quantize(dv.as<float>(), n, scale, format, dout.as<uint8_t>(), nullptr));
+    SCANN_HIP_CHECK(hipMemcpy(out_bits, dout.p, (size_t)n, hipMemcpyDeviceToHost));
+    return SCANN_HIP_OK;
+}
+
+int scann_hip_fp8_dequantize(scann_hip_ctx *ctx, const uint8_t *bits, uint64_t n, float scale, int format,
+                             float *out_values) {
+    if (!ctx) return fail(SCANN_HIP_INVALID_ARGUMENT, "ctx is null");
+    if (format != SCANN_HIP_FP8_E4M3 && format != SCANN_HIP_FP8_E5M2) return fail(SCANN_HIP_INVALID_ARGUMENT, "unknown FP8 format");
+    if (n == 0) return SCANN_HIP_OK;
+    if (!bits || !out_values) return fail(SCANN_HIP_INVALID_ARGUMENT, "null bits/output");
+    SCANN_TRY(set_device(ctx));
+    DevBuf db, dout;
+    SCANN_TRY(upload(db, bits, (size_t)n));
+    SCANN_TRY(dout.ensure((size_t)n * 4));
+    SCANN_TRY(launch_fp8_dequantize(db.as<uint8_t>(), n, scale, format, dout.as<float>(), nullptr));
+    SCANN_HIP_CHECK(hipMemcpy(out_values, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return SCANN_HIP_OK;
+}
+
+int scann_hip_fp8_distances(scann_hip_ctx *ctx, const float *query, uint32_t dim, const uint8_t *database,
+                            uint64_t stride, uint64_t num_points, int measure, float *out_distances) {
+    if (!ctx) return fail(SCANN_HIP_INVALID_ARGUMENT, "ctx is null");
+    if (measure != SCANN_HIP_SQUARED_L2 && measure != SCANN_HIP_DOT_PRODUCT)
+        return fail(SCANN_HIP_UNIMPLEMENTED, "the reference's FP8 kernels are squared L2 and dot product");
+    if (num_points == 0) return SCANN_HIP_OK;
+    if (!query || !database || !out_distances || dim == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "bad argument");
+    if (stride < dim) return fail(SCANN_HIP_INVALID_ARGUMENT, "stride < dim");
+    if (dim > 32768) return fail(SCANN_HIP_RESOURCE_EXHAUSTED, "dim > 32768");
+    SCANN_TRY(set_device(ctx));
+    DevBuf dq, ddb, dout;
+    SCANN_TRY(upload(dq, query, (size_t)dim * 4));
+    SCANN_TRY(upload(ddb, database, (size_t)num_points * stride));
+    SCANN_TRY(dout.ensure((size_t)num_points * 4));
+    SCANN_TRY(launch_fp8_one_to_many(dq.as<float>(), dim, ddb.as<uint8_t>(), stride, num_points,
+                                     measure == SCANN_HIP_DOT_PRODUCT ? 1 : 0, dout.as<float>(), nullptr));
+    SCANN_HIP_CHECK(hipMemcpy(out_distances, dout.p, (size_t)num_points * 4, hipMemcpyDeviceToHost));
     return SCANN_HIP_OK;
 }
 

@@ -93,6 +93,7 @@ struct TxhIndexDev {
     const uint32_t *codes;        // [n_local][nw] packed 4-bit codes, 8 subspaces per word
     const float *rows;            // re-rank rows; CSR order if rows_csr else by datapoint idx
     const int8_t *rows8;          // the same rows as int8 (per-row scale) for the re-rank filter, or nullptr
+    int rows8_fmt;                // 0 = int8, 1 = the reference's FP8 E4M3 codes (quantization/fp8.rs)
     const void *rows8_meta;       // [n_rows] float2 {scale, ||x - s q||}
     int rows_csr;
     const float *codebook;        // [S][K][dsub]
@@ -204,6 +205,12 @@ int launch_lut16_u8_batch(const uint8_t *d_packed, const uint8_t *d_lut8, uint32
 
 // Lut16SimdTables::from_float_tables (hashes/lut16_simd.rs:39-90); d_bias_mult = {bias, multiplier}
 // int8 copy of n rows (per-row scale = max|x| / 127) + {scale, error norm} per row
+int launch_rows_fp8_build(const float *d_rows, uint64_t n, uint32_t dim, uint32_t stride, uint8_t *d_rows8,
+                          void *d_meta, uint32_t *d_mismatch, hipStream_t st);
+int launch_fp8_quantize(const float *d_values, uint64_t n, float scale, int format, uint8_t *d_out, hipStream_t st);
+int launch_fp8_dequantize(const uint8_t *d_bits, uint64_t n, float scale, int format, float *d_out, hipStream_t st);
+int launch_fp8_one_to_many(const float *d_query, uint32_t dim, const uint8_t *d_db, uint64_t stride, uint64_t n,
+                           int dot, float *d_out, hipStream_t st);
 int launch_rows_i8_build(const float *d_rows, uint64_t n, uint32_t dim, uint32_t stride, int8_t *d_rows8,
                          void *d_meta, hipStream_t stream);
 

@@ -2401,9 +2401,118 @@ __global__ __launch_bounds__(256) void rows_i8_build_kernel(const float *__restr
     }
 }
 
+// ---- the reference's FP8 codec (quantization/fp8.rs:80-203), bit for bit -----------------------------
+// format 0 = E4M3 (bias 7, 3 mantissa bits, max code 0x7E), 1 = E5M2 (bias 15, 2 bits, max code 0x7C).
+// NOT the hardware conversion: the mantissa carry wraps without bumping the exponent, the top exponent
+// field only ever encodes the maximum, values under the smallest normal flush to (signed) zero.
+__device__ __forceinline__ uint32_t fp8_from_f32(float value, int format) {
+    const int mbits = format ? 2 : 3, bias = format ? 15 : 7, emax = format ? 31 : 15;
+    const uint32_t maxcode = format ? 0x7Cu : 0x7Eu;
+    if (value == 0.0f) return 0u;
+    const uint32_t bits = __float_as_uint(value);
+    const uint32_t sign = bits >> 31;
+    const int exp = (int)((bits >> 23) & 0xFFu);
+    const uint32_t mantissa = bits & 0x7FFFFFu;
+    if (exp == 0xFF) return (sign << 7) | maxcode;
+    const int e8 = exp - 127 + bias;
+    if (e8 <= 0) return sign << 7;
+    if (e8 >= emax) return (sign << 7) | maxcode;
+    const uint32_t m = ((mantissa >> (23 - mbits)) + ((mantissa >> (22 - mbits)) & 1u)) & ((1u << mbits) - 1u);
+    return (sign << 7) | ((uint32_t)e8 << mbits) | m;
+}
+
+__device__ __forceinline__ float fp8_to_f32(uint32_t b, int format) {
+    const int mbits = format ? 2 : 3, bias = format ? 15 : 7;
+    const uint32_t sign = (b >> 7) & 1u;
+    const int exp = (int)((b >> mbits) & (format ? 0x1Fu : 0xFu));
+    const uint32_t mantissa = b & ((1u << mbits) - 1u);
+    if (exp == 0 && mantissa == 0) return sign ? -0.0f : 0.0f;
+    const int e32 = exp == 0 ? 126 - bias : exp - bias + 127;
+    return __uint_as_float((sign << 31) | ((uint32_t)e32 << 23) | (mantissa << (23 - mbits)));
+}
+
+// Quantizer::quantize / dequantize over Fp8Quantizer (fp8.rs:247-268)
+__global__ __launch_bounds__(256) void fp8_quantize_kernel(const float *__restrict__ values, uint64_t n, float scale,
+                                                           int format, uint8_t *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        out[i] = (uint8_t)fp8_from_f32(values[i] * scale, format);
+}
+
+__global__ __launch_bounds__(256) void fp8_dequantize_kernel(const uint8_t *__restrict__ bits, uint64_t n, float scale,
+                                                             int format, float *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        out[i] = fp8_to_f32(bits[i], format) / scale;
+}
+
+// one_to_many_fp8_float_{squared_l2, dot_product} (distance_measures/one_to_many_asymmetric.rs:327-377):
+// E4M3 rows, one sequential f32 sum per row (no FMA), the dot product negated.
+__global__ __launch_bounds__(256) void fp8_one_to_many_kernel(const float *__restrict__ query, uint32_t dim,
+                                                              const uint8_t *__restrict__ db, uint64_t stride,
+                                                              uint64_t n, int dot, float *__restrict__ out) {
+    extern __shared__ float s_q8[];   // [dim]
+    for (uint32_t j = threadIdx.x; j < dim; j += 256) s_q8[j] = query[j];
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint8_t *row = db + i * stride;
+        float sum = 0.0f;
+        if (dot) {
+            for (uint32_t j = 0; j < dim; ++j) sum = sum + s_q8[j] * fp8_to_f32(row[j], 0);
+            out[i] = -sum;
+        } else {
+            for (uint32_t j = 0; j < dim; ++j) {
+                const float diff = s_q8[j] - fp8_to_f32(row[j], 0);
+                sum = sum + diff * diff;
+            }
+            out[i] = sum;
+        }
+    }
+}
+
+// The FP8 row store of the re-rank filter: the reference's E4M3 codec with Fp8Quantizer::calibrate_scale
+// per row (scale = 448 / max|x|, fp8.rs:238-244); the filter decodes with v_cvt_pk_f32_fp8 (gfx950: OCP
+// E4M3 -- equal to the reference's decode on every code its encoder emits) as x~ = dec * (1 / scale), and E
+// is computed from that same expression.  `mismatch` counts codes the hardware decodes differently
+// (never, unless the conversion instruction means another format: the create call then fails).
+__global__ __launch_bounds__(256) void rows_fp8_build_kernel(const float *__restrict__ rows, uint64_t n, uint32_t dim,
+                                                             uint32_t stride, uint8_t *__restrict__ rows8,
+                                                             float2 *__restrict__ meta, uint32_t *__restrict__ mismatch) {
+    const uint64_t r = (uint64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const uint32_t l8 = threadIdx.x & 7u;
+    const bool act = r < n;
+    const float *row = rows + (act ? r : 0) * stride;
+    float mx = 0.0f;
+    for (uint32_t j = l8; j < dim; j += 8) mx = fmaxf(mx, fabsf(row[j]));
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 8));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 8));
+    mx = fmaxf(mx, __shfl_xor(mx, 4, 8));
+    const bool finite = mx < __builtin_inff();
+    const float scale = 448.0f / fmaxf(finite ? mx : 1.0f, 1e-10f);
+    const float inv = 1.0f / scale;
+    float err = 0.0f;
+    uint32_t bad = 0;
+    for (uint32_t j = l8; j < dim; j += 8) {
+        const float x = row[j];
+        const uint32_t b = fp8_from_f32(x * scale, 0);
+        const float hw = __builtin_amdgcn_cvt_f32_fp8((int)b, 0);
+        bad += (__float_as_uint(hw) != __float_as_uint(fp8_to_f32(b, 0))) ? 1u : 0u;
+        if (act) rows8[r * dim + j] = (uint8_t)b;
+        const float e = x - hw * inv;
+        err = err + e * e;
+    }
+    err += __shfl_xor(err, 1, 8);
+    err += __shfl_xor(err, 2, 8);
+    err += __shfl_xor(err, 4, 8);
+    if (act && bad) atomicAdd(mismatch, bad);
+    if (act && l8 == 0) {
+        float E = sqrtf(err) * 1.0001f + 1e-30f;
+        if (!(E == E) || !finite) E = __builtin_inff();
+        meta[r] = make_float2(inv, E);
+    }
+}
+
 struct I8RerankArgs {
-    const int8_t *rows8;      // [n_rows][dim]
-    const float2 *meta;       // [n_rows] {scale, error norm}
+    const int8_t *rows8;      // [n_rows][dim] int8, or the reference's E4M3 codes (FMT = 1)
+    const float2 *meta;       // [n_rows] {dequantisation factor, error norm}
     const float *queries;
     uint32_t q_stride, m;
     const uint32_t *cand_row, *cand_count;
@@ -2412,7 +2521,9 @@ struct I8RerankArgs {
 
 constexpr uint32_t kI8PerBlock = 256;   // candidates per block (8 lanes each, 8 rounds): amortises the query staging
 
+template <int FMT>   // 0 = int8 rows, 1 = FP8 (E4M3) rows
 __global__ __launch_bounds__(256) void rerank_i8_kernel(uint32_t dim, I8RerankArgs a) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float s_q[];   // [dim]
     const uint32_t q = blockIdx.y, tid = threadIdx.x;
     const uint32_t nsel = a.cand_count[q];
@@ -2438,11 +2549,25 @@ __global__ __launch_bounds__(256) void rerank_i8_kernel(uint32_t dim, I8RerankAr
         for (uint32_t j0 = l8 * 16u; j0 < dim; j0 += 128u) {   // 16 dims per lane per pass (dim % 16 == 0)
             const uint4 v = *reinterpret_cast<const uint4 *>(r8 + j0);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            if constexpr (FMT == 1) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float x = me.x * (float)(int)(int8_t)(w[i >> 2] >> (8 * (i & 3)));
-                const float d = s_q[j0 + i] - x;
-                acc = fmaf(d, d, acc);
+                for (int wi = 0; wi < 4; ++wi) {
+                    const v2f lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[wi], false);
+                    const v2f hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[wi], true);
+                    const float xs[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float d = s_q[j0 + wi * 4 + i] - xs[i] * me.x;
+                        acc = fmaf(d, d, acc);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float x = me.x * (float)(int)(int8_t)(w[i >> 2] >> (8 * (i & 3)));
+                    const float d = s_q[j0 + i] - x;
+                    acc = fmaf(d, d, acc);
+                }
             }
         }
         acc += __shfl_xor(acc, 1, 8);
@@ -3518,8 +3643,13 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
         ia.rows8 = ix.rows8; ia.meta = reinterpret_cast<const float2 *>(ix.rows8_meta); ia.queries = w.queries;
         ia.q_stride = w.q_stride; ia.m = w.m; ia.cand_row = w.cand_row; ia.cand_count = w.cand_count;
         ia.lb = w.rr_lb; ia.ub = w.rr_ub;
-        SCANN_TRY(set_dyn_lds(rerank_i8_kernel, lds_rr));
-        hipLaunchKernelGGL(rerank_i8_kernel, dim3(ceil_div_u32(w.m, kI8PerBlock), w.nq), dim3(256), lds_rr, st, ix.dim, ia);
+        if (ix.rows8_fmt == 1) {
+            SCANN_TRY(set_dyn_lds(rerank_i8_kernel<1>, lds_rr));
+            hipLaunchKernelGGL(rerank_i8_kernel<1>, dim3(ceil_div_u32(w.m, kI8PerBlock), w.nq), dim3(256), lds_rr, st, ix.dim, ia);
+        } else {
+            SCANN_TRY(set_dyn_lds(rerank_i8_kernel<0>, lds_rr));
+            hipLaunchKernelGGL(rerank_i8_kernel<0>, dim3(ceil_div_u32(w.m, kI8PerBlock), w.nq), dim3(256), lds_rr, st, ix.dim, ia);
+        }
         LAUNCH_CHECK();
         ShortArgs sa;
         sa.m = w.m; sa.k = w.k; sa.queries = w.queries; sa.q_stride = w.q_stride; sa.lb = w.rr_lb; sa.ub = w.rr_ub;
@@ -3646,6 +3776,42 @@ int launch_lut16_u8_batch(const uint8_t *d_packed, const uint8_t *d_lut8, uint32
     const uint32_t gx = (uint32_t)std::min<uint64_t>(ceil_div_u64(n, 256), 8192);
     hipLaunchKernelGGL(lut16_u8_batch_kernel, dim3(gx), dim3(256), (size_t)S * 16, st, d_packed, d_lut8,
                        S, n, bias, mult, d_out);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+int launch_rows_fp8_build(const float *d_rows, uint64_t n, uint32_t dim, uint32_t stride, uint8_t *d_rows8,
+                          void *d_meta, uint32_t *d_mismatch, hipStream_t st) {
+    if (n == 0) return SCANN_HIP_OK;
+    hipLaunchKernelGGL(rows_fp8_build_kernel, dim3((uint32_t)ceil_div_u64(n, 32)), dim3(256), 0, st, d_rows, n, dim,
+                       stride, d_rows8, reinterpret_cast<float2 *>(d_meta), d_mismatch);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+int launch_fp8_quantize(const float *d_values, uint64_t n, float scale, int format, uint8_t *d_out, hipStream_t st) {
+    if (n == 0) return SCANN_HIP_OK;
+    hipLaunchKernelGGL(fp8_quantize_kernel, dim3((uint32_t)std::min<uint64_t>(ceil_div_u64(n, 256), 65535)), dim3(256), 0,
+                       st, d_values, n, scale, format, d_out);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+int launch_fp8_dequantize(const uint8_t *d_bits, uint64_t n, float scale, int format, float *d_out, hipStream_t st) {
+    if (n == 0) return SCANN_HIP_OK;
+    hipLaunchKernelGGL(fp8_dequantize_kernel, dim3((uint32_t)std::min<uint64_t>(ceil_div_u64(n, 256), 65535)), dim3(256),
+                       0, st, d_bits, n, scale, format, d_out);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+int launch_fp8_one_to_many(const float *d_query, uint32_t dim, const uint8_t *d_db, uint64_t stride, uint64_t n,
+                           int dot, float *d_out, hipStream_t st) {
+    if (n == 0) return SCANN_HIP_OK;
+    const size_t lds = (size_t)dim * sizeof(float);
+    SCANN_TRY(set_dyn_lds(fp8_one_to_many_kernel, lds));
+    hipLaunchKernelGGL(fp8_one_to_many_kernel, dim3((uint32_t)std::min<uint64_t>(ceil_div_u64(n, 256), 65535)),
+                       dim3(256), lds, st, d_query, dim, d_db, stride, n, dot, d_out);
     LAUNCH_CHECK();
     return SCANN_HIP_OK;
 }

@@ -31,6 +31,7 @@ EXPORTS = [
     "scann_hip_txh_search_local_device", "scann_hip_txh_merge_device",
     "scann_hip_assign_leaves", "scann_hip_txh_partition", "scann_hip_lut_from_query",
     "scann_hip_adc_distances", "scann_hip_lut16_distances_batch", "scann_hip_encode",
+    "scann_hip_fp8_quantize", "scann_hip_fp8_dequantize", "scann_hip_fp8_distances",
     "scann_hip_bf_distances", "scann_hip_bf_search_radius", "scann_hip_bf_assign_nearest",
     "scann_hip_kmeans_init_pp", "scann_hip_kmeans_lloyd", "scann_hip_txh_pack_blocks_device", "scann_hip_index_size", "scann_hip_index_dimensionality",
     "scann_hip_index_destroy", "scann_hip_index_enable_timing",
@@ -156,6 +157,9 @@ def load():
     L.scann_hip_abi_layout.restype = C.c_uint32
     L.scann_hip_abi_layout.argtypes = [u32p, C.c_uint32]
     L.scann_hip_lut16_quantize.argtypes = [vp, f32p, C.c_uint32, u8p, f32p, f32p]
+    L.scann_hip_fp8_quantize.argtypes = [vp, f32p, C.c_uint64, C.c_float, C.c_int, u8p]
+    L.scann_hip_fp8_dequantize.argtypes = [vp, u8p, C.c_uint64, C.c_float, C.c_int, f32p]
+    L.scann_hip_fp8_distances.argtypes = [vp, f32p, C.c_uint32, u8p, C.c_uint64, C.c_uint64, C.c_int, f32p]
     L.scann_hip_comm_unique_id.argtypes = [vp]
     L.scann_hip_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     L.scann_hip_comm_destroy.argtypes = [vp]
@@ -429,6 +433,36 @@ def lut16_quantize(tables, device=0):
     check(load().scann_hip_lut16_quantize(context(device), ptr(t, f32p) if S else None, S,
                                           ptr(lut8, u8p) if S else None, C.byref(bias), C.byref(mult)))
     return lut8, float(np.float32(bias.value)), float(np.float32(mult.value))
+
+
+FP8_E4M3, FP8_E5M2 = 0, 1
+
+
+def fp8_quantize(values, scale=1.0, fmt=FP8_E4M3, device=0):
+    """Quantizer::quantize over Fp8Quantizer (quantization/fp8.rs:247-255) on the device."""
+    v = f32(values)
+    out = np.zeros(v.shape, np.uint8)
+    check(load().scann_hip_fp8_quantize(context(device), ptr(v, f32p), v.size, float(np.float32(scale)), fmt,
+                                        ptr(out, u8p)))
+    return out
+
+
+def fp8_dequantize(bits, scale=1.0, fmt=FP8_E4M3, device=0):
+    b = np.ascontiguousarray(bits, np.uint8)
+    out = np.zeros(b.shape, np.float32)
+    check(load().scann_hip_fp8_dequantize(context(device), ptr(b, u8p), b.size, float(np.float32(scale)), fmt,
+                                          ptr(out, f32p)))
+    return out
+
+
+def fp8_distances(query, database, stride, n, measure, device=0):
+    """one_to_many_fp8_float_{squared_l2,dot_product} (one_to_many_asymmetric.rs:327-377)."""
+    q = f32(query)
+    db = np.ascontiguousarray(database, np.uint8)
+    out = np.zeros(n, np.float32)
+    check(load().scann_hip_fp8_distances(context(device), ptr(q, f32p), q.size, ptr(db, u8p), stride, n, measure,
+                                         ptr(out, f32p)))
+    return out
 
 
 def abi_layout():

@@ -1343,3 +1343,84 @@ def test_small_batch_pipeline_matches_staged_pipeline(kind, measure, monkeypatch
                 index.search_batched(q[:9], 10, o2)
                 toks.append((tok, tokd))
             assert np.array_equal(toks[0][0], toks[1][0]) and np.array_equal(bits(toks[0][1]), bits(toks[1][1]))
+
+
+# ---- FP8: the reference's codec, its one-to-many kernels, and the FP8 row store of the re-rank filter ------
+@pytest.mark.parametrize("fmt", [hip.FP8_E4M3, hip.FP8_E5M2])
+def test_fp8_codec_bit_exact(fmt):
+    """quantization/fp8.rs:80-268 on the device against the oracle restatement: every f32 exponent band,
+    zeros, infinities, NaN, the mantissa-carry wrap, flush-to-zero, scales from calibrate_scale; all 256
+    codes decoded (the reference's own 'subnormal' rule included)."""
+    rng = np.random.default_rng(5 + fmt)
+    vals = np.concatenate([
+        (rng.standard_normal(4000) * np.exp(rng.uniform(-14, 14, 4000))).astype(np.float32),
+        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.9375, -1.9375, 448.0, 449.0, 255.9, 256.0, 2.0 ** -6, 2.0 ** -7,
+                  2.0 ** -14, 2.0 ** -15, 57344.0, 65536.0, 1e30, -1e30, 1e-30], np.float32),
+        np.ldexp(np.float32(1.0), np.arange(-20, 20)).astype(np.float32)])
+    for scale in (1.0, float(orc.fp8_calibrate_scale(3.7, fmt)), 0.01):
+        got = hip.fp8_quantize(vals, scale, fmt)
+        want = orc.fp8_quantize(vals, scale, fmt)
+        assert np.array_equal(got, want), (fmt, scale, np.flatnonzero(got != want)[:5])
+    codes = np.arange(256, dtype=np.uint8)
+    for scale in (1.0, 224.0):
+        assert np.array_equal(bits(hip.fp8_dequantize(codes, scale, fmt)), bits(orc.fp8_dequantize(codes, scale, fmt)))
+    # reference unit tests on the device (fp8.rs:278-343)
+    v4 = np.array([1.0, 2.0, 3.0, 4.0], np.float32)
+    assert np.all(np.abs(hip.fp8_dequantize(hip.fp8_quantize(v4)) - v4) < 0.5)
+
+
+@pytest.mark.parametrize("measure", [hip.SQUARED_L2, hip.DOT_PRODUCT])
+@pytest.mark.parametrize("n,dim,stride", [(1, 4, 4), (3000, 128, 128), (700, 50, 64), (257, 7, 9)])
+def test_fp8_one_to_many_bit_exact(measure, n, dim, stride):
+    """one_to_many_fp8_float_{squared_l2,dot_product} (one_to_many_asymmetric.rs:327-377): arbitrary code
+    bytes (every one of the 256 codes occurs), padded strides, sequential f32 sums bit for bit."""
+    rng = np.random.default_rng(n + dim)
+    db = rng.integers(0, 256, (n, stride), dtype=np.uint8)
+    if n == 1:   # the reference's test_simd_operations: query == database == [1, 2, 3, 4]
+        q = np.array([1.0, 2.0, 3.0, 4.0], np.float32)
+        db = hip.fp8_quantize(q).reshape(1, 4)
+    else:
+        q = (rng.standard_normal(dim) * 3).astype(np.float32)
+    got = hip.fp8_distances(q, db, stride, n, measure)
+    want = orc.one_to_many_fp8(q, db, stride, n, measure)
+    assert np.array_equal(bits(got), bits(want))
+    if n == 1:
+        assert (abs(-got[0] - 30.0) < 1.0) if measure == hip.DOT_PRODUCT else (got[0] < 1.0)
+    with pytest.raises(hip.ScannError) as e:
+        hip.fp8_distances(q, db, stride, n, hip.L1)
+    assert e.value.code == hip.UNIMPLEMENTED
+
+
+@pytest.mark.parametrize("case", ["uniform", "duplicates", "scales"])
+def test_rerank_fp8_filter_matches_full_rerank(case, monkeypatch):
+    """SCANN_HIP_RERANK_STORE=fp8: the re-rank filter over rows stored with the reference's E4M3 codec and a
+    per-row calibrate_scale.  Same proof as the int8 store, so rows, distance bits and tie order must equal
+    the full re-rank's -- with duplicated rows, rows spanning e^+-4 in magnitude and a zero row."""
+    n, dim, S = 30000, 64, 16
+    rng = np.random.default_rng(12)
+    rows = synth.uniform_f32(n, dim, 6)
+    if case == "duplicates":
+        rows[1::3] = rows[0::3][: rows[1::3].shape[0]]
+    if case == "scales":
+        rows = (rows * np.exp(rng.uniform(-4, 4, (n, 1))).astype(np.float32)).astype(np.float32)
+        rows[7] = 0.0
+    data, stride = orc.to_strided(rows)
+    ixa = trainer.build_ah_index(rows, S, K=16, seed=3, pq_iters=3)
+    kw = dict(data=data, n_rows=n, dim=dim, stride=stride, centers=None, leaf_offsets=None, leaf_ids=None,
+              codebook=ixa["codebook"], codes=ixa["codes"], codes_packed4=False, use_residuals=False,
+              partitions_to_search=1, pre_reorder_multiplier=1.0)
+    q = synth.uniform_f32(48, dim, 80)
+    o = hip.default_opts()
+    monkeypatch.setenv("SCANN_HIP_RERANK_I8", "0")
+    plain = hip.txh_create(**kw)
+    monkeypatch.setenv("SCANN_HIP_RERANK_I8", "2")
+    monkeypatch.setenv("SCANN_HIP_RERANK_I8_MIN", "1")
+    monkeypatch.setenv("SCANN_HIP_RERANK_STORE", "fp8")
+    filt = hip.txh_create(**kw)
+    for k, mm in ((10, 900), (10, 45), (1, 300), (40, 170)):
+        o.pre_reorder_k = mm
+        a = plain.search_batched(q, k, o)
+        b = filt.search_batched(q, k, o)
+        assert np.array_equal(a[2], b[2]), (case, k, mm)
+        assert np.array_equal(bits(a[1]), bits(b[1])), (case, k, mm)
+        assert np.array_equal(a[0], b[0]), (case, k, mm)

@@ -411,3 +411,41 @@ def test_l1_and_cosine_known_answers():
         sbb = np.float32(sbb + np.float32(b[j] * b[j]))
     want = np.float32(1.0) - np.float32(sab / np.float32(np.sqrt(saa) * np.sqrt(sbb)))
     assert np.float32(orc.measure_distance(orc.COSINE, a, b)) == np.float32(want)
+
+
+def test_fp8_codec_known_answers():
+    """quantization/fp8.rs tests (:278-343): E4M3 / E5M2 round trips within the stated relative errors,
+    Fp8Quantizer::e4m3 on [1, 2, 3, 4] within 0.5, the FP8 one-to-many kernels on query == database
+    ([1, 2, 3, 4]: |dot - 30| < 1, squared L2 < 1; one_to_many_asymmetric.rs:327-377 negate the dot) --
+    plus the codec's fixed points the restatement must keep: bias 7 / 15 layouts, max codes 0x7E / 0x7C for
+    overflow, infinity and NaN, flush-to-zero below the smallest normal, calibrate_scale."""
+    for val in (0.0, 1.0, -1.0, 0.5, 2.0, 100.0, -0.1):                         # test_fp8_e4m3_roundtrip
+        rec = orc.fp8_to_f32(orc.fp8_from_f32(val))
+        if val != 0.0:
+            assert abs((val - rec) / val) < 0.2, (val, rec)
+        else:
+            assert rec == 0.0
+    for val in (0.0, 1.0, -1.0, 0.5, 2.0, 4.0, -0.125):                         # test_fp8_e5m2_roundtrip
+        rec = orc.fp8_to_f32(orc.fp8_from_f32(val, orc.FP8_E5M2), orc.FP8_E5M2)
+        if abs(val) > 1e-6:
+            assert abs((val - rec) / val) < 0.5, (val, rec)
+    vals = np.array([1.0, 2.0, 3.0, 4.0], np.float32)                           # test_fp8_quantizer
+    deq = orc.fp8_dequantize(orc.fp8_quantize(vals), 1.0)
+    assert np.all(np.abs(vals - deq) < 0.5)
+    db = orc.fp8_quantize(vals)                                                 # test_simd_operations
+    dot = orc.one_to_many_fp8(vals, db, 4, 1, orc.DOT_PRODUCT)[0]
+    assert abs(-dot - 30.0) < 1.0
+    assert orc.one_to_many_fp8(vals, db, 4, 1, orc.SQUARED_L2)[0] < 1.0
+    # exact layouts: 1.0 = exponent field 7 (E4M3) / 15 (E5M2), powers of two and 1.5 are exact
+    assert orc.fp8_from_f32(1.0) == 0x38 and orc.fp8_from_f32(-2.0) == 0xC0 and orc.fp8_from_f32(1.5) == 0x3C
+    assert orc.fp8_from_f32(1.0, orc.FP8_E5M2) == 0x3C and orc.fp8_to_f32(0x3C, orc.FP8_E5M2) == 1.0
+    assert orc.fp8_to_f32(0x7E) == 448.0
+    assert orc.fp8_to_f32(0x7C, orc.FP8_E5M2) == 65536.0   # (to_f32_e5m2 decodes its overflow code as 2^16, :185-203)
+    for big in (1e9, np.inf, np.nan, 256.0):      # exponent field 15 is only ever the maximum (fp8.rs:108-111)
+        assert orc.fp8_from_f32(big) == 0x7E
+    assert orc.fp8_from_f32(-np.inf) == 0xFE and orc.fp8_from_f32(np.inf, orc.FP8_E5M2) == 0x7C
+    assert orc.fp8_from_f32(2.0 ** -7) == 0 and orc.fp8_from_f32(-(2.0 ** -8)) == 0x80   # flush to (signed) zero
+    assert orc.fp8_from_f32(2.0 ** -6) == 0x08                                            # smallest normal
+    assert orc.fp8_from_f32(1.9375) == 0x38      # the mantissa carry wraps without bumping the exponent (:114)
+    assert orc.fp8_calibrate_scale(2.0) == np.float32(224.0) and orc.fp8_calibrate_scale(0.0) == np.float32(448.0 / 1e-10)
+    assert orc.fp8_calibrate_scale(4.0, orc.FP8_E5M2) == np.float32(14336.0)
