@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -51,6 +53,7 @@ struct TxhWorkspace {
 struct PinBuf {
     void *host = nullptr, *dev = nullptr;
     size_t bytes = 0;
+    uint32_t seq = 0;   // completion-flag value of the last small call staged here
     PinBuf() = default;
     PinBuf(const PinBuf &) = delete;
     PinBuf &operator=(const PinBuf &) = delete;
@@ -66,6 +69,7 @@ struct PinBuf {
         need = (need + 4095) & ~(size_t)4095;
         SCANN_HIP_CHECK(hipHostMalloc(&host, need, hipHostMallocMapped));
         SCANN_HIP_CHECK(hipHostGetDevicePointer(&dev, host, 0));
+        std::memset(host, 0, need);   // (completion flags: no stale word may equal a live sequence number)
         bytes = need;
         return SCANN_HIP_OK;
     }
@@ -115,7 +119,7 @@ struct scann_hip_index {
 
     // ---- tree-x-hybrid / AH ----
     TxhIndexDev tx{};
-    DevBuf d_centers, d_leaf_off, d_leaf_gsize, d_leaf_ids, d_codes, d_rows, d_codebook, d_rows8, d_rows8_meta;
+    DevBuf d_centers, d_centers_t, d_leaf_off, d_leaf_gsize, d_leaf_ids, d_codes, d_rows, d_codebook, d_rows8, d_rows8_meta;
     std::vector<uint32_t> local_sizes_desc;  // local leaf sizes, descending, prefix-summed
     uint32_t default_P = 0;
     float multiplier = 3.0f;
@@ -464,6 +468,18 @@ int scann::txh_create_checked(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, s
     t.kp = bits == 4 ? 16u : 256u;
     t.n_local = n;
     t.centers = ah ? nullptr : ix->d_centers.as<float>();
+    t.centers_t = nullptr;
+    t.centers_pitch = 0;
+    if (!ah && L <= 4096) {   // transposed centroids: the small-batch leaf selection reads them coalesced (txh.hip)
+        const uint32_t pitch = (L + 63u) & ~63u;
+        if ((s = ix->d_centers_t.ensure((size_t)pitch * d->dim * 4)) != SCANN_HIP_OK) return bail(s);
+        if ((s = launch_transpose_centers(ix->d_centers.as<float>(), L, d->dim, pitch, ix->d_centers_t.as<float>(),
+                                          ix->stream)) != SCANN_HIP_OK)
+            return bail(s);
+        if (hipStreamSynchronize(ix->stream) != hipSuccess) return bail(fail(SCANN_HIP_INTERNAL, "centroid transpose failed"));
+        t.centers_t = ix->d_centers_t.as<float>();
+        t.centers_pitch = pitch;
+    }
     t.leaf_off = ix->d_leaf_off.as<uint32_t>();
     t.leaf_gsize = ix->d_leaf_gsize.as<uint32_t>();
     t.leaf_ids = ah ? nullptr : ix->d_leaf_ids.as<uint32_t>();
@@ -676,6 +692,8 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
     w->exact_reorder = p.exact_reorder;
     w->no_threshold = p.no_threshold;
     w->small = (uint32_t)p.small;
+    w->small_done = nullptr;
+    w->small_seq = 0;
     w->small_max_leaf = ix->local_sizes_desc.empty() ? 0u : ix->local_sizes_desc[0];
     w->need_sorted_cands = 0;
     w->allow = nullptr;
@@ -876,6 +894,32 @@ static int acquire_slot(scann_hip_index *ix, SlotLock *out) {
     return SCANN_HIP_OK;
 }
 
+// Completion of a small-batch call whose last kernel stores `seq` into the nq pinned flag words after
+// its result rows (system-scope release): the host polls the flags instead of paying the wake-up
+// latency of hipStreamSynchronize for a 30-microsecond job.  Falls back to the stream synchronise after
+// ~2 ms without completion (long jobs, or a launch that failed: the synchronise reports it).
+static int wait_small_done(hipStream_t stream, const volatile uint32_t *flags, uint32_t nq, uint32_t seq) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0;; ++spin) {
+        bool all = true;
+        for (uint32_t i = 0; i < nq; ++i)
+            if (flags[i] != seq) {
+                all = false;
+                break;
+            }
+        if (all) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return SCANN_HIP_OK;
+        }
+        if ((spin & 255u) == 255u &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2000))
+            break;
+        __builtin_ia32_pause();
+    }
+    SCANN_HIP_CHECK(hipStreamSynchronize(stream));
+    return SCANN_HIP_OK;
+}
+
 static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t nq,
                            uint32_t q_stride, uint32_t k, const scann_hip_search_opts *opts,
                            uint32_t *out_idx, float *out_dist, uint32_t *out_count) {
@@ -903,13 +947,17 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
             const size_t qb = (size_t)nq * q_stride * 4, ob = (size_t)nq * k * 4;
             const size_t off_idx = (qb + 255) & ~(size_t)255, off_dist = off_idx + ((ob + 255) & ~(size_t)255),
                          off_cnt = off_dist + ((ob + 255) & ~(size_t)255);
-            SCANN_TRY(sl.pin->ensure(off_cnt + (size_t)nq * 4 + 256));
+            const size_t off_flag = off_cnt + (((size_t)nq * 4 + 255) & ~(size_t)255);
+            SCANN_TRY(sl.pin->ensure(off_flag + (size_t)nq * 4 + 256));
             char *hp = static_cast<char *>(sl.pin->host), *dp = static_cast<char *>(sl.pin->dev);
             std::memcpy(hp, queries, qb);
+            const uint32_t seq = ++sl.pin->seq ? sl.pin->seq : ++sl.pin->seq;   // (never 0: fresh memory)
             w.queries = reinterpret_cast<const float *>(dp);
             w.out_idx = reinterpret_cast<uint32_t *>(dp + off_idx);
             w.out_dist = reinterpret_cast<float *>(dp + off_dist);
             w.out_count = reinterpret_cast<uint32_t *>(dp + off_cnt);
+            w.small_done = reinterpret_cast<uint32_t *>(dp + off_flag);
+            w.small_seq = seq;
             if (sl.primary) ix->next_events();
             SCANN_TRY(txh_launch_search(ix->tx, w, false, stream, sl.primary ? ix->ev0 : nullptr,
                                         sl.primary ? ix->ev1 : nullptr));
@@ -917,7 +965,7 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
                 ix->timing_valid = ix->timing;
                 ix->timed_kernel = "small_scan_kernel";
             }
-            SCANN_HIP_CHECK(hipStreamSynchronize(stream));
+            SCANN_TRY(wait_small_done(stream, reinterpret_cast<const volatile uint32_t *>(hp + off_flag), nq, seq));
             std::memcpy(out_idx, hp + off_idx, ob);
             std::memcpy(out_dist, hp + off_dist, ob);
             std::memcpy(out_count, hp + off_cnt, (size_t)nq * 4);
@@ -995,9 +1043,11 @@ static int bf_small_search_host(scann_hip_index *ix, SlotLock &sl, const float *
     const size_t qb = (size_t)nq * q_stride * 4, ob = (size_t)nq * k * 4;
     const size_t off_idx = (qb + 255) & ~(size_t)255, off_dist = off_idx + ((ob + 255) & ~(size_t)255),
                  off_cnt = off_dist + ((ob + 255) & ~(size_t)255);
-    SCANN_TRY(sl.pin->ensure(off_cnt + (size_t)nq * 4 + 256));
+    const size_t off_flag = off_cnt + (((size_t)nq * 4 + 255) & ~(size_t)255);
+    SCANN_TRY(sl.pin->ensure(off_flag + (size_t)nq * 4 + 256));
     char *hp = static_cast<char *>(sl.pin->host), *dp = static_cast<char *>(sl.pin->dev);
     std::memcpy(hp, queries, qb);
+    const uint32_t seq = ++sl.pin->seq ? sl.pin->seq : ++sl.pin->seq;
     TxhWork w{};
     w.nq = nq; w.q_stride = q_stride; w.P = 1; w.m = kk; w.k = k; w.cap = n; w.exact_reorder = 0;
     w.no_threshold = 1; w.need_sorted_cands = 0; w.allow = nullptr; w.allow_bits = 0;
@@ -1009,8 +1059,10 @@ static int bf_small_search_host(scann_hip_index *ix, SlotLock &sl, const float *
     w.out_dist = reinterpret_cast<float *>(dp + off_dist);
     w.out_count = reinterpret_cast<uint32_t *>(dp + off_cnt);
     w.small = 1; w.small_max_leaf = n;
+    w.small_done = reinterpret_cast<uint32_t *>(dp + off_flag);
+    w.small_seq = seq;
     SCANN_TRY(txh_launch_search(ix->bfx, w, false, sl.stream, nullptr, nullptr));
-    SCANN_HIP_CHECK(hipStreamSynchronize(sl.stream));
+    SCANN_TRY(wait_small_done(sl.stream, reinterpret_cast<const volatile uint32_t *>(hp + off_flag), nq, seq));
     std::memcpy(out_idx, hp + off_idx, ob);
     std::memcpy(out_dist, hp + off_dist, ob);
     std::memcpy(out_count, hp + off_cnt, (size_t)nq * 4);

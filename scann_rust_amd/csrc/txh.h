@@ -87,6 +87,8 @@ struct TxhIndexDev {
     uint32_t code_bits, kp;       // 4-bit codes / 16 table slots (K <= 16) or 8-bit / 256 slots
     uint64_t n_local;
     const float *centers;         // [L][dim]; nullptr in AsymmetricHasher mode
+    const float *centers_t;       // [dim][centers_pitch] transposed copy (small-batch leaf selection), or nullptr
+    uint32_t centers_pitch;
     const uint32_t *leaf_off;     // [L+1] local CSR offsets
     const uint32_t *leaf_gsize;   // [L] global leaf sizes (== local when unsharded)
     const uint32_t *leaf_ids;     // [n_local] datapoint index of CSR row; nullptr = identity
@@ -145,6 +147,8 @@ struct TxhWork {
     uint32_t *cand32_cnt;      // [nq]
     uint32_t *cand32;          // [nq][cap32] stream positions of the prefilter's survivors
     uint32_t *cand32_codes;    // [nq][cap32][S/8] their packed codes (written next to the positions)
+    uint32_t *small_done;      // small-batch host calls: [nq] pinned completion flags (or nullptr) ...
+    uint32_t small_seq;        // ... and the value the finish kernel stores there after the result rows
     uint32_t cap32;
     uint32_t *sbase;           // [nq][P+2] prefix of per-leaf sample counts; [P]=samples, [P+1]=local points
     uint32_t *pair_sbase;      // [max_slots]
@@ -205,6 +209,8 @@ int launch_lut16_u8_batch(const uint8_t *d_packed, const uint8_t *d_lut8, uint32
 
 // Lut16SimdTables::from_float_tables (hashes/lut16_simd.rs:39-90); d_bias_mult = {bias, multiplier}
 // int8 copy of n rows (per-row scale = max|x| / 127) + {scale, error norm} per row
+int launch_transpose_centers(const float *d_centers, uint32_t L, uint32_t dim, uint32_t pitch, float *d_out,
+                             hipStream_t st);
 int launch_rows_fp8_build(const float *d_rows, uint64_t n, uint32_t dim, uint32_t stride, uint8_t *d_rows8,
                           void *d_meta, uint32_t *d_mismatch, hipStream_t st);
 int launch_fp8_quantize(const float *d_values, uint64_t n, float scale, int format, uint8_t *d_out, hipStream_t st);

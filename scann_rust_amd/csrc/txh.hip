@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
     const uint32_t *__restrict__ leaf_gsize, const uint32_t *__restrict__ leaf_off, uint32_t st,
     uint32_t *__restrict__ tokens, float *__restrict__ token_dists, uint32_t *__restrict__ vbase,
     uint32_t *__restrict__ sbase, const float *__restrict__ centers_inline, const float *__restrict__ queries,
-    uint32_t q_stride, uint32_t dim) {
+    uint32_t q_stride, uint32_t dim, uint32_t centers_pitch) {
     extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];    // [n_pow2]
     uint64_t *s_top = skeys + n_pow2;                                   // [p_pow2] (select path)
     const SelCfg cfg = sel_cfg(L);
@@ -93,43 +93,50 @@ __global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
     const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = nt >> 6;
     const bool select_path = p_pow2 != 0;
     const uint32_t nfill = select_path ? L : n_pow2;
+    // inline mode (small batches): the leaf size tables of this index live in LDS behind the scan words,
+    // so nothing after the scoring waits on global memory
+    uint32_t *s_lsz = s_scan + 64, *s_lgs = s_lsz + (centers_inline ? L : 0u);
+    float *s_qv = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(s_lgs + (centers_inline ? L : 0u)) + 15u) & ~(uintptr_t)15u);
     if (centers_inline) {
-        float *s_qv = reinterpret_cast<float *>(skeys);   // (skeys is filled only after this block)
+        // centers_inline is the TRANSPOSED centroid matrix [dim][centers_pitch]: thread c reads element
+        // (j, c), so a wave's load covers two cache lines instead of 64 (row-major rows made the kernel
+        // wait on the L1's line-request rate: 15 us for 1000 x 128 centroids).  16 loads in flight; the sum is
+        // the reference's sequential one.
         for (uint32_t j = tid; j < dim; j += nt) s_qv[j] = queries[(size_t)q * q_stride + j];
+        for (uint32_t l = tid; l < L; l += nt) {
+            s_lsz[l] = leaf_off[l + 1] - leaf_off[l];
+            s_lgs[l] = leaf_gsize[l];
+        }
         __syncthreads();
-        const bool vec = (dim & 3u) == 0 && (reinterpret_cast<uintptr_t>(centers_inline) & 15u) == 0;
         for (uint32_t c = tid; c < L; c += nt) {
-            const float *crow = centers_inline + (size_t)c * dim;
+            const float *col = centers_inline + c;
             float acc = 0.0f;
-            if (vec) {
-#pragma unroll 8
-                for (uint32_t j = 0; j < dim; j += 4) {   // 16-byte loads, the same sequential sum
-                    const float4 cv = *reinterpret_cast<const float4 *>(crow + j);
-                    const float4 qv = *reinterpret_cast<const float4 *>(s_qv + j);
-                    const float d0 = qv.x - cv.x, d1 = qv.y - cv.y, d2 = qv.z - cv.z, d3 = qv.w - cv.w;
-                    acc = acc + d0 * d0;
-                    acc = acc + d1 * d1;
-                    acc = acc + d2 * d2;
-                    acc = acc + d3 * d3;
-                }
-            } else {
-                for (uint32_t j = 0; j < dim; ++j) {
-                    const float d = s_qv[j] - crow[j];
-                    acc = acc + d * d;
-                }
+            for (uint32_t j0 = 0; j0 < dim; j0 += 16) {
+                float cv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    cv[u] = j0 + (uint32_t)u < dim ? col[(size_t)(j0 + u) * centers_pitch] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (j0 + (uint32_t)u < dim) {
+                        const float d = s_qv[j0 + u] - cv[u];
+                        acc = acc + d * d;
+                    }
             }
-            cdist[(size_t)q * L + c] = acc;   // read back below after the barrier
+            cdist[(size_t)q * L + c] = acc;   // (kept for NaN payloads: see token_dists below)
+            skeys[c] = ((uint64_t)((acc != acc) ? 0xFFFFFFFFu : f32_to_ordered(acc)) << 32) | c;
         }
-        __syncthreads();
-    }
-    for (uint32_t i = tid; i < nfill; i += nt) {
-        uint64_t key = SCANN_KEY_MAX;
-        if (i < L) {
-            float d = cdist[(size_t)q * L + i];
-            uint32_t o = (d != d) ? 0xFFFFFFFFu : f32_to_ordered(d);
-            key = ((uint64_t)o << 32) | i;
+        for (uint32_t i = L + tid; i < nfill; i += nt) skeys[i] = SCANN_KEY_MAX;
+    } else {
+        for (uint32_t i = tid; i < nfill; i += nt) {
+            uint64_t key = SCANN_KEY_MAX;
+            if (i < L) {
+                float d = cdist[(size_t)q * L + i];
+                uint32_t o = (d != d) ? 0xFFFFFFFFu : f32_to_ordered(d);
+                key = ((uint64_t)o << 32) | i;
+            }
+            skeys[i] = key;
         }
-        skeys[i] = key;
     }
     __syncthreads();
     const uint64_t *sorted = skeys;
@@ -154,7 +161,10 @@ __global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
         uint64_t key = sorted[r];
         uint32_t id = (uint32_t)key;
         tokens[(size_t)q * P + r] = id;
-        token_dists[(size_t)q * P + r] = cdist[(size_t)q * L + id];
+        // inline mode: the distance is the key's high word (a NaN keeps its payload through cdist)
+        const uint32_t ob = (uint32_t)(key >> 32);
+        token_dists[(size_t)q * P + r] = (centers_inline && ob != 0xFFFFFFFFu) ? ordered_to_f32(ob)
+                                                                              : cdist[(size_t)q * L + id];
     }
     // exclusive prefixes over the P tokens: global leaf sizes (merge-key base), sample counts
     // (every st-th local point of each selected leaf) and local points
@@ -163,8 +173,8 @@ __global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
     uint32_t a_g = 0, a_s = 0, a_t = 0;
     for (uint32_t r = r0; r < r1; ++r) {
         const uint32_t leaf = (uint32_t)sorted[r];
-        const uint32_t sz = leaf_off[leaf + 1] - leaf_off[leaf];
-        a_g += leaf_gsize[leaf];
+        const uint32_t sz = centers_inline ? s_lsz[leaf] : leaf_off[leaf + 1] - leaf_off[leaf];
+        a_g += centers_inline ? s_lgs[leaf] : leaf_gsize[leaf];
         a_s += (sz + st - 1) / st;
         a_t += sz;
     }
@@ -198,10 +208,10 @@ __global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
     uint32_t vb = b_g + i_g - a_g, sb = b_s + i_s - a_s;
     for (uint32_t r = r0; r < r1; ++r) {
         const uint32_t leaf = (uint32_t)sorted[r];
-        const uint32_t sz = leaf_off[leaf + 1] - leaf_off[leaf];
+        const uint32_t sz = centers_inline ? s_lsz[leaf] : leaf_off[leaf + 1] - leaf_off[leaf];
         vbase[(size_t)q * (P + 1) + r] = vb;
         sbase[(size_t)q * (P + 2) + r] = sb;
-        vb += leaf_gsize[leaf];
+        vb += centers_inline ? s_lgs[leaf] : leaf_gsize[leaf];
         sb += (sz + st - 1) / st;
     }
     if (tid == 0) {
@@ -2087,16 +2097,17 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
 // measure of the re-ordering (utils/reordering.rs:35-44): squared_l2_avx2 / dot_product_avx2 /
 // l1_distance_avx2 (simd/x86.rs) or the cosine of one_to_one.rs:559-612.  The result is valid in the
 // group's lane 0 (act must be uniform over the group).
+template <int U = 8>   // independent loads in flight per lane (U * 8 dims per memory round trip)
 __device__ __forceinline__ float exact_pair_8lanes(const TxhIndexDev &ix, const float *s_q, const float *row, bool act,
                                                   uint32_t lane8) {
     const uint32_t dim = ix.dim, chunks = dim >> 3;
     float accv = 0.0f, aav = 0.0f, bbv = 0.0f;   // (aa / bb: Cosine's two extra lane chains)
-    for (uint32_t i0 = 0; i0 < chunks; i0 += 8) {   // 8 independent loads in flight per lane
-        float xv[8];
+    for (uint32_t i0 = 0; i0 < chunks; i0 += U) {
+        float xv[U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) xv[u] = (act && i0 + u < chunks) ? row[8 * (i0 + u) + lane8] : 0.0f;
+        for (int u = 0; u < U; ++u) xv[u] = (act && i0 + u < chunks) ? row[8 * (i0 + u) + lane8] : 0.0f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (i0 + u < chunks) {
                 const float qv = s_q[8 * (i0 + u) + lane8];
                 if (ix.measure == SCANN_HIP_DOT_PRODUCT) {   // dot_product_avx2, x86.rs:72-96
@@ -2825,6 +2836,9 @@ struct SmallArgs {
     uint32_t *out_idx;
     float *out_dist;
     uint32_t *out_count;
+    uint32_t *done;           // pinned completion flags [nq] of a host call (or nullptr) and their value
+    uint32_t seq;
+    uint32_t chunk;           // points per workgroup of the scan (a multiple of 256)
 };
 
 __global__ __launch_bounds__(256) void small_scan_kernel(TxhIndexDev ix, SmallArgs a) {
@@ -2833,7 +2847,7 @@ __global__ __launch_bounds__(256) void small_scan_kernel(TxhIndexDev ix, SmallAr
     if (pair == 0 && chunk == 0 && tid == 0) a.counters[CNT_STATUS] = 0;
     const uint32_t leaf = a.tokens[(size_t)q * a.P + r];
     const uint32_t lb = ix.leaf_off[leaf], size = ix.leaf_off[leaf + 1] - lb;
-    const uint32_t c0 = chunk * kSmallChunk;
+    const uint32_t c0 = chunk * a.chunk;
     if (c0 >= size) return;   // block-uniform
     const uint32_t S = ix.S, K = ix.K, dsub = ix.dsub, kp = ix.kp, dim = ix.dim;
     if (ix.exact_scan) {
@@ -2844,7 +2858,7 @@ __global__ __launch_bounds__(256) void small_scan_kernel(TxhIndexDev ix, SmallAr
         __syncthreads();
         const uint32_t vbe = a.vbase[(size_t)q * (a.P + 1) + r];
         uint64_t *oute = a.cand + (size_t)q * a.cap;
-        for (uint32_t j = c0 + tid; j < min(size, c0 + kSmallChunk); j += 256) {
+        for (uint32_t j = c0 + tid; j < min(size, c0 + a.chunk); j += 256) {
             const uint32_t csr = lb + j;
             const float *row = ix.rows + (size_t)(ix.rows_csr ? csr : ix.leaf_ids[csr]) * ix.stride;
             const float dist = exact_pair_thread(ix.measure, dim, s_qe, row);
@@ -2876,7 +2890,7 @@ __global__ __launch_bounds__(256) void small_scan_kernel(TxhIndexDev ix, SmallAr
     const uint32_t vb = a.vbase[(size_t)q * (a.P + 1) + r];
     const uint32_t bits = ix.code_bits, per = 32u / bits, mask = (1u << bits) - 1u, nw = ix.nw;
     uint64_t *out = a.cand + (size_t)q * a.cap;
-    for (uint32_t j = c0 + tid; j < min(size, c0 + kSmallChunk); j += 256) {
+    for (uint32_t j = c0 + tid; j < min(size, c0 + a.chunk); j += 256) {
         const uint32_t *w = ix.codes + (size_t)(lb + j) * nw;
         float acc = 0.0f;   // LookupTable::compute_distance (lut.rs:74-82): 0.0 + lut[0][c0] + lut[1][c1] ...
         for (uint32_t sub = 0; sub < S; ++sub) {
@@ -2908,21 +2922,44 @@ __global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDe
     // distinct keys) -> only the keys under the pivot are ranked.  Two passes over the list instead of
     // the histogram select's five; the histogram select remains for m close to cnt.
     uint64_t T = SCANN_KEY_MAX - 1;
+    uint32_t from_fin = 0;   // > 0: the candidates are among s_fin[0 .. from_fin)
     if (cnt > m) {
         bool done = false;
-        if ((uint64_t)m * 4 <= kFinGroups && cnt >= 4 * kFinGroups) {
-            constexpr int G = kFinGroups / kSelectThreads;   // sub-streams per thread
+        if (cnt <= kFinGroups) {   // a short stream: one load of the list into LDS, everything else there
+            for (uint32_t i = tid; i < cnt; i += nt) s_fin[i] = list[i];
+            __syncthreads();
+            const uint64_t t = block_select<uint64_t>(s_fin, cnt, m, sel_cfg(cnt), s_hist, s_slist, s_red);
+            if (t != SCANN_KEY_MAX) T = t;
+            done = true;
+            from_fin = cnt;
+            __syncthreads();
+        } else if ((uint64_t)m * 4 <= kFinGroups) {
+            // Both passes read the list as 16-byte pairs, four loads in flight per thread (one workgroup
+            // streams 800 KB at 100 k points: the passes are bound by its load round trips).  `head` = one
+            // leading key when the list starts on an odd 8-byte slot; a last odd key is `tail`.
+            constexpr int G = kFinGroups / kSelectThreads;   // minima per thread (any partition of the list works)
+            const uint32_t head = (reinterpret_cast<uintptr_t>(list) & 8u) ? 1u : 0u;
+            const uint32_t npairs = (cnt - head) >> 1;
+            const bool tail = ((cnt - head) & 1u) != 0;
+            const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(list + head);
             uint64_t mn[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) mn[g] = SCANN_KEY_MAX;
-            for (uint32_t i0 = 0; i0 < cnt; i0 += nt * G) {
+            for (uint32_t p0 = 0; p0 < npairs; p0 += nt * G) {
+                ulonglong2 v[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    const uint32_t i = i0 + (uint32_t)g * nt + tid;
-                    const uint64_t key = i < cnt ? list[i] : SCANN_KEY_MAX;
-                    mn[g] = key < mn[g] ? key : mn[g];
+                    const uint32_t pi = p0 + (uint32_t)g * nt + tid;
+                    v[g] = pi < npairs ? pairs[pi] : make_ulonglong2(SCANN_KEY_MAX, SCANN_KEY_MAX);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const uint64_t lo2 = v[g].x < v[g].y ? v[g].x : v[g].y;
+                    mn[g] = lo2 < mn[g] ? lo2 : mn[g];
                 }
             }
+            if (tid == 0 && head) mn[0] = list[0] < mn[0] ? list[0] : mn[0];
+            if (tid == 1 && tail) mn[0] = list[cnt - 1] < mn[0] ? list[cnt - 1] : mn[0];
 #pragma unroll
             for (int g = 0; g < G; ++g) s_fin[(uint32_t)g * nt + tid] = mn[g];
             __syncthreads();
@@ -2932,17 +2969,28 @@ __global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDe
             if (pivot != SCANN_KEY_MAX) {
                 if (tid == 0) s_n = 0;
                 __syncthreads();
-                for (uint32_t b0 = 0; b0 < cnt; b0 += nt) {   // keys under the pivot -> s_fin (reused)
-                    const uint32_t i = b0 + tid;
-                    const uint64_t key = i < cnt ? list[i] : SCANN_KEY_MAX;
-                    const bool keep = key <= pivot;
-                    uint32_t wtot;
-                    const uint32_t wpre = wave_prefix_count(keep, &wtot);
-                    uint32_t base = 0;
-                    if ((tid & 63u) == 0 && wtot) base = atomicAdd(&s_n, wtot);
-                    base = (uint32_t)__shfl((int)base, 0);
-                    if (keep && base + wpre < kFinGroups) s_fin[base + wpre] = key;
+                // keys under the pivot -> s_fin (reused): ~1 % of the list, one LDS atomic each
+                auto take = [&](uint64_t key) {
+                    if (key <= pivot) {
+                        const uint32_t pos = atomicAdd(&s_n, 1u);
+                        if (pos < kFinGroups) s_fin[pos] = key;
+                    }
+                };
+                for (uint32_t p0 = 0; p0 < npairs; p0 += nt * G) {
+                    ulonglong2 v[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const uint32_t pi = p0 + (uint32_t)g * nt + tid;
+                        v[g] = pi < npairs ? pairs[pi] : make_ulonglong2(SCANN_KEY_MAX, SCANN_KEY_MAX);
+                    }
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        take(v[g].x);
+                        take(v[g].y);
+                    }
                 }
+                if (tid == 0 && head) take(list[0]);
+                if (tid == 1 && tail) take(list[cnt - 1]);
                 __syncthreads();
                 const uint32_t c2 = s_n;
                 __syncthreads();
@@ -2950,6 +2998,7 @@ __global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDe
                     const uint64_t t = block_select<uint64_t>(s_fin, c2, m, sel_cfg(c2), s_hist, s_slist, s_red);
                     if (t != SCANN_KEY_MAX) T = t;
                     done = true;
+                    from_fin = c2;       // the m smallest keys are all among these: no third pass over the list
                     __syncthreads();
                 }
                 if (tid == 0) s_n = 0;
@@ -2963,10 +3012,12 @@ __global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDe
             __syncthreads();
         }
     }
-    for (uint32_t b0 = 0; b0 < cnt; b0 += nt) {
+    const uint64_t *src = from_fin ? s_fin : list;
+    const uint32_t nsrc = from_fin ? from_fin : cnt;
+    for (uint32_t b0 = 0; b0 < nsrc; b0 += nt) {
         const uint32_t i = b0 + tid;
         uint64_t key = SCANN_KEY_MAX;
-        if (i < cnt) key = list[i];
+        if (i < nsrc) key = src[i];
         const bool keep = key <= T;
         uint32_t wtot;
         const uint32_t wpre = wave_prefix_count(keep, &wtot);
@@ -2987,13 +3038,16 @@ __global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDe
             s_drow[r] = ix.leaf_off[a.tokens[(size_t)q * P + r]];
         }
     __syncthreads();
-    // decode + exact distance: 8 lanes per candidate
+    // decode + exact distance: 8 lanes per candidate.  The passes' row ids first (their leaf_ids loads
+    // travel together), then one memory round trip per candidate row of up to 128 dims.
     const uint32_t lane8 = tid & 7u;
-    for (uint32_t b0 = 0; b0 < nsel; b0 += nt / 8) {
-        const uint32_t c = b0 + (tid >> 3);
-        const bool act = c < nsel;
+    constexpr uint32_t kPasses = kSmallMaxM / (kSelectThreads / 8);
+    uint32_t idxs[kPasses], rowis[kPasses];
+#pragma unroll
+    for (uint32_t ps = 0; ps < kPasses; ++ps) {
+        const uint32_t c = ps * (nt / 8) + (tid >> 3);
         uint32_t idx = 0, rowi = 0;
-        if (act) {
+        if (c < nsel) {
             const uint32_t vpos = (uint32_t)s_keys[c];
             uint32_t lo = 0, hi = P;
             while (hi - lo > 1) {
@@ -3005,10 +3059,18 @@ __global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDe
             idx = ix.leaf_ids ? ix.leaf_ids[csr] : csr;
             rowi = ix.rows_csr ? csr : idx;
         }
+        idxs[ps] = idx;
+        rowis[ps] = rowi;
+    }
+#pragma unroll
+    for (uint32_t ps = 0; ps < kPasses; ++ps) {
+        const uint32_t c = ps * (nt / 8) + (tid >> 3);
+        if (ps * (nt / 8) >= nsel) break;   // block-uniform
+        const bool act = c < nsel;
         float r = 0.0f;
-        if (a.exact_reorder) r = exact_pair_8lanes(ix, s_q, ix.rows + (size_t)rowi * ix.stride, act, lane8);
+        if (a.exact_reorder) r = exact_pair_8lanes<16>(ix, s_q, ix.rows + (size_t)rowis[ps] * ix.stride, act, lane8);
         if (act && lane8 == 0) {
-            s_idx[c] = idx;
+            s_idx[c] = idxs[ps];
             // without re-ordering the k best by approximate distance are wanted: order by the key itself
             s_eb[c] = a.exact_reorder ? f32_to_ordered(r) : (uint32_t)(s_keys[c] >> 32);
         }
@@ -3055,6 +3117,11 @@ __global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDe
         a.out_dist[(size_t)q * k + i] = __builtin_inff();
     }
     if (tid == 0) a.out_count[q] = nout;
+    if (a.done) {   // host call polling for completion: the flag after this block's result rows
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&a.done[q], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // =====================================================================================
@@ -3378,7 +3445,7 @@ static int launch_partition_stage(const TxhIndexDev &ix, const TxhWork &w, hipSt
     SCANN_TRY(set_dyn_lds(select_leaves_kernel, lds2));
     hipLaunchKernelGGL(select_leaves_kernel, dim3(w.nq), dim3(p2 && ix.L <= 4096 ? 256u : kSelectThreads), lds2, st,
                        w.cdist, ix.L, n2, w.P, p2, ix.leaf_gsize, ix.leaf_off, w.st, w.tokens, w.token_dists,
-                       w.vbase, w.sbase, (const float *)nullptr, (const float *)nullptr, 0u, 0u);
+                       w.vbase, w.sbase, (const float *)nullptr, (const float *)nullptr, 0u, 0u, 0u);
     LAUNCH_CHECK();
     return SCANN_HIP_OK;
 }
@@ -3530,12 +3597,13 @@ static int launch_search_small(const TxhIndexDev &ix, const TxhWork &w, hipStrea
         const uint32_t n2 = next_pow2_u32(ix.L);
         const uint32_t p2 = (w.P * 4u <= n2) ? next_pow2_u32(std::max(1u, w.P)) : 0u;
         const SelCfg lcfg = sel_cfg(ix.L);
+        // (+ the leaf size tables and the query: the kernel's inline mode)
         const size_t lds2 = (size_t)(n2 + p2) * sizeof(uint64_t) + (size_t)lcfg.bins * 4 + (size_t)lcfg.list * 8 +
-                            48 * 8 + 64 * 4;
+                            48 * 8 + 64 * 4 + (size_t)ix.L * 8 + (size_t)((ix.dim + 3u) & ~3u) * 4 + 16;
         SCANN_TRY(set_dyn_lds(select_leaves_kernel, lds2));
         hipLaunchKernelGGL(select_leaves_kernel, dim3(w.nq), dim3(kSelectThreads), lds2, st, w.cdist, ix.L, n2, w.P, p2,
-                           ix.leaf_gsize, ix.leaf_off, w.st, w.tokens, w.token_dists, w.vbase, w.sbase, ix.centers,
-                           w.queries, w.q_stride, ix.dim);
+                           ix.leaf_gsize, ix.leaf_off, w.st, w.tokens, w.token_dists, w.vbase, w.sbase, ix.centers_t,
+                           w.queries, w.q_stride, ix.dim, ix.centers_pitch);
     }
     LAUNCH_CHECK();
     SmallArgs a;
@@ -3543,10 +3611,14 @@ static int launch_search_small(const TxhIndexDev &ix, const TxhWork &w, hipStrea
     a.exact_reorder = w.exact_reorder; a.queries = w.queries; a.tokens = w.tokens; a.vbase = w.vbase;
     a.cand = w.cand; a.counters = w.counters; a.allow = w.allow; a.allow_bits = w.allow_bits;
     a.out_idx = w.out_idx; a.out_dist = w.out_dist; a.out_count = w.out_count;
+    a.done = w.small_done; a.seq = w.small_seq;
+    // exact scans read a whole row per point (one row per thread keeps every load in flight at once); the
+    // ADC scan amortises the table build of its workgroup over four points per thread
+    a.chunk = ix.exact_scan ? 256u : kSmallChunk;
     const size_t lds_scan = ((size_t)(ix.exact_scan ? 0u : ix.S * ix.kp) + ix.dim) * sizeof(float);
     SCANN_TRY(set_dyn_lds(small_scan_kernel, lds_scan));
     if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
-    hipLaunchKernelGGL(small_scan_kernel, dim3(ceil_div_u32(w.small_max_leaf, kSmallChunk), w.nq * w.P), dim3(256),
+    hipLaunchKernelGGL(small_scan_kernel, dim3(ceil_div_u32(w.small_max_leaf, a.chunk), w.nq * w.P), dim3(256),
                        lds_scan, st, ix, a);
     LAUNCH_CHECK();
     if (ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
@@ -3776,6 +3848,24 @@ int launch_lut16_u8_batch(const uint8_t *d_packed, const uint8_t *d_lut8, uint32
     const uint32_t gx = (uint32_t)std::min<uint64_t>(ceil_div_u64(n, 256), 8192);
     hipLaunchKernelGGL(lut16_u8_batch_kernel, dim3(gx), dim3(256), (size_t)S * 16, st, d_packed, d_lut8,
                        S, n, bias, mult, d_out);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+__global__ __launch_bounds__(256) void transpose_centers_kernel(const float *__restrict__ centers, uint32_t L,
+                                                                uint32_t dim, uint32_t pitch, float *__restrict__ out) {
+    const uint64_t total = (uint64_t)dim * pitch;
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (uint64_t)gridDim.x * 256) {
+        const uint32_t j = (uint32_t)(e / pitch), c = (uint32_t)(e - (uint64_t)j * pitch);
+        out[e] = c < L ? centers[(size_t)c * dim + j] : 0.0f;
+    }
+}
+
+int launch_transpose_centers(const float *d_centers, uint32_t L, uint32_t dim, uint32_t pitch, float *d_out,
+                             hipStream_t st) {
+    if (L == 0 || dim == 0) return SCANN_HIP_OK;
+    hipLaunchKernelGGL(transpose_centers_kernel, dim3((uint32_t)std::min<uint64_t>(ceil_div_u64((uint64_t)dim * pitch, 256), 4096)),
+                       dim3(256), 0, st, d_centers, L, dim, pitch, d_out);
     LAUNCH_CHECK();
     return SCANN_HIP_OK;
 }
