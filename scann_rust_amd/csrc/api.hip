@@ -42,7 +42,7 @@ struct TxhWorkspace {
     DevBuf queries, cdist, tokens, token_dists, vbase, leaf_cnt, leaf_cursor, pair_off, tile_off,
         counters, pair_q, pair_leaf, pair_vbase, pair_thr, slot_of, lutq, thr, cand_cnt, cand, cand_key,
         cand_idx, cand_dist, cand_exact, cand_row, cand_count, out_idx, out_dist, out_count, allow,
-        sbase, pair_sbase, stile_off, samp, lut8, lut8_meta, cand32, cand32_codes, cand32_cnt, mfma_thr1, rr_lb, rr_ub;
+        sbase, pair_sbase, stile_off, samp, lut8, lut8_meta, cand32, cand32_codes, cand32_cnt, mfma_thr1, rr_lb, rr_ub, small_tickets;
 };
 
 // Pinned host memory the GPU reads and writes in place (grow-only).  Small host-side searches keep
@@ -639,6 +639,16 @@ int scann::txh_resolve_m(scann_hip_index *ix, uint32_t k, const scann_hip_search
 
 extern "C" {
 
+// ticket counters of small_fused_kernel: zeroed once, the kernel leaves them zero
+static int ensure_small_tickets(TxhWorkspace &s, uint32_t **out) {
+    if (!s.small_tickets.p) {
+        SCANN_TRY(s.small_tickets.ensure(64 * 4));
+        SCANN_HIP_CHECK(hipMemset(s.small_tickets.p, 0, 64 * 4));
+    }
+    *out = s.small_tickets.as<uint32_t>();
+    return SCANN_HIP_OK;
+}
+
 static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t nq, const TxhCallParams &p,
                                 bool own_queries, uint32_t q_stride, bool own_outputs,
                                 TxhWork *w) {
@@ -694,6 +704,8 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
     w->small = (uint32_t)p.small;
     w->small_done = nullptr;
     w->small_seq = 0;
+    w->small_tickets = nullptr;
+    if (p.small) SCANN_TRY(ensure_small_tickets(s, &w->small_tickets));
     w->small_max_leaf = ix->local_sizes_desc.empty() ? 0u : ix->local_sizes_desc[0];
     w->need_sorted_cands = 0;
     w->allow = nullptr;
@@ -1059,6 +1071,7 @@ static int bf_small_search_host(scann_hip_index *ix, SlotLock &sl, const float *
     w.out_dist = reinterpret_cast<float *>(dp + off_dist);
     w.out_count = reinterpret_cast<uint32_t *>(dp + off_cnt);
     w.small = 1; w.small_max_leaf = n;
+    SCANN_TRY(ensure_small_tickets(ws, &w.small_tickets));
     w.small_done = reinterpret_cast<uint32_t *>(dp + off_flag);
     w.small_seq = seq;
     SCANN_TRY(txh_launch_search(ix->bfx, w, false, sl.stream, nullptr, nullptr));

@@ -149,6 +149,7 @@ struct TxhWork {
     uint32_t *cand32_codes;    // [nq][cap32][S/8] their packed codes (written next to the positions)
     uint32_t *small_done;      // small-batch host calls: [nq] pinned completion flags (or nullptr) ...
     uint32_t small_seq;        // ... and the value the finish kernel stores there after the result rows
+    uint32_t *small_tickets;   // [kSmallBatch] ticket counters of the one-launch pipeline (zero between launches)
     uint32_t cap32;
     uint32_t *sbase;           // [nq][P+2] prefix of per-leaf sample counts; [P]=samples, [P+1]=local points
     uint32_t *pair_sbase;      // [max_slots]

@@ -76,20 +76,23 @@ __global__ __launch_bounds__(64) void centroid_scores_kernel(
 // centers_inline != nullptr (small batches): the block scores the centroids itself first, with
 // centroid_scores_kernel's arithmetic (sequential scalar sum of (q_j - c_j)^2, no FMA), instead of reading
 // a matrix another launch produced.
-__global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
+// The kernel's body: also the first stage of small_fused_kernel, where EVERY workgroup of a query runs it
+// (write_out: only one of them stores the global outputs; s_tok_out / s_vb_out: LDS copies of the tokens
+// and the P + 1 key bases for the stages that follow in the same workgroup).
+__device__ __forceinline__ void select_leaves_body(
+    uint64_t *skeys, uint32_t q, bool write_out, uint32_t *s_tok_out, uint32_t *s_vb_out,
     float *__restrict__ cdist, uint32_t L, uint32_t n_pow2, uint32_t P, uint32_t p_pow2,
     const uint32_t *__restrict__ leaf_gsize, const uint32_t *__restrict__ leaf_off, uint32_t st,
     uint32_t *__restrict__ tokens, float *__restrict__ token_dists, uint32_t *__restrict__ vbase,
     uint32_t *__restrict__ sbase, const float *__restrict__ centers_inline, const float *__restrict__ queries,
     uint32_t q_stride, uint32_t dim, uint32_t centers_pitch) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];    // [n_pow2]
     uint64_t *s_top = skeys + n_pow2;                                   // [p_pow2] (select path)
     const SelCfg cfg = sel_cfg(L);
     uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_top + p_pow2);    // [cfg.bins]
     uint64_t *s_list = reinterpret_cast<uint64_t *>(s_hist + cfg.bins); // [cfg.list]
     uint64_t *s_red = s_list + cfg.list;                                // [48]
     uint32_t *s_scan = reinterpret_cast<uint32_t *>(s_red + 48);        // [3][kSelectThreads / 64] + cursor
-    const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = nt >> 6;
     const bool select_path = p_pow2 != 0;
     const uint32_t nfill = select_path ? L : n_pow2;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
                         acc = acc + d * d;
                     }
             }
-            cdist[(size_t)q * L + c] = acc;   // (kept for NaN payloads: see token_dists below)
+            if (write_out) cdist[(size_t)q * L + c] = acc;   // (kept for NaN payloads: see token_dists below)
             skeys[c] = ((uint64_t)((acc != acc) ? 0xFFFFFFFFu : f32_to_ordered(acc)) << 32) | c;
         }
         for (uint32_t i = L + tid; i < nfill; i += nt) skeys[i] = SCANN_KEY_MAX;
@@ -160,11 +163,14 @@ __global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
     for (uint32_t r = tid; r < P; r += nt) {
         uint64_t key = sorted[r];
         uint32_t id = (uint32_t)key;
-        tokens[(size_t)q * P + r] = id;
-        // inline mode: the distance is the key's high word (a NaN keeps its payload through cdist)
-        const uint32_t ob = (uint32_t)(key >> 32);
-        token_dists[(size_t)q * P + r] = (centers_inline && ob != 0xFFFFFFFFu) ? ordered_to_f32(ob)
-                                                                              : cdist[(size_t)q * L + id];
+        if (s_tok_out) s_tok_out[r] = id;
+        if (write_out) {
+            tokens[(size_t)q * P + r] = id;
+            // inline mode: the distance is the key's high word (a NaN keeps its payload through cdist)
+            const uint32_t ob = (uint32_t)(key >> 32);
+            token_dists[(size_t)q * P + r] = (centers_inline && ob != 0xFFFFFFFFu) ? ordered_to_f32(ob)
+                                                                                  : cdist[(size_t)q * L + id];
+        }
     }
     // exclusive prefixes over the P tokens: global leaf sizes (merge-key base), sample counts
     // (every st-th local point of each selected leaf) and local points
@@ -209,16 +215,33 @@ __global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
     for (uint32_t r = r0; r < r1; ++r) {
         const uint32_t leaf = (uint32_t)sorted[r];
         const uint32_t sz = centers_inline ? s_lsz[leaf] : leaf_off[leaf + 1] - leaf_off[leaf];
-        vbase[(size_t)q * (P + 1) + r] = vb;
-        sbase[(size_t)q * (P + 2) + r] = sb;
+        if (s_vb_out) s_vb_out[r] = vb;
+        if (write_out) {
+            vbase[(size_t)q * (P + 1) + r] = vb;
+            sbase[(size_t)q * (P + 2) + r] = sb;
+        }
         vb += centers_inline ? s_lgs[leaf] : leaf_gsize[leaf];
         sb += (sz + st - 1) / st;
     }
     if (tid == 0) {
-        vbase[(size_t)q * (P + 1) + P] = t_g;
-        sbase[(size_t)q * (P + 2) + P] = t_s;
-        sbase[(size_t)q * (P + 2) + P + 1] = t_t;
+        if (s_vb_out) s_vb_out[P] = t_g;
+        if (write_out) {
+            vbase[(size_t)q * (P + 1) + P] = t_g;
+            sbase[(size_t)q * (P + 2) + P] = t_s;
+            sbase[(size_t)q * (P + 2) + P + 1] = t_t;
+        }
     }
+}
+
+__global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
+    float *__restrict__ cdist, uint32_t L, uint32_t n_pow2, uint32_t P, uint32_t p_pow2,
+    const uint32_t *__restrict__ leaf_gsize, const uint32_t *__restrict__ leaf_off, uint32_t st,
+    uint32_t *__restrict__ tokens, float *__restrict__ token_dists, uint32_t *__restrict__ vbase,
+    uint32_t *__restrict__ sbase, const float *__restrict__ centers_inline, const float *__restrict__ queries,
+    uint32_t q_stride, uint32_t dim, uint32_t centers_pitch) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];    // [n_pow2] ...
+    select_leaves_body(skeys, blockIdx.x, true, nullptr, nullptr, cdist, L, n_pow2, P, p_pow2, leaf_gsize, leaf_off, st,
+                       tokens, token_dists, vbase, sbase, centers_inline, queries, q_stride, dim, centers_pitch);
 }
 
 // AsymmetricHasher mode: one implicit leaf (id 0) for every query.
@@ -2904,13 +2927,30 @@ __global__ __launch_bounds__(256) void small_scan_kernel(TxhIndexDev ix, SmallAr
     }
 }
 
-__global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDev ix, SmallArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float s_q[];   // [dim]
+// The finish stage: body of small_finish_kernel and last stage of small_fused_kernel (there vbq / tokq are
+// the workgroup's LDS copies of the query's key bases and tokens).
+// AGENT: the key list was written by other workgroups of the SAME launch (agent-scope write-through stores):
+// read it with agent-scope loads (the per-XCD L2s are not coherent with each other inside a kernel).
+template <bool AGENT>
+__device__ __forceinline__ uint64_t list_key(const uint64_t *p) {
+    if constexpr (AGENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+
+template <bool AGENT>
+__device__ __forceinline__ void small_finish_body(const TxhIndexDev &ix, const SmallArgs &a, uint32_t q, float *s_q,
+                                                  const uint32_t *vbq, const uint32_t *tokq) {
     __shared__ uint64_t s_keys[kSmallMaxM], s_slist[kSelListMax], s_red[48], s_fin[kFinGroups];
     __shared__ uint32_t s_hist[kSelBinsMax], s_eb[kSmallMaxM], s_idx[kSmallMaxM], s_n;
-    const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = kSelectThreads;
+    const uint32_t tid = threadIdx.x, nt = kSelectThreads;
     const uint32_t P = a.P, m = a.m, k = a.k;
-    const uint32_t *vbq = a.vbase + (size_t)q * (P + 1);
+    // result rows: plain stores, or -- when the host polls a completion flag in the same pinned buffer --
+    // system-scope write-through stores (visible to the host once they have completed)
+    const bool polled = a.done != nullptr;
+    auto out_store = [&](auto *p, auto v) {
+        if (polled) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else *p = v;
+    };
     const uint32_t cnt = min(vbq[P], a.cap);
     const uint64_t *list = a.cand + (size_t)q * a.cap;
     for (uint32_t j = tid; j < ix.dim; j += nt) s_q[j] = a.queries[(size_t)q * a.q_stride + j];
@@ -2926,7 +2966,7 @@ __global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDe
     if (cnt > m) {
         bool done = false;
         if (cnt <= kFinGroups) {   // a short stream: one load of the list into LDS, everything else there
-            for (uint32_t i = tid; i < cnt; i += nt) s_fin[i] = list[i];
+            for (uint32_t i = tid; i < cnt; i += nt) s_fin[i] = list_key<AGENT>(list + i);
             __syncthreads();
             const uint64_t t = block_select<uint64_t>(s_fin, cnt, m, sel_cfg(cnt), s_hist, s_slist, s_red);
             if (t != SCANN_KEY_MAX) T = t;
@@ -2950,7 +2990,15 @@ __global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDe
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const uint32_t pi = p0 + (uint32_t)g * nt + tid;
-                    v[g] = pi < npairs ? pairs[pi] : make_ulonglong2(SCANN_KEY_MAX, SCANN_KEY_MAX);
+                    v[g] = make_ulonglong2(SCANN_KEY_MAX, SCANN_KEY_MAX);
+                    if (pi < npairs) {
+                        if constexpr (AGENT) {
+                            v[g].x = list_key<true>(list + head + 2 * (size_t)pi);
+                            v[g].y = list_key<true>(list + head + 2 * (size_t)pi + 1);
+                        } else {
+                            v[g] = pairs[pi];
+                        }
+                    }
                 }
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
@@ -2958,8 +3006,8 @@ __global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDe
                     mn[g] = lo2 < mn[g] ? lo2 : mn[g];
                 }
             }
-            if (tid == 0 && head) mn[0] = list[0] < mn[0] ? list[0] : mn[0];
-            if (tid == 1 && tail) mn[0] = list[cnt - 1] < mn[0] ? list[cnt - 1] : mn[0];
+            if (tid == 0 && head) { const uint64_t k0 = list_key<AGENT>(list); mn[0] = k0 < mn[0] ? k0 : mn[0]; }
+            if (tid == 1 && tail) { const uint64_t k1 = list_key<AGENT>(list + cnt - 1); mn[0] = k1 < mn[0] ? k1 : mn[0]; }
 #pragma unroll
             for (int g = 0; g < G; ++g) s_fin[(uint32_t)g * nt + tid] = mn[g];
             __syncthreads();
@@ -2981,7 +3029,15 @@ __global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDe
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         const uint32_t pi = p0 + (uint32_t)g * nt + tid;
-                        v[g] = pi < npairs ? pairs[pi] : make_ulonglong2(SCANN_KEY_MAX, SCANN_KEY_MAX);
+                        v[g] = make_ulonglong2(SCANN_KEY_MAX, SCANN_KEY_MAX);
+                    if (pi < npairs) {
+                        if constexpr (AGENT) {
+                            v[g].x = list_key<true>(list + head + 2 * (size_t)pi);
+                            v[g].y = list_key<true>(list + head + 2 * (size_t)pi + 1);
+                        } else {
+                            v[g] = pairs[pi];
+                        }
+                    }
                     }
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
@@ -2989,8 +3045,8 @@ __global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDe
                         take(v[g].y);
                     }
                 }
-                if (tid == 0 && head) take(list[0]);
-                if (tid == 1 && tail) take(list[cnt - 1]);
+                if (tid == 0 && head) take(list_key<AGENT>(list));
+                if (tid == 1 && tail) take(list_key<AGENT>(list + cnt - 1));
                 __syncthreads();
                 const uint32_t c2 = s_n;
                 __syncthreads();
@@ -3017,7 +3073,7 @@ __global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDe
     for (uint32_t b0 = 0; b0 < nsrc; b0 += nt) {
         const uint32_t i = b0 + tid;
         uint64_t key = SCANN_KEY_MAX;
-        if (i < nsrc) key = src[i];
+        if (i < nsrc) key = from_fin ? src[i] : list_key<AGENT>(src + i);
         const bool keep = key <= T;
         uint32_t wtot;
         const uint32_t wpre = wave_prefix_count(keep, &wtot);
@@ -3035,7 +3091,7 @@ __global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDe
     if (staged)
         for (uint32_t r = tid; r < P; r += nt) {
             s_dvb[r] = vbq[r];
-            s_drow[r] = ix.leaf_off[a.tokens[(size_t)q * P + r]];
+            s_drow[r] = ix.leaf_off[tokq[r]];
         }
     __syncthreads();
     // decode + exact distance: 8 lanes per candidate.  The passes' row ids first (their leaf_ids loads
@@ -3055,7 +3111,7 @@ __global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDe
                 if ((staged ? s_dvb[mid] : vbq[mid]) <= vpos) lo = mid; else hi = mid;
             }
             const uint32_t csr = staged ? s_drow[lo] + (vpos - s_dvb[lo])
-                                        : ix.leaf_off[a.tokens[(size_t)q * P + lo]] + (vpos - vbq[lo]);
+                                        : ix.leaf_off[tokq[lo]] + (vpos - vbq[lo]);
             idx = ix.leaf_ids ? ix.leaf_ids[csr] : csr;
             rowi = ix.rows_csr ? csr : idx;
         }
@@ -3107,21 +3163,30 @@ __global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDe
                     }
             }
             if (tid == 0) {
-                a.out_idx[(size_t)q * k + r0] = s_idx[b_sl];
-                a.out_dist[(size_t)q * k + r0] = ordered_to_f32(b_eb);
+                out_store(&a.out_idx[(size_t)q * k + r0], s_idx[b_sl]);
+                out_store(&a.out_dist[(size_t)q * k + r0], ordered_to_f32(b_eb));
             }
         }
     }
     for (uint32_t i = nout + tid; i < k; i += nt) {
-        a.out_idx[(size_t)q * k + i] = kInvalid;
-        a.out_dist[(size_t)q * k + i] = __builtin_inff();
+        out_store(&a.out_idx[(size_t)q * k + i], kInvalid);
+        out_store(&a.out_dist[(size_t)q * k + i], __builtin_inff());
     }
-    if (tid == 0) a.out_count[q] = nout;
+    if (tid == 0) out_store(&a.out_count[q], nout);
     if (a.done) {   // host call polling for completion: the flag after this block's result rows
-        __threadfence_system();
+        // (rows and flag live in pinned host memory and are written with system-scope write-through stores,
+        // so waiting for their completion orders them; a system-scope release FENCE would write back the
+        // whole L2 -- tens of microseconds)
+        __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(&a.done[q], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) __hip_atomic_store(&a.done[q], a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+__global__ __launch_bounds__(kSelectThreads) void small_finish_kernel(TxhIndexDev ix, SmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_qf[];   // [dim]
+    const uint32_t q = blockIdx.x;
+    small_finish_body<false>(ix, a, q, s_qf, a.vbase + (size_t)q * (a.P + 1), a.tokens + (size_t)q * a.P);
 }
 
 // =====================================================================================
@@ -3587,9 +3652,197 @@ static int launch_exact_scan(const TxhIndexDev &ix, const TxhWork &w, hipStream_
     return SCANN_HIP_OK;
 }
 
+// ---- the small-batch pipeline as ONE launch ----------------------------------------------------------
+// A kernel that follows another in a stream starts ~8-10 us after it (dispatch latency), which for a handful
+// of queries is most of the job.  Here every workgroup (query q, 1024 stream positions) first repeats the
+// query's leaf selection (select_leaves_body: the tables come from L2, the repetition costs no time), then
+// scores its positions into the dense key list, and the LAST workgroup of the query to finish (a ticket
+// counter behind a __threadfence) runs the finish stage.  No workgroup ever waits for another.
+constexpr uint32_t kFusedChunk = kSelectThreads;   // stream positions per workgroup
+constexpr uint32_t kFusedMaxWgs = 512;              // nq x workgroups per query above which three launches are used
+
+struct FusedArgs {
+    uint32_t L, n_pow2, p_pow2, st;
+    float *cdist, *token_dists;
+    uint32_t *tokens, *vbase, *sbase;   // (written by workgroup 0 of each query)
+    uint32_t *tickets;                  // [nq], zero between launches
+};
+
+__global__ __launch_bounds__(kSelectThreads) void small_fused_kernel(TxhIndexDev ix, SmallArgs a, FusedArgs f) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // selection | scan tables | query
+    __shared__ uint32_t s_tok[kDecodeStage], s_vb[kDecodeStage + 1], s_lrow[kDecodeStage], s_last;
+    const uint32_t q = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, nt = kSelectThreads;
+    const uint32_t P = a.P, dim = ix.dim;
+    if (q == 0 && b == 0 && tid == 0) a.counters[CNT_STATUS] = 0;
+    // ---- stage 1: the P nearest leaves and their key bases (every workgroup of the query)
+    if (ix.ah_mode) {
+        if (tid == 0) {
+            s_tok[0] = 0;
+            s_vb[0] = 0;
+            s_vb[1] = ix.leaf_gsize[0];
+            if (b == 0) {   // (ah_tokens_kernel)
+                const uint32_t sz = ix.leaf_off[1] - ix.leaf_off[0];
+                f.tokens[q] = 0;
+                f.token_dists[q] = 0.0f;
+                f.vbase[2 * q] = 0;
+                f.vbase[2 * q + 1] = ix.leaf_gsize[0];
+                f.sbase[3 * q] = 0;
+                f.sbase[3 * q + 1] = (sz + f.st - 1) / f.st;
+                f.sbase[3 * q + 2] = sz;
+            }
+        }
+    } else {
+        select_leaves_body(reinterpret_cast<uint64_t *>(s_dyn), q, b == 0, s_tok, s_vb, f.cdist, f.L, f.n_pow2, P,
+                           f.p_pow2, ix.leaf_gsize, ix.leaf_off, f.st, f.tokens, f.token_dists, f.vbase, f.sbase,
+                           ix.centers_t, a.queries, a.q_stride, dim, ix.centers_pitch);
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < P; r += nt) s_lrow[r] = ix.leaf_off[s_tok[r]];
+    const uint32_t cnt = min(s_vb[P], a.cap);
+    const uint32_t chunk = a.chunk;   // stream positions per workgroup (<= the workgroup's threads)
+    const uint32_t v0 = b * chunk;
+    if (v0 >= cnt && b != 0) return;   // an idle workgroup (block-uniform; workgroup 0 always takes part)
+    __syncthreads();
+    // ---- stage 2: keys of the stream positions [v0, v0 + kFusedChunk)
+    const uint32_t v = v0 + tid;
+    const bool have = tid < chunk && v < cnt;
+    uint32_t r = 0;
+    if (have) {
+        uint32_t lo = 0, hi = P;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_vb[mid] <= v) lo = mid; else hi = mid;
+        }
+        r = lo;
+    }
+    const uint32_t j = have ? v - s_vb[r] : 0u;
+    const uint32_t csr = have ? s_lrow[r] + j : 0u;
+    uint64_t *out = a.cand + (size_t)q * a.cap;
+    if (ix.exact_scan) {
+        float *s_qe = reinterpret_cast<float *>(s_dyn);
+        for (uint32_t d = tid; d < dim; d += nt) s_qe[d] = a.queries[(size_t)q * a.q_stride + d];
+        __syncthreads();
+        if (have) {
+            const float *row = ix.rows + (size_t)(ix.rows_csr ? csr : ix.leaf_ids[csr]) * ix.stride;
+            __hip_atomic_store(&out[v], make_key(exact_pair_thread(ix.measure, dim, s_qe, row), v), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if (cnt) {
+        const uint32_t S = ix.S, K = ix.K, dsub = ix.dsub, kp = ix.kp;
+        float *s_lut = reinterpret_cast<float *>(s_dyn), *s_qr = s_lut + S * kp;
+        // the leaves this workgroup's positions fall into (uniform: from the first and last position)
+        uint32_t r_first = 0, r_last = 0;
+        {
+            const uint32_t va = v0, vz = min(v0 + chunk, cnt) - 1u;
+            uint32_t lo = 0, hi = P;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_vb[mid] <= va) lo = mid; else hi = mid;
+            }
+            r_first = lo;
+            lo = 0; hi = P;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_vb[mid] <= vz) lo = mid; else hi = mid;
+            }
+            r_last = lo;
+        }
+        const uint32_t bits = ix.code_bits, per = 32u / bits, mask = (1u << bits) - 1u, nw = ix.nw;
+        for (uint32_t rr = r_first; rr <= r_last; ++rr) {
+            if (s_vb[rr + 1] == s_vb[rr]) continue;   // an empty leaf (uniform)
+            const uint32_t leaf = s_tok[rr];
+            for (uint32_t d = tid; d < dim; d += nt) {   // residual q - centroid (mod.rs:309-316)
+                float x = a.queries[(size_t)q * a.q_stride + d];
+                if (ix.use_residuals) x = x - ix.centers[(size_t)leaf * dim + d];
+                s_qr[d] = x;
+            }
+            __syncthreads();
+            for (uint32_t e = tid; e < S * kp; e += nt) {   // LookupTable::from_query (lut.rs:47-70, codebook.rs:98-115)
+                const uint32_t sub = e / kp, c = e - sub * kp;
+                float acc = 0.0f;
+                if (c < K) {
+                    const float *cb = ix.codebook + ((size_t)sub * K + c) * dsub;
+                    for (uint32_t d = 0; d < dsub; ++d) {
+                        const float t = s_qr[sub * dsub + d] - cb[d];
+                        acc = acc + t * t;
+                    }
+                }
+                s_lut[e] = acc;
+            }
+            __syncthreads();
+            if (have && r == rr) {
+                const uint32_t *w = ix.codes + (size_t)csr * nw;
+                float acc = 0.0f;   // LookupTable::compute_distance (lut.rs:74-82)
+                for (uint32_t sub = 0; sub < S; ++sub) {
+                    const uint32_t code = (w[sub / per] >> (bits * (sub % per))) & mask;
+                    const float tv = s_lut[sub * kp + code];
+                    acc = sub == 0 ? tv : acc + tv;
+                }
+                __hip_atomic_store(&out[v], row_allowed(ix, a.allow, a.allow_bits, csr) ? make_key(acc, v) : SCANN_KEY_MAX,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();   // (the tables are rebuilt for the next leaf)
+        }
+    }
+    // ---- stage 3: the last workgroup of the query to get here finishes it.  The keys were stored with
+    // agent scope (write-through: the XCDs' L2s are not coherent with each other inside a kernel, and an
+    // agent-scope FENCE would write back the whole L2 -- tens of microseconds); every thread waits for its own
+    // store, the barrier orders the workgroup, the ticket is an agent-scope atomic, and the finish stage reads
+    // the list with agent-scope loads.
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t target = max(1u, (cnt + chunk - 1u) / chunk);
+        const uint32_t t = __hip_atomic_fetch_add(&f.tickets[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t + 1u == target) ? 1u : 0u;
+        if (s_last) __hip_atomic_store(&f.tickets[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    small_finish_body<true>(ix, a, q, reinterpret_cast<float *>(s_dyn), s_vb, s_tok);
+}
+
 // the three-launch pipeline for small batches (see "Small batches" above)
 static int launch_search_small(const TxhIndexDev &ix, const TxhWork &w, hipStream_t st, hipEvent_t ev0,
                                hipEvent_t ev1) {
+    {   // one launch when the grid stays small (SCANN_HIP_FUSED=0: always three)
+        // Exact scans read a whole row per thread, 64 cache lines per wave instruction: they are bound by the
+        // L1's line-request rate of ONE compute unit, so their workgroups take only 128 positions each (more
+        // compute units share the rows); ADC scans read 16 coalesced code bytes per point and take 1024 --
+        // but rebuild the tables per leaf one after the other, so tree indexes with several leaves per
+        // query keep the three-launch form, whose scan builds every leaf's table in its own workgroup.
+        uint32_t chunk = kFusedChunk;
+        if (ix.exact_scan) chunk = std::min(kFusedChunk, std::max(128u, (ceil_div_u32(w.cap, 256u) + 127u) & ~127u));
+        const uint32_t G = std::max(1u, ceil_div_u32(w.cap, chunk));
+        bool fused = w.small_tickets && w.P <= kDecodeStage && (uint64_t)w.nq * G <= kFusedMaxWgs &&
+                     (ix.exact_scan || w.P == 1);
+        if (const char *e = std::getenv("SCANN_HIP_FUSED")) fused = fused && std::atoi(e) != 0;
+        if (fused) {
+            SmallArgs a;
+            a.nq = w.nq; a.P = w.P; a.m = w.m; a.k = w.k; a.cap = w.cap; a.q_stride = w.q_stride;
+            a.exact_reorder = w.exact_reorder; a.queries = w.queries; a.tokens = w.tokens; a.vbase = w.vbase;
+            a.cand = w.cand; a.counters = w.counters; a.allow = w.allow; a.allow_bits = w.allow_bits;
+            a.out_idx = w.out_idx; a.out_dist = w.out_dist; a.out_count = w.out_count;
+            a.done = w.small_done; a.seq = w.small_seq; a.chunk = chunk;
+            FusedArgs f;
+            f.L = ix.L; f.n_pow2 = next_pow2_u32(ix.L);
+            f.p_pow2 = (w.P * 4u <= f.n_pow2) ? next_pow2_u32(std::max(1u, w.P)) : 0u;
+            f.st = w.st; f.cdist = w.cdist; f.token_dists = w.token_dists; f.tokens = w.tokens; f.vbase = w.vbase;
+            f.sbase = w.sbase; f.tickets = w.small_tickets;
+            const SelCfg lcfg = sel_cfg(ix.L);
+            const size_t lds_sel = ix.ah_mode ? 0 : (size_t)(f.n_pow2 + f.p_pow2) * sizeof(uint64_t) + (size_t)lcfg.bins * 4 +
+                                                    (size_t)lcfg.list * 8 + 48 * 8 + 64 * 4 + (size_t)ix.L * 8 +
+                                                    (size_t)((ix.dim + 3u) & ~3u) * 4 + 16;
+            const size_t lds_scan = ((size_t)(ix.exact_scan ? 0u : ix.S * ix.kp) + ix.dim) * sizeof(float);
+            const size_t lds = std::max(lds_sel, lds_scan);
+            SCANN_TRY(set_dyn_lds(small_fused_kernel, lds));
+            if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
+            hipLaunchKernelGGL(small_fused_kernel, dim3(G, w.nq), dim3(kSelectThreads), lds, st, ix, a, f);
+            LAUNCH_CHECK();
+            if (ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
+            return SCANN_HIP_OK;
+        }
+    }
     if (ix.ah_mode) {
         hipLaunchKernelGGL(ah_tokens_kernel, dim3(ceil_div_u32(w.nq, 256)), dim3(256), 0, st, w.nq,
                            ix.leaf_gsize, ix.leaf_off, w.st, w.tokens, w.token_dists, w.vbase, w.sbase);

@@ -1256,7 +1256,8 @@ def _small_cases():
 
 @pytest.mark.parametrize("kind,measure", list(_small_cases()))
 def test_small_batch_pipeline_matches_staged_pipeline(kind, measure, monkeypatch):
-    """Calls of <= 16 queries run select_leaves (inline centroid scoring) -> small_scan -> small_finish with
+    """Calls of <= 16 queries run select_leaves (inline centroid scoring) -> small_scan -> small_finish -- as ONE
+    launch (small_fused_kernel) when the grid is small, as three otherwise (SCANN_HIP_FUSED=0 forces three) -- with
     pinned zero-copy staging; SCANN_HIP_SMALL=0 sends the same call down the staged pipeline the batched
     parity tests pin to the oracle. Rows, distance bits and counts must be identical for every searcher
     kind and measure, for 1, 7 and 16 queries, for k above the scanned stream (short results), and with an
@@ -1305,12 +1306,16 @@ def test_small_batch_pipeline_matches_staged_pipeline(kind, measure, monkeypatch
     for nq in (1, 7, 16):
         for k in (10, 1, 64):
             monkeypatch.delenv("SCANN_HIP_SMALL", raising=False)
-            a = index.search_batched(q[:nq], k, o)
+            a = index.search_batched(q[:nq], k, o)              # one launch (small_fused_kernel) when the grid is small
+            monkeypatch.setenv("SCANN_HIP_FUSED", "0")
+            a3 = index.search_batched(q[:nq], k, o)             # the three-launch form
+            monkeypatch.delenv("SCANN_HIP_FUSED", raising=False)
             monkeypatch.setenv("SCANN_HIP_SMALL", "0")
-            b = index.search_batched(q[:nq], k, o)
-            assert np.array_equal(a[2], b[2]), (kind, nq, k)
-            assert np.array_equal(bits(a[1]), bits(b[1])), (kind, nq, k)
-            assert np.array_equal(a[0], b[0]), (kind, nq, k)
+            b = index.search_batched(q[:nq], k, o)              # the staged pipeline
+            for x, what in ((a, "fused"), (a3, "three launches")):
+                assert np.array_equal(x[2], b[2]), (kind, nq, k, what)
+                assert np.array_equal(bits(x[1]), bits(b[1])), (kind, nq, k, what)
+                assert np.array_equal(x[0], b[0]), (kind, nq, k, what)
         if oracle is not None:
             monkeypatch.delenv("SCANN_HIP_SMALL", raising=False)
             gi, gd, gc = index.search_batched(q[:nq], 10, o)
