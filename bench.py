@@ -94,6 +94,16 @@ def parse():
     p.add_argument("--bf-exact", action="store_true",
                    help="bf_dot: exact f32-MFMA kernels only (no bf16 shortlist)")
     a = p.parse_args()
+    a.raw = {key: getattr(a, key) for key in ("workload", "n", "dim", "subspaces", "leaves", "partitions_to_search",
+                                              "pre_reorder_k")}
+    return resolve_defaults(a)
+
+
+def resolve_defaults(a):
+    """Workload defaults from the launch shape (also called again when the sharded path cannot start and
+    the run falls back to replicas: `a.raw` keeps what the command line itself gave)."""
+    for key, val in a.raw.items():
+        setattr(a, key, val)
     sharded = (a.gpus > 1 or a.force_sharded) and a.multi_gpu == "shard" and a.workload in (None, "txh")
     a.sharded = sharded
     if a.workload is None:
@@ -372,25 +382,50 @@ def main():
     data = codebook = codes = None
     flops_per_query = None
     comm = None
+    shard_fallback = None
+    if sharded:
+        # The communicator first: if RCCL cannot be brought up on this node (it has never seen this code
+        # with more than one rank before the driver's scaling run), every rank falls back to the replica
+        # layout together and the JSON line says so -- a number with a note instead of a dead run.
+        err = ""
+        try:
+            if os.environ.get("SCANN_BENCH_FAIL_COMM"):   # (rehearsal of the fallback)
+                raise RuntimeError("forced by SCANN_BENCH_FAIL_COMM")
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(hip.Comm.unique_id()), dtype=torch.uint8).clone()
+            if nproc > 1:
+                dist.broadcast(uid, 0)
+            # RCCL prints a version banner on STDOUT when the first communicator is created; rank 0's stdout
+            # must carry exactly one JSON line, so the banner is sent to stderr
+            sys.stdout.flush()
+            saved_stdout = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                comm = hip.Comm(uid.numpy().tobytes(), rank, nproc, device=local_rank)
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_stdout, 1)
+                os.close(saved_stdout)
+        except Exception as e:   # noqa: BLE001 (any failure of the bring-up takes the fallback)
+            err = "%s: %s" % (type(e).__name__, e)
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+        if nproc > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok[0].item()) == 0:
+            shard_fallback = err or "another rank could not create the RCCL communicator"
+            print("[bench] rank %d: sharded path unavailable (%s); falling back to replicas" % (rank, shard_fallback),
+                  file=sys.stderr, flush=True)
+            comm = None
+            args.multi_gpu = "replica"
+            resolve_defaults(args)
+            sharded = False
+            replica = nproc > 1
+            n, dim, S, m = args.n, args.dim, args.subspaces, args.pre_reorder_k
+            stride = hip.compute_stride(dim)
     if sharded:
         st = build_txh_shard(args, torch, dist, hip, device, local_rank, rank, nproc, stride)
         index, queries_all = st["index"], st["queries"]
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            uid = torch.frombuffer(bytearray(hip.Comm.unique_id()), dtype=torch.uint8).clone()
-        if nproc > 1:
-            dist.broadcast(uid, 0)
-        # RCCL prints a version banner on STDOUT when the first communicator is created; rank 0's stdout
-        # must carry exactly one JSON line, so the banner is sent to stderr
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            comm = hip.Comm(uid.numpy().tobytes(), rank, nproc, device=local_rank)
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
     elif args.workload == "txh":
         st = build_txh_single(args, torch, hip, device, local_rank, stride)
         index, queries_all, data, codebook, codes = st["index"], st["queries"], st["data"], st["codebook"], st["codes"]
@@ -691,6 +726,9 @@ def main():
             "roofline": roof, "algorithmic_hbm": algo, "cpu_baseline": cpu, "batch_sweep": sweep,
             "secondary": secondary, "lib_sha256": lib_sha256(hip),
         }
+        if shard_fallback:
+            line["config"]["note"] = ("the leaf-sharded layout could not start (%s): replica layout measured "
+                                      "instead" % shard_fallback)
         print(json.dumps(line), flush=True)
     if comm is not None:
         torch.cuda.synchronize()
