@@ -2797,10 +2797,33 @@ __device__ __forceinline__ float exact_pair_thread(int measure, uint32_t dim, co
     const uint32_t chunks = dim >> 3;
     float ac[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, aa[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f},
           bb[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    for (uint32_t c = 0; c < chunks; ++c) {
+    // rows are 16-byte aligned when their stride is a multiple of 4 floats (compute_stride: always): 16-byte
+    // loads, four 8-dim chunks (eight loads) in flight -- a 4-byte load per element costs the L1 as many line
+    // requests as a 16-byte one
+    const bool vec = (reinterpret_cast<uintptr_t>(row) & 15u) == 0;
+    for (uint32_t c0 = 0; c0 < chunks; c0 += 4) {
+        float xs[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (c0 + u < chunks) {
+                if (vec) {
+                    const float4 lo4 = *reinterpret_cast<const float4 *>(row + 8 * (c0 + u));
+                    const float4 hi4 = *reinterpret_cast<const float4 *>(row + 8 * (c0 + u) + 4);
+                    xs[u][0] = lo4.x; xs[u][1] = lo4.y; xs[u][2] = lo4.z; xs[u][3] = lo4.w;
+                    xs[u][4] = hi4.x; xs[u][5] = hi4.y; xs[u][6] = hi4.z; xs[u][7] = hi4.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xs[u][j] = row[8 * (c0 + u) + j];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+        if (c0 + u >= chunks) break;
+        const uint32_t c = c0 + u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float qv = sq[8 * c + j], x = row[8 * c + j];
+            const float qv = sq[8 * c + j], x = xs[u][j];
             if (measure == SCANN_HIP_DOT_PRODUCT) {
                 ac[j] = fmaf(qv, x, ac[j]);
             } else if (measure == SCANN_HIP_L1) {
@@ -2813,6 +2836,7 @@ __device__ __forceinline__ float exact_pair_thread(int measure, uint32_t dim, co
                 const float d = qv - x;
                 ac[j] = fmaf(d, d, ac[j]);
             }
+        }
         }
     }
     float r, saa = 0.0f, sbb = 0.0f;
@@ -3068,6 +3092,7 @@ __device__ __forceinline__ void small_finish_body(const TxhIndexDev &ix, const S
             __syncthreads();
         }
     }
+
     const uint64_t *src = from_fin ? s_fin : list;
     const uint32_t nsrc = from_fin ? from_fin : cnt;
     for (uint32_t b0 = 0; b0 < nsrc; b0 += nt) {
@@ -3084,6 +3109,7 @@ __device__ __forceinline__ void small_finish_body(const TxhIndexDev &ix, const S
     }
     __syncthreads();
     const uint32_t nsel = min(s_n, min(m, kSmallMaxM));
+
     // decode tables of this query (key base and first CSR row of each selected leaf) in LDS: the
     // per-candidate chain vbase -> token -> leaf_off is otherwise three dependent global loads per pass
     uint32_t *s_dvb = reinterpret_cast<uint32_t *>(s_fin), *s_drow = s_dvb + kDecodeStage;   // (s_fin is free now)
@@ -3132,39 +3158,96 @@ __device__ __forceinline__ void small_finish_body(const TxhIndexDev &ix, const S
         }
     }
     __syncthreads();
+
     const uint32_t nout = min(k, nsel);
-    if (tid < 64) {   // the k best by (exact, merge key): wave 0, strided entries, k arg-min rounds
-        constexpr int E = kSmallMaxM / 64;
-        uint32_t eb[E];
-        uint64_t kk[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const uint32_t j = (uint32_t)e * 64u + tid;
-            eb[e] = j < nsel ? s_eb[j] : 0xFFFFFFFFu;
-            kk[e] = j < nsel ? s_keys[j] : SCANN_KEY_MAX;
+    if (nsel <= 64u) {
+        // few candidates (m = k: exact scans, hashers without re-ordering): one per lane of wave 0, each lane
+        // counts the candidates ahead of it in the (exact, merge key) order and writes its row at that rank
+        if (tid < 64) {
+            const uint32_t eb = tid < nsel ? s_eb[tid] : 0xFFFFFFFFu;
+            const uint64_t kk = tid < nsel ? s_keys[tid] : SCANN_KEY_MAX;
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < nsel; ++j) {
+                const uint32_t oe = (uint32_t)__shfl((int)eb, (int)j);
+                const uint64_t ok = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(kk >> 32), (int)j) << 32) |
+                                    (uint32_t)__shfl((int)(uint32_t)kk, (int)j);
+                rank += (oe < eb || (oe == eb && ok < kk)) ? 1u : 0u;
+            }
+            if (tid < nsel && rank < nout) {
+                out_store(&a.out_idx[(size_t)q * k + rank], s_idx[tid]);
+                out_store(&a.out_dist[(size_t)q * k + rank], ordered_to_f32(eb));
+            }
         }
-        for (uint32_t r0 = 0; r0 < nout; ++r0) {
-            uint32_t b_eb = 0xFFFFFFFFu, b_sl = 0xFFFFFFFFu;
-            uint64_t b_kk = SCANN_KEY_MAX;
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-                if ((uint32_t)e * 64u < nsel && (eb[e] < b_eb || (eb[e] == b_eb && kk[e] < b_kk))) {
-                    b_eb = eb[e];
-                    b_kk = kk[e];
-                    b_sl = (uint32_t)e * 64u + tid;
+    } else {
+        // the k best by (exact, merge key), two levels: every wave extracts the k best of ITS 64 candidates (one
+        // per lane: a round is one wave arg-min), then wave 0 the k best of the waves' finalists
+        // (s_hist / s_slist are free by now: [0, 1024) ordered exact, [1024, 2048) candidate slot; merge keys)
+        const uint32_t wave = tid >> 6, lane = tid & 63u;
+        const uint32_t nwv = (nsel + 63u) >> 6;           // waves that hold candidates
+        uint32_t *f_eb = s_hist, *f_sl = s_hist + kSmallMaxM;
+        uint64_t *f_kk = s_slist;
+        {
+            uint32_t eb = tid < nsel ? s_eb[tid] : 0xFFFFFFFFu;
+            uint64_t kk = tid < nsel ? s_keys[tid] : SCANN_KEY_MAX;
+            if (wave < nwv) {
+                for (uint32_t r0 = 0; r0 < nout; ++r0) {
+                    uint32_t b_eb = eb, b_sl = kk == SCANN_KEY_MAX ? 0xFFFFFFFFu : tid;
+                    uint64_t b_kk = kk;
+                    wave_argmin96(b_eb, b_kk, b_sl);
+                    if (b_sl == tid) {   // the winner leaves the pool
+                        eb = 0xFFFFFFFFu;
+                        kk = SCANN_KEY_MAX;
+                    }
+                    if (lane == 0) {
+                        f_eb[wave * nout + r0] = b_eb;
+                        f_kk[wave * nout + r0] = b_kk;
+                        f_sl[wave * nout + r0] = b_sl;
+                    }
                 }
-            wave_argmin96(b_eb, b_kk, b_sl);
-            if (b_sl != 0xFFFFFFFFu && (b_sl & 63u) == tid) {
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            constexpr int E = kSmallMaxM / 64;
+            const uint32_t nfin = nwv * nout;             // <= 16 * 64
+            uint32_t eb[E], sl[E];
+            uint64_t kk[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t j = (uint32_t)e * 64u + tid;
+                const bool ok = j < nfin && f_sl[j] != 0xFFFFFFFFu;
+                eb[e] = ok ? f_eb[j] : 0xFFFFFFFFu;
+                kk[e] = ok ? f_kk[j] : SCANN_KEY_MAX;
+                sl[e] = ok ? f_sl[j] : 0xFFFFFFFFu;
+            }
+            for (uint32_t r0 = 0; r0 < nout; ++r0) {
+                uint32_t b_eb = 0xFFFFFFFFu, b_sl = 0xFFFFFFFFu;
+                uint64_t b_kk = SCANN_KEY_MAX;
+                int b_e = -1;
 #pragma unroll
                 for (int e = 0; e < E; ++e)
-                    if ((uint32_t)e == (b_sl >> 6)) {
-                        eb[e] = 0xFFFFFFFFu;
-                        kk[e] = SCANN_KEY_MAX;
+                    if ((uint32_t)e * 64u < nfin && sl[e] != 0xFFFFFFFFu &&
+                        (eb[e] < b_eb || (eb[e] == b_eb && kk[e] < b_kk))) {
+                        b_eb = eb[e];
+                        b_kk = kk[e];
+                        b_sl = sl[e];
+                        b_e = e;
                     }
-            }
-            if (tid == 0) {
-                out_store(&a.out_idx[(size_t)q * k + r0], s_idx[b_sl]);
-                out_store(&a.out_dist[(size_t)q * k + r0], ordered_to_f32(b_eb));
+                const uint32_t mine = b_sl;
+                wave_argmin96(b_eb, b_kk, b_sl);
+                if (b_sl != 0xFFFFFFFFu && mine == b_sl) {   // (candidate slots are unique: exactly one lane)
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        if (e == b_e) {
+                            eb[e] = 0xFFFFFFFFu;
+                            kk[e] = SCANN_KEY_MAX;
+                            sl[e] = 0xFFFFFFFFu;
+                        }
+                }
+                if (tid == 0) {
+                    out_store(&a.out_idx[(size_t)q * k + r0], s_idx[b_sl]);
+                    out_store(&a.out_dist[(size_t)q * k + r0], ordered_to_f32(b_eb));
+                }
             }
         }
     }
@@ -3173,6 +3256,7 @@ __device__ __forceinline__ void small_finish_body(const TxhIndexDev &ix, const S
         out_store(&a.out_dist[(size_t)q * k + i], __builtin_inff());
     }
     if (tid == 0) out_store(&a.out_count[q], nout);
+
     if (a.done) {   // host call polling for completion: the flag after this block's result rows
         // (rows and flag live in pinned host memory and are written with system-scope write-through stores,
         // so waiting for their completion orders them; a system-scope release FENCE would write back the

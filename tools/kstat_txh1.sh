@@ -5,6 +5,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 bench.p
 python3 - <<PY
 import csv,glob
 f=glob.glob("$O/ks/**/*kernel_stats.csv", recursive=True)[0]
-print("m=$m", " ".join("%s %.1f" % (r["Name"].split("(")[0].split("::")[-1][:22], float(r["AverageNs"])/1e3) for r in csv.DictReader(open(f)) if int(r["Calls"])>=200))
+print("m=$m")
+for r in csv.DictReader(open(f)):
+    if int(r["Calls"]) >= 200 and ("small_" in r["Name"] or "select_leaves" in r["Name"]):
+        print("   %-28s %6.1f us" % (r["Name"].split("(")[0].split("::")[-1][:28], float(r["AverageNs"]) / 1e3))
 PY
 done

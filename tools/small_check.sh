@@ -6,4 +6,4 @@ bash tools/ann_table.sh gpurun_out/ann_small.txt > /dev/null 2>&1 || exit 1
 grep -E "^(algorithm|qps|batched_qps)" gpurun_out/ann_small.txt | paste - - - | head -4
 bash tools/prof_cli.sh cli_part --algorithm partitioned --distance squared-l2 --k 10 --synthetic-train 10000 --synthetic-test 200 --dim 64 --seed 42 | grep "small_\|select_leaves\|^qps" || exit 1
 bash tools/prof_cli.sh cli_bf --algorithm brute-force --distance squared-l2 --k 10 --synthetic-train 10000 --synthetic-test 200 --dim 64 --seed 42 | grep "small_\|^qps" || exit 1
-bash tools/kstat_txh1.sh 2>&1 | grep "m=1000" | tr ' ' '\n' | paste - - | grep "small_\|select_leaves"
+bash tools/kstat_txh1.sh 2>&1 | grep -A4 "m=1000"
