@@ -114,13 +114,13 @@ __device__ __forceinline__ void select_leaves_body(
         for (uint32_t c = tid; c < L; c += nt) {
             const float *col = centers_inline + c;
             float acc = 0.0f;
-            for (uint32_t j0 = 0; j0 < dim; j0 += 16) {
-                float cv[16];
+            for (uint32_t j0 = 0; j0 < dim; j0 += 64) {   // 64 loads in flight: one memory round trip per 64 dims
+                float cv[64];
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
+                for (int u = 0; u < 64; ++u)
                     cv[u] = j0 + (uint32_t)u < dim ? col[(size_t)(j0 + u) * centers_pitch] : 0.0f;
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
+                for (int u = 0; u < 64; ++u)
                     if (j0 + (uint32_t)u < dim) {
                         const float d = s_qv[j0 + u] - cv[u];
                         acc = acc + d * d;
