@@ -2772,19 +2772,22 @@ __global__ __launch_bounds__(256) void rerank_short_kernel(TxhIndexDev ix, Short
 }
 
 // =====================================================================================
-// Small batches (nq <= 16, short candidate streams): the search as THREE launches.
+// Small batches (nq <= 16, short candidate streams): the search as THREE launches -- or ONE.
 //
 // The batched pipeline above groups (query, leaf) pairs by leaf, samples a filter bound and scans
-// through tile queues: ~12 dependent launches, each ~5 us of dispatch on its own -- ~115-150 us of
+// through tile queues: ~12 dependent launches, each ~4 us of dispatch on its own -- ~115-150 us of
 // device time for ONE query, of which the scan is 15-40.  For a handful of queries none of that
 // machinery pays:
 //   1. select_leaves_kernel with inline centroid scoring            TreePartitioner::partition
-//   2. small_scan_kernel: one workgroup per (query, leaf, 1024-point chunk) builds the pair's table
+//   2. small_scan_kernel: one workgroup per (query, leaf, chunk of points) builds the pair's table
 //      in LDS (lut_build_kernel's arithmetic) and writes EVERY point's merge key at its stream
 //      position (dense list, no bound, no atomics)                  mod.rs:297-339
 //   3. small_finish_kernel: block per query: the m smallest keys (rank select), decode, exact
 //      distances (exact_pair_8lanes), the k best by (exact, merge key)   mod.rs:283-293, 342-364
-// Same keys, same arithmetic, same order: rows identical to the batched pipeline's.
+// small_fused_kernel (below) runs the three stages in one launch for exact-scan indexes and flat
+// hashers.  Same keys, same arithmetic, same order: rows identical to the batched pipeline's.
+// (Tried for the finish stage's rank select of a handful of keys: a tournament of 64-bit wave minima,
+// m rounds per wave and m over the finalists -- slower than block_select's histogram passes.)
 // =====================================================================================
 constexpr uint32_t kSmallChunk = 1024;      // points per workgroup of the scan
 constexpr uint32_t kSmallMaxM = 1024;       // candidates the finish kernel keeps in LDS
