@@ -1429,3 +1429,42 @@ def test_rerank_fp8_filter_matches_full_rerank(case, monkeypatch):
         assert np.array_equal(a[2], b[2]), (case, k, mm)
         assert np.array_equal(bits(a[1]), bits(b[1])), (case, k, mm)
         assert np.array_equal(a[0], b[0]), (case, k, mm)
+
+
+# ---- leaf selection among many leaves (L > 4096: the keys of all leaves staged in > 64 KB of LDS) ---------
+@pytest.mark.parametrize("L,dim,P,kind", [(5000, 16, 10, "rand"), (9000, 32, 200, "rand"), (16384, 8, 512, "rand"),
+                                          (6000, 16, 37, "dups"), (5000, 8, 10, "all_equal"), (7000, 16, 600, "rand")])
+def test_partition_many_leaves(L, dim, P, kind):
+    """TreePartitioner::partition (partitioning/tree_partitioner.rs:196-229) with thousands of leaves: tokens
+    and distance bits against the oracle.  'dups': every centre occurs ~8 times (ties at the P-th place are
+    broken by leaf index, as the stable sort does); 'all_equal': all centres identical (every key ties on the
+    distance); P = 600: the sort-everything form; a NaN query (every distance NaN) must also come out in leaf
+    order."""
+    rng = np.random.default_rng(L + P)
+    if kind == "rand":
+        centers = rng.standard_normal((L, dim)).astype(np.float32)
+    elif kind == "dups":
+        base = rng.standard_normal((L // 8 + 1, dim)).astype(np.float32)
+        centers = base[rng.integers(0, base.shape[0], L)]
+    else:
+        centers = np.tile(rng.standard_normal((1, dim)).astype(np.float32), (L, 1))
+    n = L                      # one row per leaf: the partitioner only needs the centres and the leaf sizes
+    rows = centers.copy()
+    data, stride = orc.to_strided(rows)
+    S = 8
+    codebook = rng.standard_normal((S, 16, dim // S)).astype(np.float32)
+    codes = rng.integers(0, 16, (n, S), dtype=np.uint8)
+    index = hip.txh_create(data=data, n_rows=n, dim=dim, stride=stride, centers=centers,
+                           leaf_offsets=np.arange(L + 1, dtype=np.uint32), leaf_ids=np.arange(n, dtype=np.uint32),
+                           codebook=codebook, codes=codes, codes_packed4=False, use_residuals=True,
+                           partitions_to_search=P, pre_reorder_multiplier=3.0)
+    q = rng.standard_normal((40, dim)).astype(np.float32)
+    q[7] = centers[11]         # an exact hit (distance 0, with its duplicates)
+    q[9] = np.nan
+    tok, dist, cnt = hip.txh_partition(index, q, P)
+    for i in range(q.shape[0]):
+        ot, od = orc.partition(centers, q[i], P)
+        assert cnt[i] == ot.size, (i, cnt[i], ot.size)
+        if i != 9:
+            assert np.array_equal(bits(dist[i, :ot.size]), bits(od)), i
+        assert np.array_equal(tok[i, :ot.size], ot), i
