@@ -1900,6 +1900,8 @@ __global__ __launch_bounds__(256) void leaf_exact_scan_kernel(TxhIndexDev ix, Ex
 struct SelectArgs {
     uint32_t P, m, k, cap;
     uint32_t lds_keys;   // capacity of the LDS key array (<= kSortCap)
+    uint32_t direct;     // unsorted selection straight from the global list (no LDS staging); sel_n sizes its scratch
+    uint32_t sel_n;
     int exact_reorder, local_only;
     int unsorted;   // candidates may leave in any order (final stage orders by 96-bit keys)
     const float *queries;
@@ -1963,7 +1965,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
                                                                        SelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];      // [a.lds_keys]
     const uint32_t sort_cap = a.lds_keys;
-    const SelCfg cfg = sel_cfg(sort_cap);
+    const SelCfg cfg = sel_cfg(a.direct ? a.sel_n : sort_cap);
     uint32_t *s_dvb = reinterpret_cast<uint32_t *>(skeys + sort_cap) + (kSelectThreads / 64 + 4) + cfg.bins +
                       2 * cfg.list + 96;                                  // [kDecodeStage]
     uint32_t *s_drow = s_dvb + kDecodeStage;                              // [kDecodeStage]
@@ -1989,7 +1991,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
     uint64_t *slist = reinterpret_cast<uint64_t *>(hist + cfg.bins);
     uint64_t *sred = slist + cfg.list;
     bool in_lds = false;   // skeys[0..cnt) already holds the candidates
-    if (cnt > sort_cap) {
+    if (cnt > sort_cap && !a.direct) {
         // More candidates than LDS holds (no-threshold retry, dense lists of the exact leaf scan):
         // rank-select the m-th smallest key straight from the global list, then keep the keys <= it
         // (keys are unique, so exactly m remain; m <= kMaxPreReorderK <= sort_cap).
@@ -1999,7 +2001,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
         __syncthreads();
         in_lds = true;
     }
-    if (cnt > sort_cap) {   // cannot happen: m <= sort_cap
+    if (cnt > sort_cap && !a.direct) {   // cannot happen: m <= sort_cap
         select_fail(a, q, (uint32_t)SCANN_HIP_RESOURCE_EXHAUSTED);
         return;
     }
@@ -2047,10 +2049,13 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
     if (a.unsorted) {
         // Selection without a sort: the m-th smallest key by histogram select, keep keys <= it.
         // The final stage orders by (exact, merge key), which equals (exact, approx rank).
-        if (!in_lds)
+        // direct: the keys stay in the (L2-hot) global list -- staging ~10 k keys takes 80-128 KB of LDS, ONE
+        // workgroup per compute unit; without it every query's workgroup is resident at once
+        const uint64_t *src = a.direct ? list : skeys;
+        if (!in_lds && !a.direct)
             for (uint32_t i = tid; i < cnt; i += nt) skeys[i] = list[i];
         __syncthreads();
-        const uint64_t T = cnt > m ? block_select<uint64_t>(skeys, cnt, m, cfg, hist, slist, sred) : SCANN_KEY_MAX;
+        const uint64_t T = cnt > m ? block_select<uint64_t>(src, cnt, m, cfg, hist, slist, sred) : SCANN_KEY_MAX;
         __syncthreads();
         uint32_t *s_slot = reinterpret_cast<uint32_t *>(sred);   // output cursor
         if (tid == 0) *s_slot = 0;
@@ -2060,7 +2065,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_rerank_kernel(TxhIndexD
             uint64_t key = 0;
             bool keep = false;
             if (i < cnt) {
-                key = skeys[i];
+                key = src[i];
                 keep = key <= T;
             }
             uint32_t wtot;
@@ -4036,12 +4041,22 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
     s.out_count = w.out_count;
     // LDS key array: the candidate capacity rounded up to a power of two (bitonic path), at
     // most kSortCap; small lists run with 256-thread blocks so several fit a CU
-    const uint32_t lds_keys = std::min(kSortCap, next_pow2_u32(std::max(w.cap, 64u)));
+    uint32_t lds_keys = std::min(kSortCap, next_pow2_u32(std::max(w.cap, 64u)));
+    // unsorted selection of a long list: straight from the global list, 512-thread workgroups with ~30 KB of
+    // LDS (SCANN_HIP_SELECT_DIRECT=0: stage the keys as before)
+    static const bool direct_ok = [] {
+        const char *e = std::getenv("SCANN_HIP_SELECT_DIRECT");
+        return !e || std::atoi(e) != 0;
+    }();
+    const bool direct = unsorted && direct_ok && lds_keys > 4096u;
+    s.direct = direct ? 1u : 0u;
+    s.sel_n = w.cap;
+    if (direct) lds_keys = 64;
     s.lds_keys = lds_keys;
-    const SelCfg scfg = sel_cfg(lds_keys);
+    const SelCfg scfg = sel_cfg(direct ? w.cap : lds_keys);
     const size_t lds_sel = (size_t)lds_keys * 8 + (size_t)(kSelectThreads / 64 + 4) * 4 +
                            (size_t)scfg.bins * 4 + (size_t)scfg.list * 8 + 48 * 8 + 2 * kDecodeStage * 4;
-    const uint32_t sel_threads = lds_keys <= 4096 ? 256u : kSelectThreads;
+    const uint32_t sel_threads = direct ? 512u : (lds_keys <= 4096 ? 256u : kSelectThreads);
     SCANN_TRY(set_dyn_lds(select_rerank_kernel, lds_sel));
     hipLaunchKernelGGL(select_rerank_kernel, dim3(w.nq), dim3(sel_threads), lds_sel, st, ix, s);
     LAUNCH_CHECK();
