@@ -366,6 +366,70 @@ __global__ __launch_bounds__(1024) void worklist_scan_kernel(
     }
 }
 
+// AsymmetricHasher mode (one leaf, every query's only token): everything txh_init_kernel, ah_tokens_kernel and
+// the three worklist kernels write is known from nq alone -- one single-workgroup kernel instead of five
+// launches (~4.5 us of dispatch each).  Same arrays, same values.
+struct AhSetupArgs {
+    uint32_t nq, max_slots, st, tp, quads_per_tile, chunks_per_tile, stp, squads_per_tile;
+    const uint32_t *leaf_gsize, *leaf_off;
+    uint32_t *leaf_cnt, *leaf_cursor, *counters, *cand_cnt, *cand32_cnt, *pair_q, *pair_leaf, *pair_vbase, *pair_sbase,
+        *slot_of, *tokens, *vbase, *sbase, *pair_off, *tile_off, *stile_off;
+    float *token_dists;
+};
+
+__global__ __launch_bounds__(1024) void ah_setup_kernel(AhSetupArgs a) {
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t sz = a.leaf_off[1] - a.leaf_off[0], gs = a.leaf_gsize[0];
+    const uint32_t c = sz ? a.nq : 0u, pad = (c + 3u) & ~3u;
+    const uint32_t ssz = (sz + a.st - 1) / a.st;
+    for (uint32_t i = tid; i < a.max_slots; i += nt) a.pair_q[i] = (sz && i < a.nq) ? i : kInvalid;   // slot of query i = i
+    for (uint32_t i = tid; i < CNT_WORDS; i += nt) {
+        uint32_t v = 0;
+        if (c) {
+            const uint32_t nch = (sz + a.tp - 1) / a.tp;
+            if (i == CNT_TOTAL_QUADS) v = pad / 4;
+            if (i == CNT_TOTAL_TILES)
+                v = ((nch + a.chunks_per_tile - 1) / a.chunks_per_tile) * ((pad / 4 + a.quads_per_tile - 1) / a.quads_per_tile);
+            if (i == CNT_TOTAL_STILES)
+                v = ((ssz + a.stp - 1) / a.stp) * ((pad / 4 + a.squads_per_tile - 1) / a.squads_per_tile);
+        }
+        a.counters[i] = v;
+    }
+    for (uint32_t q = tid; q < a.nq; q += nt) {
+        a.cand_cnt[q] = 0;
+        if (a.cand32_cnt) a.cand32_cnt[q] = 0;
+        a.tokens[q] = 0;
+        a.token_dists[q] = 0.0f;
+        a.vbase[2 * q] = 0;
+        a.vbase[2 * q + 1] = gs;
+        a.sbase[3 * q] = 0;
+        a.sbase[3 * q + 1] = ssz;
+        a.sbase[3 * q + 2] = sz;
+        if (sz) {
+            a.pair_leaf[q] = 0;
+            a.pair_vbase[q] = 0;
+            a.pair_sbase[q] = 0;
+        }
+        a.slot_of[q] = sz ? q : kInvalid;
+    }
+    if (tid == 0) {
+        a.leaf_cnt[0] = c;
+        a.leaf_cursor[0] = 0;
+        uint32_t tiles = 0, stiles = 0;
+        if (c) {
+            const uint32_t nch = (sz + a.tp - 1) / a.tp;
+            tiles = ((nch + a.chunks_per_tile - 1) / a.chunks_per_tile) * ((pad / 4 + a.quads_per_tile - 1) / a.quads_per_tile);
+            stiles = ((ssz + a.stp - 1) / a.stp) * ((pad / 4 + a.squads_per_tile - 1) / a.squads_per_tile);
+        }
+        a.pair_off[0] = 0;
+        a.pair_off[1] = pad;
+        a.tile_off[0] = 0;
+        a.tile_off[1] = tiles;
+        a.stile_off[0] = 0;
+        a.stile_off[1] = stiles;
+    }
+}
+
 __global__ void worklist_fill_kernel(uint32_t nq, uint32_t P, int ah, const uint32_t *__restrict__ tokens,
                                      const uint32_t *__restrict__ vbase,
                                      const uint32_t *__restrict__ sbase,
@@ -1055,9 +1119,29 @@ struct Lut8Meta {
 };
 
 // lutq [quad][s][16][4] f32 -> lut8 [slot][s][16] i8 (quantised value - 128) + meta[slot]
+// Pass bound of a pair slot on the integer sums (see the derivation above), as thr + 1: a point passes iff
+// acc - thr1 < 0.  Sums lie in [-128 S, 127 S]; the bound is clamped just outside that range (everything
+// passes: no filter bound, or a table that is not quantised; nothing passes: padding slots).
+__device__ __forceinline__ int mfma_pass_bound(uint32_t S, uint32_t pq, uint64_t T, double bias_sum, double scale) {
+    const int lim = 128 * (int)S + 8;
+    int thr = -lim;
+    if (pq != kInvalid) {
+        thr = lim;
+        if (T != SCANN_KEY_MAX && scale > 0.0) {
+            const double Tf = (double)ordered_to_f32((uint32_t)(T >> 32));
+            const double qmax = floor((Tf * (1.0 + (double)S * 1.1920928955078125e-07) - bias_sum) / scale +
+                                      0.5 * (double)S + 1.0) - 128.0 * (double)S;
+            thr = qmax >= (double)lim ? lim : (qmax <= -(double)lim ? -lim : (int)qmax);
+        }
+    }
+    return thr + 1;
+}
+
 __global__ __launch_bounds__(256) void lut8_build_kernel(uint32_t S, const float *__restrict__ lutq,
                                                         const uint32_t *__restrict__ counters,
-                                                        int8_t *__restrict__ lut8, Lut8Meta *__restrict__ meta) {
+                                                        int8_t *__restrict__ lut8, Lut8Meta *__restrict__ meta,
+                                                        const uint32_t *__restrict__ pair_q,
+                                                        const uint64_t *__restrict__ pair_thr, int *__restrict__ thr1) {
     __shared__ float s_min[4][64], s_rng[4][64];
     __shared__ double s_scale[4];
     __shared__ int s_bad[4];
@@ -1098,6 +1182,9 @@ __global__ __launch_bounds__(256) void lut8_build_kernel(uint32_t S, const float
         m.bias_sum = bias;
         m.scale = sc;
         meta[(size_t)quad * 4 + tid] = m;
+        // (the pair's pass bound right away: the filter bounds are known by now -- one launch less)
+        const size_t slot = (size_t)quad * 4 + tid;
+        thr1[slot] = mfma_pass_bound(S, pair_q[slot], pair_thr[slot], bias, sc);
     }
     __syncthreads();
     if (sub < S) {
@@ -1117,33 +1204,8 @@ __global__ __launch_bounds__(256) void lut8_build_kernel(uint32_t S, const float
     }
 }
 
-// Pass bound of every pair slot on the integer sums (see the derivation above), as thr + 1: a point
-// passes iff acc - thr1 < 0.  Sums lie in [-128 S, 127 S]; the bound is clamped just outside that
-// range (everything passes: no filter bound, or a table that is not quantised; nothing passes:
-// padding slots).
-__global__ void mfma_bounds_kernel(uint32_t nslots, uint32_t S, const uint32_t *__restrict__ pair_q,
-                                   const uint64_t *__restrict__ pair_thr, const Lut8Meta *__restrict__ meta,
-                                   int *__restrict__ thr1) {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= nslots) return;
-    const int lim = 128 * (int)S + 8;
-    int thr = -lim;
-    if (pair_q[slot] != kInvalid) {
-        const uint64_t T = pair_thr[slot];
-        const Lut8Meta m = meta[slot];
-        thr = lim;
-        if (T != SCANN_KEY_MAX && m.scale > 0.0) {
-            const double Tf = (double)ordered_to_f32((uint32_t)(T >> 32));
-            const double qmax = floor((Tf * (1.0 + (double)S * 1.1920928955078125e-07) - m.bias_sum) / m.scale +
-                                      0.5 * (double)S + 1.0) - 128.0 * (double)S;
-            thr = qmax >= (double)lim ? lim : (qmax <= -(double)lim ? -lim : (int)qmax);
-        }
-    }
-    thr1[slot] = thr + 1;
-}
-
 struct MfmaArgs {
-    const int *thr1;          // [slots] pass bound + 1 (mfma_bounds_kernel)
+    const int *thr1;          // [slots] pass bound + 1 (lut8_build_kernel)
     const uint32_t *pair_off, *tile_off, *pair_q, *pair_vbase;
     uint32_t *counters;
     const int8_t *lut8;
@@ -3639,10 +3701,7 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
     if constexpr (C::BITS == 4) {
         if (w.mfma) {
             hipLaunchKernelGGL(lut8_build_kernel, dim3(w.max_quads), dim3(256), 0, st, (uint32_t)C::S, w.lutq,
-                               w.counters, w.lut8, reinterpret_cast<Lut8Meta *>(w.lut8_meta));
-            LAUNCH_CHECK();
-            hipLaunchKernelGGL(mfma_bounds_kernel, dim3(ceil_div_u32(w.max_slots, 256)), dim3(256), 0, st, w.max_slots,
-                               (uint32_t)C::S, w.pair_q, w.pair_thr, reinterpret_cast<const Lut8Meta *>(w.lut8_meta),
+                               w.counters, w.lut8, reinterpret_cast<Lut8Meta *>(w.lut8_meta), w.pair_q, w.pair_thr,
                                w.mfma_thr1);
             LAUNCH_CHECK();
             MfmaArgs ma;
@@ -3978,6 +4037,21 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
                       hipEvent_t ev0, hipEvent_t ev1) {
     if (w.nq == 0) return SCANN_HIP_OK;
     if (w.small && !local_only && !w.need_sorted_cands) return launch_search_small(ix, w, st, ev0, ev1);
+    const uint32_t wl_tp = ix.exact_scan ? kExactRows : w.mfma ? kMfmaRange : w.resident ? kResThreads * kScanPPT : scan_tile_points(ix);
+    const uint32_t wl_qpt = ix.exact_scan ? exact_quads_per_tile(ix.dim) : w.mfma ? 8u : w.resident ? kResQuads : w.qpt;
+    const uint32_t wl_cpt = (w.resident && !ix.exact_scan && !w.mfma) ? w.res_cl : 1u;
+    if (ix.ah_mode && ix.L == 1 && w.P == 1) {
+        AhSetupArgs h;
+        h.nq = w.nq; h.max_slots = w.max_slots; h.st = w.st; h.tp = wl_tp; h.quads_per_tile = wl_qpt;
+        h.chunks_per_tile = wl_cpt; h.stp = scan_tile_points(ix); h.squads_per_tile = w.sqpt;
+        h.leaf_gsize = ix.leaf_gsize; h.leaf_off = ix.leaf_off; h.leaf_cnt = w.leaf_cnt; h.leaf_cursor = w.leaf_cursor;
+        h.counters = w.counters; h.cand_cnt = w.cand_cnt; h.cand32_cnt = w.mfma ? w.cand32_cnt : nullptr;
+        h.pair_q = w.pair_q; h.pair_leaf = w.pair_leaf; h.pair_vbase = w.pair_vbase; h.pair_sbase = w.pair_sbase;
+        h.slot_of = w.slot_of; h.tokens = w.tokens; h.vbase = w.vbase; h.sbase = w.sbase; h.pair_off = w.pair_off;
+        h.tile_off = w.tile_off; h.stile_off = w.stile_off; h.token_dists = w.token_dists;
+        hipLaunchKernelGGL(ah_setup_kernel, dim3(1), dim3(1024), 0, st, h);
+        LAUNCH_CHECK();
+    } else {
     {
         const uint32_t work = std::max(std::max(ix.L, w.nq), w.max_slots);
         hipLaunchKernelGGL(txh_init_kernel, dim3(std::min(1024u, ceil_div_u32(work, 256))), dim3(256), 0, st,
@@ -3992,10 +4066,7 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
                        npairs, ix.ah_mode, w.tokens, ix.leaf_off, w.leaf_cnt);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(worklist_scan_kernel, dim3(1), dim3(1024), 0, st, ix.L, w.leaf_cnt,
-                       ix.leaf_off,
-                       ix.exact_scan ? kExactRows : w.mfma ? kMfmaRange : w.resident ? kResThreads * kScanPPT : scan_tile_points(ix),
-                       ix.exact_scan ? exact_quads_per_tile(ix.dim) : w.mfma ? 8u : w.resident ? kResQuads : w.qpt,
-                       (w.resident && !ix.exact_scan && !w.mfma) ? w.res_cl : 1u, scan_tile_points(ix), w.st,
+                       ix.leaf_off, wl_tp, wl_qpt, wl_cpt, scan_tile_points(ix), w.st,
                        w.sqpt, w.pair_off, w.tile_off,
                        w.stile_off, w.counters);
     LAUNCH_CHECK();
@@ -4003,6 +4074,7 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
                        w.P, ix.ah_mode, w.tokens, w.vbase, w.sbase, ix.leaf_off, w.pair_off, w.leaf_cursor, w.pair_q,
                        w.pair_leaf, w.pair_vbase, w.pair_sbase, w.slot_of);
     LAUNCH_CHECK();
+    }
     if (ix.exact_scan) {
         SCANN_TRY(launch_exact_scan(ix, w, st, ev0, ev1));
     } else {
