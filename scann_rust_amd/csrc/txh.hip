@@ -1359,6 +1359,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
             // 1024 results): v_sub + v_alignbit shift the sign of acc - thr1 into the mask, so result r
             // ends up at bit 15 - r.
             uint32_t m16 = 0;
+            // the MFMA chain issues ahead of the other waves' staging / flush streams (s_setprio: -2 % kernel time)
+            __builtin_amdgcn_s_setprio(2);
 #pragma unroll
             for (int kt = 0; kt < KS; ++kt) {
                 if (kt + D < KS) av[(kt + D) % (D + 1)] = onehot(kt + D);
@@ -1368,6 +1370,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
                     m16 = __builtin_amdgcn_alignbit(m16, (uint32_t)(accO[r] - thr1), 31);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_s_setprio(0);
             if (t == 0) return;                // nothing before the first tile (wave-uniform)
             const uint32_t base = c0 + (t - 1) * 32u + 4u * h;
             if (t == ntile && (npts & 31u)) {  // partial last tile: rows past the leaf's end are padding
