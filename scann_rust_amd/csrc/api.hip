@@ -794,13 +794,13 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
         SCANN_TRY(s.lut8_meta.ensure((size_t)(max_slots + 4) * 16));
         SCANN_TRY(s.mfma_thr1.ensure((size_t)(max_slots + 4) * 4));
         SCANN_TRY(s.cand32.ensure((size_t)nq * cap32 * 4));
-        SCANN_TRY(s.cand32_codes.ensure((size_t)nq * cap32 * (t.S / 8) * 4));   // the survivors' packed codes
+        if (t.ah_mode) SCANN_TRY(s.cand32_codes.ensure((size_t)nq * cap32 * (t.S / 8) * 4));   // flat hashers: the survivors' packed codes
         SCANN_TRY(s.cand32_cnt.ensure((size_t)nq * 4));
         w->lut8 = s.lut8.as<int8_t>();
         w->lut8_meta = s.lut8_meta.p;
         w->mfma_thr1 = s.mfma_thr1.as<int>();
         w->cand32 = s.cand32.as<uint32_t>();
-        w->cand32_codes = s.cand32_codes.as<uint32_t>();
+        w->cand32_codes = t.ah_mode ? s.cand32_codes.as<uint32_t>() : nullptr;
         w->cand32_cnt = s.cand32_cnt.as<uint32_t>();
         w->cap32 = (uint32_t)cap32;
     }

@@ -1328,10 +1328,12 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
                 const uint32_t dst = s_fgb[wave][c] + idx;
                 if (dst < a.cap32) {
                     const size_t o = (size_t)s_fq[wave][c] * a.cap32 + dst;
-                    uint32_t cw[NW];
-                    Codec<S, 4>::load_words(ix.codes + (size_t)(lb + j) * NW, cw);
                     a.cand32[o] = s_fvb[wave][c] + j;
-                    Codec<S, 4>::store_words(a.cand32_codes + o * NW, cw);
+                    if (a.cand32_codes) {   // (wave-uniform)
+                        uint32_t cw[NW];
+                        Codec<S, 4>::load_words(ix.codes + (size_t)(lb + j) * NW, cw);
+                        Codec<S, 4>::store_words(a.cand32_codes + o * NW, cw);
+                    }
                 }
             }
         };
@@ -1393,10 +1395,12 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
                         const uint32_t pos = atomicAdd(&a.cand32_cnt[pq], 1u);
                         if (pos < a.cap32) {
                             const size_t o = (size_t)pq * a.cap32 + pos;
-                            uint32_t cw[NW];
-                            Codec<S, 4>::load_words(ix.codes + (size_t)(lb + j) * NW, cw);
                             a.cand32[o] = vb + j;
-                            Codec<S, 4>::store_words(a.cand32_codes + o * NW, cw);
+                            if (a.cand32_codes) {
+                                uint32_t cw[NW];
+                                Codec<S, 4>::load_words(ix.codes + (size_t)(lb + j) * NW, cw);
+                                Codec<S, 4>::store_words(a.cand32_codes + o * NW, cw);
+                            }
                         }
                     }
                     ++sl;
@@ -1479,7 +1483,7 @@ __global__ __launch_bounds__(kRefineThreads) void adc_refine_kernel(TxhIndexDev 
     }
     uint64_t *out = a.cand + (size_t)q * a.cap;
     const uint32_t *list = a.cand32 + (size_t)q * a.cap32;
-    const uint32_t *list_codes = a.cand32_codes + (size_t)q * a.cap32 * NW;
+    const uint32_t *list_codes = a.cand32_codes ? a.cand32_codes + (size_t)q * a.cap32 * NW : nullptr;
     constexpr int U = SCANN_REFINE_U;   // entries per thread per pass: their dependent loads (position -> codes) overlap
     for (uint32_t b0 = 0; b0 < cnt; b0 += kRefineThreads * U) {
         uint32_t vpos[U], csr[U], lo_[U];
@@ -1488,7 +1492,7 @@ __global__ __launch_bounds__(kRefineThreads) void adc_refine_kernel(TxhIndexDev 
         for (int u = 0; u < U; ++u) {
             const uint32_t e = b0 + tid + kRefineThreads * u;
             vpos[u] = e < cnt ? list[e] : 0xFFFFFFFFu;
-            C::load_words(list_codes + (size_t)(e < cnt ? e : 0u) * NW, w[u]);   // (written with the position)
+            if (a.cand32_codes) C::load_words(list_codes + (size_t)(e < cnt ? e : 0u) * NW, w[u]);   // (written with the position)
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1500,6 +1504,7 @@ __global__ __launch_bounds__(kRefineThreads) void adc_refine_kernel(TxhIndexDev 
             }
             lo_[u] = lo;
             csr[u] = (staged ? s_drow[lo] : ix.leaf_off[a.tokens[(size_t)q * P + lo]]) + (vp - (staged ? s_dvb[lo] : vbq[lo]));
+            if (!a.cand32_codes) C::load_words(ix.codes + (size_t)(vpos[u] == 0xFFFFFFFFu ? 0u : csr[u]) * NW, w[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -3707,11 +3712,18 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
                                w.counters, w.lut8, reinterpret_cast<Lut8Meta *>(w.lut8_meta), w.pair_q, w.pair_thr,
                                w.mfma_thr1);
             LAUNCH_CHECK();
+            // The survivors' codes travel with their positions for flat hashers: their ~12 k survivors per query
+            // are spread over the whole code array (random 16-byte gathers from 16 MB: refine 145 -> 65 us at
+            // C3).  In a tree index the survivors sit densely in the query's nearest leaves, the gathers hit
+            // L2, and writing the codes only costs the scan (10M x 128, P = 25 / 50: step +3.5 %).
+            // SCANN_HIP_MFMA_CODES: 0 never, 1 always.
+            bool codes_in_list = ix.ah_mode != 0;
+            if (const char *e = std::getenv("SCANN_HIP_MFMA_CODES")) codes_in_list = std::atoi(e) != 0;
             MfmaArgs ma;
             ma.thr1 = w.mfma_thr1;
             ma.pair_off = w.pair_off; ma.tile_off = w.tile_off; ma.pair_q = w.pair_q; ma.pair_vbase = w.pair_vbase;
             ma.counters = w.counters; ma.lut8 = w.lut8; ma.meta = reinterpret_cast<const Lut8Meta *>(w.lut8_meta);
-            ma.pair_thr = w.pair_thr; ma.cand32_cnt = w.cand32_cnt; ma.cand32 = w.cand32; ma.cand32_codes = w.cand32_codes; ma.cap32 = w.cap32;
+            ma.pair_thr = w.pair_thr; ma.cand32_cnt = w.cand32_cnt; ma.cand32 = w.cand32; ma.cand32_codes = codes_in_list ? w.cand32_codes : nullptr; ma.cap32 = w.cap32;
             if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
             uint32_t mwgs = 4;   // workgroups per CU (4 waves each)
             if (const char *e = std::getenv("SCANN_HIP_MFMA_WGS")) mwgs = (uint32_t)std::max(1, std::atoi(e));
@@ -3721,7 +3733,7 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
             RefineArgs ra;
             ra.P = w.P; ra.cap = w.cap; ra.cap32 = w.cap32; ra.tokens = w.tokens; ra.vbase = w.vbase;
             ra.slot_of = w.slot_of; ra.lutq = w.lutq; ra.thr = w.thr; ra.cand32_cnt = w.cand32_cnt;
-            ra.cand32 = w.cand32; ra.cand32_codes = w.cand32_codes; ra.cand_cnt = w.cand_cnt; ra.cand = w.cand; ra.counters = w.counters;
+            ra.cand32 = w.cand32; ra.cand32_codes = codes_in_list ? w.cand32_codes : nullptr; ra.cand_cnt = w.cand_cnt; ra.cand = w.cand; ra.counters = w.counters;
             ra.allow = w.allow; ra.allow_bits = w.allow_bits;
             const size_t lds_rf = w.P <= kRefineTablesMax ? (size_t)w.P * C::S * 16 * sizeof(float) : 16;
             SCANN_TRY(set_dyn_lds(adc_refine_kernel<C>, lds_rf));
