@@ -312,7 +312,7 @@ def scan_roofline(hip, workload, kernel_name, kernel_ms, scanned_points, S, K, Q
     code_bytes = S // 2 if K <= 16 else S
     algo_bytes = scanned_points * code_bytes + pairs_per_query * S * (16 if K <= 16 else 256) * 4 + k * 8
     t = kernel_ms * 1e-3
-    if kernel_name == "adc_mfma_kernel":
+    if kernel_name in ("adc_mfma_kernel", "adc_mfma16_kernel"):
         # integer-MFMA prefilter: one-hot(codes) [points x S*16] x u8 tables [S*16 x queries]; every
         # (point, query) costs S*16 multiply-adds on the matrix cores (16x the useful table adds: the price
         # of turning a gather into a product).  Bound: the i8 MFMA rate.

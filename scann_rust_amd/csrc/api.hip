@@ -757,12 +757,23 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
         // Integer-MFMA prefilter + exact refine (txh.hip K6d): 4-bit codes, a filter bound to prove
         // against, and enough pairs per leaf to fill 32-column MFMA tiles (a leaf scanned by few
         // queries would leave most columns empty; the LDS-gather kernels take those).
-        w->mfma = (t.code_bits == 4 && !p.no_threshold && !t.exact_scan && quads_per_leaf >= 6) ? 1u : 0u;
-        // SCANN_HIP_MFMA: 0 = never, 2 = whenever the code layout allows (tests), else the heuristic
+        // Leaves scanned by 8-24 queries (2-5 quads: typical Tree-X-Hybrid batches) take the 16-column form
+        // (adc_mfma16_kernel); fewer than that and the LDS-gather kernel wins.
+        const bool mfma_ok = t.code_bits == 4 && !p.no_threshold && !t.exact_scan;
+        // The prefilter pays while the wanted candidates are a small share of the scanned stream: every
+        // survivor (~1.5-2.4 m) is staged, flushed and recomputed by the refine.  Measured: 1M x 128 flat,
+        // m = 5000 (0.5 %): 2.7x faster than the gather scan; 10M x 128 / 1000 leaves, m / stream 0.1-0.6 %:
+        // steps 1.1-1.4x faster; 1-3 % (P = 10 or 25 with m = 8192): 1.1-1.2x slower.
+        const uint64_t stream = std::max<uint64_t>(1, max_stream(ix, P));
+        const bool sparse = (uint64_t)p.m * 128 <= stream;
+        w->mfma = !(mfma_ok && sparse) ? 0u : quads_per_leaf >= 6 ? 1u : quads_per_leaf >= 2 ? 2u : 0u;
+        // SCANN_HIP_MFMA: 0 = never, 2 / 3 = the 32- / 16-column form whenever the code layout allows (tests),
+        // else the heuristic
         if (const char *e = std::getenv("SCANN_HIP_MFMA")) {
             const int v = std::atoi(e);
             if (v == 0) w->mfma = 0u;
-            if (v == 2) w->mfma = (t.code_bits == 4 && !p.no_threshold && !t.exact_scan) ? 1u : 0u;
+            if (v == 2) w->mfma = mfma_ok ? 1u : 0u;
+            if (v == 3) w->mfma = mfma_ok ? 2u : 0u;
         }
         if (w->mfma) w->resident = 0u;
     }
@@ -998,7 +1009,7 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
         SCANN_TRY(txh_launch_search(ix->tx, w, false, stream, sl.primary ? ix->ev0 : nullptr,
                                     sl.primary ? ix->ev1 : nullptr));
         if (sl.primary) ix->timing_valid = ix->timing;
-        if (sl.primary) ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.mfma ? "adc_mfma_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
+        if (sl.primary) ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.mfma == 2 ? "adc_mfma16_kernel" : w.mfma ? "adc_mfma_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
         uint32_t counters[CNT_N];
         SCANN_HIP_CHECK(hipMemcpyAsync(counters, w.counters, sizeof(counters), hipMemcpyDeviceToHost,
                                        stream));
@@ -1184,7 +1195,7 @@ int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries,
     SCANN_TRY(txh_launch_search(ix->tx, w, false, st, ix->ev0,
                                 ix->ev1));
     ix->timing_valid = ix->timing;
-    ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.mfma ? "adc_mfma_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
+    ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.mfma == 2 ? "adc_mfma16_kernel" : w.mfma ? "adc_mfma_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
     return SCANN_HIP_OK;
 }
 
@@ -1236,7 +1247,7 @@ int scann_hip_txh_search_local_device(scann_hip_index *ix, const float *d_querie
     SCANN_TRY(txh_launch_search(ix->tx, w, true, st, ix->ev0,
                                 ix->ev1));
     ix->timing_valid = ix->timing;
-    ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.mfma ? "adc_mfma_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
+    ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.mfma == 2 ? "adc_mfma16_kernel" : w.mfma ? "adc_mfma_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
     return SCANN_HIP_OK;
 }
 

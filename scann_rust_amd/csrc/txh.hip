@@ -1422,6 +1422,214 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
     }
 }
 
+// The prefilter with 16-pair tiles on v_mfma_i32_16x16x64_i8, for leaves scanned by 8-24 queries of the batch
+// (typical Tree-X-Hybrid batches: 1024 queries x 10 leaves over 1000 leaves): a 32-pair tile would be a
+// third full there.  A tile = 32 points (two groups of 16) x 16 pairs = 2 x S/4 MFMAs of 4 subspaces each, two
+// independent accumulator chains of 4 registers.  Lane (c16 = lane & 15, kb = lane >> 4): A row = point c16 of
+// the group, K block kb = subspace 4 kt + kb (one-hot row from the LDS identity table); B column = pair c16;
+// results D[row 4 kb + r][column c16], r = 0..3.  Items, bounds, staging, flush and lists as in adc_mfma_kernel
+// (the worklist is built with 4 quads per tile).  Measured as a 32-pair kernel (two halves) this shape lost to
+// adc_mfma_kernel (more vector work per tile); here it replaces the f32 LDS-gather scan.
+template <int S_>
+__global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? 4 : 2)) void adc_mfma16_kernel(TxhIndexDev ix, MfmaArgs a) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    constexpr int S = S_, KT = S / 4, NW = S / 8, NP = (NW + 1) / 2;
+    __shared__ __attribute__((aligned(16))) uint32_t s_ident[64];                 // 16 one-hot rows of 16 bytes
+    __shared__ uint32_t s_stage[kMfmaWaves][16][kMfmaStage];
+    __shared__ uint32_t s_cnt[kMfmaWaves][16];
+    __shared__ uint32_t s_fpre[kMfmaWaves][16], s_fq[kMfmaWaves][16], s_fgb[kMfmaWaves][16], s_fvb[kMfmaWaves][16];   // per pair
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t c16 = lane & 15u, kb = lane >> 4;
+    if (tid < 64) {
+        const uint32_t c = tid >> 2, wsel = tid & 3u;
+        s_ident[tid] = (wsel == (c >> 2)) ? (1u << (8 * (c & 3u))) : 0u;
+    }
+    __syncthreads();
+    const uint32_t total_tiles = a.counters[CNT_TOTAL_TILES];
+    const char *ident = reinterpret_cast<const char *>(s_ident);
+
+    uint32_t tile = 0;
+    if (lane == 0) tile = grab_tile(a.counters + CNT_XQ, total_tiles);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    while (tile != kInvalid) {
+        uint32_t next_tile = 0;
+        if (lane == 0) next_tile = grab_tile(a.counters + CNT_XQ, total_tiles);
+        uint32_t lo = 0, hi = ix.L;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (uniform_load(a.tile_off + mid) <= tile) lo = mid; else hi = mid;
+        }
+        const uint32_t leaf = lo;
+        const uint32_t lb = uniform_load(ix.leaf_off + leaf);
+        const uint32_t size = uniform_load(ix.leaf_off + leaf + 1) - lb;
+        const uint32_t nranges = (size + kMfmaRange - 1) / kMfmaRange;
+        const uint32_t local = tile - uniform_load(a.tile_off + leaf);
+        const uint32_t range = local % nranges, pt = local / nranges;
+        const uint32_t slot0 = uniform_load(a.pair_off + leaf);
+        const uint32_t slot_end = uniform_load(a.pair_off + leaf + 1);
+        const uint32_t c0 = range * kMfmaRange;
+        const uint32_t npts = min(kMfmaRange, size - c0);
+
+        // this lane's pair (column c16 of the tile): tables, bound; query and key base go to LDS for the flush
+        const uint32_t slot = slot0 + pt * 16u + c16;
+        const bool pair_ok = slot < slot_end;
+        if (lane < 16) {
+            s_cnt[wave][lane] = 0;
+            s_fq[wave][lane] = pair_ok ? a.pair_q[slot] : kInvalid;
+            s_fvb[wave][lane] = pair_ok ? a.pair_vbase[slot] : 0u;
+        }
+        v4i b[KT];
+        {
+            const int8_t *bsrc = a.lut8 + ((size_t)(pair_ok ? slot : slot0) * S + kb) * 16;   // padding columns: any table
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) b[kt] = *reinterpret_cast<const v4i *>(bsrc + (size_t)kt * 64);
+        }
+        const int thr1 = pair_ok ? a.thr1[slot] : -(128 * S + 7);   // a point passes iff acc - thr1 < 0
+
+        const uint32_t ntile = (npts + 31u) >> 5;
+        uint32_t wn[2][NW];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint32_t j = c0 + 16u * g + c16;
+            Codec<S, 4>::load_words(ix.codes + (size_t)(lb + (j < size ? j : 0u)) * NW, wn[g]);
+        }
+        auto flush = [&](bool all) {
+            uint32_t n = 0, gbase = 0;
+            if (lane < 16) {
+                n = min(s_cnt[wave][lane], kMfmaStage);
+                if (!all && n + 32u <= kMfmaStage) n = 0;
+                if (n) {
+                    gbase = atomicAdd(&a.cand32_cnt[s_fq[wave][lane]], n);
+                    s_cnt[wave][lane] = 0;
+                }
+            }
+            uint32_t incl = n;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+                if ((int)lane >= o) incl += up;
+            }
+            const uint32_t total = (uint32_t)__shfl((int)incl, 15);
+            if (total == 0) return;
+            if (lane < 16) {
+                s_fpre[wave][lane] = incl - n;
+                s_fgb[wave][lane] = gbase;
+            }
+            for (uint32_t e = lane; e < total; e += 64u) {
+                uint32_t c = 0;
+#pragma unroll
+                for (uint32_t stp = 8; stp; stp >>= 1)
+                    if (s_fpre[wave][c + stp] <= e) c += stp;
+                const uint32_t idx = e - s_fpre[wave][c];
+                const uint32_t j = s_stage[wave][c][idx];
+                const uint32_t dst = s_fgb[wave][c] + idx;
+                if (dst < a.cap32) {
+                    const size_t o = (size_t)s_fq[wave][c] * a.cap32 + dst;
+                    a.cand32[o] = s_fvb[wave][c] + j;
+                    if (a.cand32_codes) {
+                        uint32_t cw[NW];
+                        Codec<S, 4>::load_words(ix.codes + (size_t)(lb + j) * NW, cw);
+                        Codec<S, 4>::store_words(a.cand32_codes + o * NW, cw);
+                    }
+                }
+            }
+        };
+        // step(t): the MFMAs of tile t into accN, the survivor mask of tile t - 1 from accO between them, then
+        // the staging of tile t - 1's survivors
+        auto step = [&](v4i (&accN)[2], const v4i (&accO)[2], uint32_t t) {
+            // byte kt' of pk[g][i] = code * 16 of subspace 4 kt + kb, kt = 4 i + {0, 2, 1, 3}[kt']
+            uint32_t pk[2][NP];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    const uint32_t y0 = (wn[g][2 * i] >> (4u * kb)) & 0x000F000Fu;
+                    const uint32_t y1 = (2 * i + 1 < NW) ? ((wn[g][(2 * i + 1 < NW) ? 2 * i + 1 : 0] >> (4u * kb)) & 0x000F000Fu) : 0u;
+                    pk[g][i] = (y0 | (y1 << 8)) << 4;
+                }
+            if (t + 1 < ntile) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const uint32_t j = c0 + (t + 1) * 32u + 16u * g + c16;
+                    Codec<S, 4>::load_words(ix.codes + (size_t)(lb + (j < size ? j : 0u)) * NW, wn[g]);
+                }
+            }
+            accN[0] = v4i{0, 0, 0, 0};
+            accN[1] = v4i{0, 0, 0, 0};
+            constexpr int NA = 2 * KT;                        // MFMAs per tile, in order (kt, g)
+            constexpr int D = kMfmaDepth < NA ? kMfmaDepth : NA;
+            v4i av[D + 1];
+            auto onehot = [&](int ai) {
+                const int kt = ai >> 1, g = ai & 1;
+                const int byte = ((kt & 1) << 1) | ((kt >> 1) & 1);   // kt & 3 -> {0, 2, 1, 3}
+                const uint32_t off = (pk[g][kt >> 2] >> (8 * byte)) & 0xFFu;
+                return *reinterpret_cast<const v4i *>(ident + off);
+            };
+#pragma unroll
+            for (int ai = 0; ai < D; ++ai) av[ai] = onehot(ai);
+            uint32_t m8 = 0;   // survivor bits: result (g, r) at bit 7 - (4 g + r)
+            __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+            for (int ai = 0; ai < NA; ++ai) {
+                const int kt = ai >> 1, g = ai & 1;
+                if (ai + D < NA) av[(ai + D) % (D + 1)] = onehot(ai + D);
+                accN[g] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[ai % (D + 1)], b[kt], accN[g], 0, 0, 0);
+#pragma unroll
+                for (int ri = ai * 8 / NA; ri < (ai + 1) * 8 / NA; ++ri)
+                    m8 = __builtin_amdgcn_alignbit(m8, (uint32_t)(accO[ri >> 2][ri & 3] - thr1), 31);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (t == 0) return;
+            const uint32_t base = c0 + (t - 1) * 32u + 4u * kb;
+            if (t == ntile && (npts & 31u)) {  // partial last tile: rows past the leaf's end are padding
+                uint32_t okm = 0;
+#pragma unroll
+                for (int ri = 0; ri < 8; ++ri)
+                    okm |= (base + 16u * (uint32_t)(ri >> 2) + (uint32_t)(ri & 3) < size ? 1u : 0u) << (7 - ri);
+                m8 &= okm;
+            }
+            bool risk = false;
+            m8 &= 0xFFu;
+            if (m8) {
+                uint32_t sl = atomicAdd(&s_cnt[wave][c16], (uint32_t)__popc(m8));
+                do {
+                    const uint32_t qi = 7u - ((uint32_t)__ffs((int)m8) - 1u);
+                    m8 &= m8 - 1u;
+                    const uint32_t j = base + 16u * (qi >> 2) + (qi & 3u);
+                    if (sl < kMfmaStage) {
+                        s_stage[wave][c16][sl] = j;
+                    } else {   // stage full: direct (slow) append
+                        const uint32_t pqd = s_fq[wave][c16];
+                        const uint32_t pos = atomicAdd(&a.cand32_cnt[pqd], 1u);
+                        if (pos < a.cap32) {
+                            const size_t o = (size_t)pqd * a.cap32 + pos;
+                            a.cand32[o] = s_fvb[wave][c16] + j;
+                            if (a.cand32_codes) {
+                                uint32_t cw[NW];
+                                Codec<S, 4>::load_words(ix.codes + (size_t)(lb + j) * NW, cw);
+                                Codec<S, 4>::store_words(a.cand32_codes + o * NW, cw);
+                            }
+                        }
+                    }
+                    ++sl;
+                } while (m8);
+                risk = sl + 32u > kMfmaStage;
+            }
+            if (__any(risk)) flush(false);
+        };
+        v4i accA[2], accB[2];
+        accA[0] = accA[1] = accB[0] = accB[1] = v4i{0, 0, 0, 0};
+        step(accA, accB, 0u);
+        for (uint32_t tl = 1; tl <= ntile; tl += 2) {
+            step(accB, accA, tl);
+            if (tl + 1 <= ntile) step(accA, accB, tl + 1);
+        }
+        flush(true);
+        tile = __builtin_amdgcn_readfirstlane(next_tile);
+    }
+}
+
 // Exact refine of the prefilter's survivors: block per query.  Recomputes the reference's f32 sums
 // (LookupTable::compute_distance, hashes/lut.rs:74-82: acc = lut[0][c0]; acc += lut[s][cs], s
 // ascending), forms the merge keys and keeps key <= T -- exactly adc_scan_kernel's survivors.
@@ -3727,7 +3935,10 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
             if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
             uint32_t mwgs = 4;   // workgroups per CU (4 waves each)
             if (const char *e = std::getenv("SCANN_HIP_MFMA_WGS")) mwgs = (uint32_t)std::max(1, std::atoi(e));
-            hipLaunchKernelGGL(adc_mfma_kernel<C::S>, dim3((uint32_t)cus * mwgs), dim3(kMfmaWaves * 64), 0, st, ix, ma);
+            if (w.mfma == 2)
+                hipLaunchKernelGGL(adc_mfma16_kernel<C::S>, dim3((uint32_t)cus * mwgs), dim3(kMfmaWaves * 64), 0, st, ix, ma);
+            else
+                hipLaunchKernelGGL(adc_mfma_kernel<C::S>, dim3((uint32_t)cus * mwgs), dim3(kMfmaWaves * 64), 0, st, ix, ma);
             LAUNCH_CHECK();
             if (ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
             RefineArgs ra;
@@ -4053,7 +4264,7 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
     if (w.nq == 0) return SCANN_HIP_OK;
     if (w.small && !local_only && !w.need_sorted_cands) return launch_search_small(ix, w, st, ev0, ev1);
     const uint32_t wl_tp = ix.exact_scan ? kExactRows : w.mfma ? kMfmaRange : w.resident ? kResThreads * kScanPPT : scan_tile_points(ix);
-    const uint32_t wl_qpt = ix.exact_scan ? exact_quads_per_tile(ix.dim) : w.mfma ? 8u : w.resident ? kResQuads : w.qpt;
+    const uint32_t wl_qpt = ix.exact_scan ? exact_quads_per_tile(ix.dim) : w.mfma == 2 ? 4u : w.mfma ? 8u : w.resident ? kResQuads : w.qpt;
     const uint32_t wl_cpt = (w.resident && !ix.exact_scan && !w.mfma) ? w.res_cl : 1u;
     if (ix.ah_mode && ix.L == 1 && w.P == 1) {
         AhSetupArgs h;

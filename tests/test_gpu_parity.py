@@ -1116,7 +1116,7 @@ def test_sharded_search_through_rccl_world1():
 @pytest.mark.parametrize("mode", ["ah", "txh"])
 def test_scan_paths_agree(mode, monkeypatch):
     """adc_scan_kernel (f32 LDS gather per chunk), adc_scan_res_kernel (resident tables) and the
-    integer-MFMA prefilter + exact refine (adc_mfma_kernel / adc_refine_kernel) are three schedules of the
+    integer-MFMA prefilter + exact refine (adc_mfma_kernel / adc_mfma16_kernel + adc_refine_kernel) are schedules of the
     same arithmetic: candidates (approximate distances bitwise, index sets) and final rows must be
     identical, with a filter bound in force (n >> m) and with an allow-bitmap."""
     if mode == "ah":
@@ -1136,7 +1136,8 @@ def test_scan_paths_agree(mode, monkeypatch):
     got = {}
     for name, env in (("chunk", {"SCANN_HIP_MFMA": "0", "SCANN_HIP_RESIDENT": "0"}),
                       ("resident", {"SCANN_HIP_MFMA": "0", "SCANN_HIP_RESIDENT": "2"}),
-                      ("mfma", {"SCANN_HIP_MFMA": "2"})):
+                      ("mfma", {"SCANN_HIP_MFMA": "2"}),          # 32-pair tiles (v_mfma_i32_32x32x32_i8)
+                      ("mfma16", {"SCANN_HIP_MFMA": "3"})):       # 16-pair tiles (v_mfma_i32_16x16x64_i8)
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         plain = index.search_batched(q, 10, o, stages=True)
@@ -1145,7 +1146,7 @@ def test_scan_paths_agree(mode, monkeypatch):
         got[name] = (plain, filt)
         monkeypatch.delenv("SCANN_HIP_RESIDENT", raising=False)
     ref_plain, ref_filt = got["chunk"]
-    for name in ("resident", "mfma"):
+    for name in ("resident", "mfma", "mfma16"):
         plain, filt = got[name]
         assert np.array_equal(plain[0], ref_plain[0]) and np.array_equal(bits(plain[1]), bits(ref_plain[1])), name
         assert np.array_equal(plain[2], ref_plain[2]), name
