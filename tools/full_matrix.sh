@@ -6,6 +6,7 @@ run() {
 }
 run SCANN_HIP_MFMA=0
 run SCANN_HIP_MFMA=2
+run SCANN_HIP_MFMA=3
 run SCANN_HIP_RERANK_I8=2 SCANN_HIP_RERANK_I8_MIN=1
 run SCANN_HIP_RERANK_I8=2 SCANN_HIP_RERANK_I8_MIN=1 SCANN_HIP_RERANK_STORE=fp8
 run SCANN_HIP_SMALL=0
