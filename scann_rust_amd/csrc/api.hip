@@ -800,7 +800,9 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
     if (w->mfma) {
         // survivors of the integer bound: the f32 filter's (<= cap) plus the quantisation margin
         const uint64_t ms2 = std::min<uint64_t>(std::max<uint64_t>(1, max_stream(ix, P)), 0xFFFFFFFFull);
-        const uint64_t cap32 = std::min<uint64_t>(ms2, (uint64_t)p.cap * 2 + 2048);
+        // (the margin's share is independent of m -- the points within 17 table steps above the bound -- and in
+        // the dense nearest leaves of a tree index it can be several thousand: a generous floor)
+        const uint64_t cap32 = std::min<uint64_t>(ms2, (uint64_t)p.cap * 4 + 16384);
         SCANN_TRY(s.lut8.ensure((size_t)max_slots * t.S * 16 + 64));
         SCANN_TRY(s.lut8_meta.ensure((size_t)(max_slots + 4) * 16));
         SCANN_TRY(s.mfma_thr1.ensure((size_t)(max_slots + 4) * 4));

@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--dist", default="clustered", choices=["clustered", "uniform"])
     ap.add_argument("--Ps", default="10,25,50,100")
     ap.add_argument("--ms", default="30,100,300")
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--kmeans-iters", type=int, default=8)
     ap.add_argument("--json", default="")
     a = ap.parse_args()
@@ -131,7 +131,7 @@ def main():
                     index.h, ctypes.c_void_p(qd.data_ptr()), Q, dim, k, ctypes.byref(o),
                     ctypes.c_void_p(oi.data_ptr()), ctypes.c_void_p(od.data_ptr()),
                     ctypes.c_void_p(oc.data_ptr()), sptr))
-            for _ in range(2):
+            for _ in range(10):   # (also lets the clocks settle after the previous configuration's kernels)
                 run()
             torch.cuda.synchronize()
             index.enable_timing(True)
