@@ -4339,7 +4339,10 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
     s.out_count = w.out_count;
     // LDS key array: the candidate capacity rounded up to a power of two (bitonic path), at
     // most kSortCap; small lists run with 256-thread blocks so several fit a CU
-    uint32_t lds_keys = std::min(kSortCap, next_pow2_u32(std::max(w.cap, 64u)));
+    // (sorted path: room for the m keys that are kept -- a longer list is rank-selected straight from global
+    // memory first, so the bitonic sort runs over pow2(m) keys, not pow2(capacity): half the stages' work at
+    // capacity ~1.4 m)
+    uint32_t lds_keys = std::min(kSortCap, next_pow2_u32(std::max(unsorted ? w.cap : std::min(w.cap, w.m), 64u)));
     // unsorted selection of a long list: straight from the global list, 512-thread workgroups with ~30 KB of
     // LDS (SCANN_HIP_SELECT_DIRECT=0: stage the keys as before)
     static const bool direct_ok = [] {
