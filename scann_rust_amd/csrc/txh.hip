@@ -1882,7 +1882,7 @@ __global__ __launch_bounds__(kScanThreads, C::WGS) void adc_sample_kernel(TxhInd
 __global__ __launch_bounds__(kSelectThreads) void threshold_select_kernel(
     uint32_t P, uint32_t m, uint32_t st, int no_threshold, const uint32_t *__restrict__ sbase,
     const uint32_t *__restrict__ samp, uint32_t scap, const uint32_t *__restrict__ slot_of,
-    uint64_t *__restrict__ thr, uint64_t *__restrict__ pair_thr) {
+    uint64_t *__restrict__ thr, uint64_t *__restrict__ pair_thr, const uint32_t *__restrict__ vbase) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_vals[];   // [scap rounded to 4]
     const SelCfg cfg = sel_cfg(scap);
     uint32_t *s_hist = s_vals + ((scap + 3u) & ~3u);                    // [cfg.bins]
@@ -1930,7 +1930,62 @@ __global__ __launch_bounds__(kSelectThreads) void threshold_select_kernel(
     // absent samples (0xFFFFFFFF: rejected by the allow-bitmap, padding) sort last; the bound
     // is MAX if the J-th smallest is one of them
     const uint32_t v = block_select<uint32_t>(s_vals, 4 * n4, J, cfg, s_hist, s_list, s_red);
-    publish(v == 0xFFFFFFFFu ? SCANN_KEY_MAX : (((uint64_t)v << 32) | 0xFFFFFFFFull));
+    if (v == 0xFFFFFFFFu) {
+        publish(SCANN_KEY_MAX);
+        return;
+    }
+    // Ties at the bound.  Coarse codes over clustered data give thousands of points the SAME approximate
+    // distance; a bound on the distance alone lets the whole tie group through (measured: 2.5x the expected
+    // survivors, candidate buffers overflowing).  The merge keys (distance, stream position) are unique, so the
+    // bound is the J-th smallest sample KEY: among the samples that tie on the distance, the one with the
+    // (J - #smaller)-th smallest stream position (sample i of token r is point i * st of that leaf).
+    __syncthreads();
+    uint32_t *s_cnt2 = reinterpret_cast<uint32_t *>(s_red);   // [0] smaller, [1] tied, [2] cursor, [3] result
+    if (tid < 4) s_cnt2[tid] = tid == 3 ? 0xFFFFFFFFu : 0u;
+    __syncthreads();
+    uint32_t less = 0, tied = 0;
+    for (uint32_t i = tid; i < 4 * n4; i += nt) {
+        const uint32_t x = s_vals[i];
+        less += x < v ? 1u : 0u;
+        tied += x == v ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        less += (uint32_t)__shfl_xor((int)less, o);
+        tied += (uint32_t)__shfl_xor((int)tied, o);
+    }
+    if ((tid & 63u) == 0) {
+        atomicAdd(&s_cnt2[0], less);
+        atomicAdd(&s_cnt2[1], tied);
+    }
+    __syncthreads();
+    const uint32_t a_less = s_cnt2[0], b_tied = s_cnt2[1];
+    uint32_t low = 0xFFFFFFFFu;   // (a single sample at the bound, or a tie group too large to rank: all of it passes)
+    if (vbase && b_tied > 1 && b_tied <= cfg.list && J > a_less) {   // block-uniform
+        uint32_t *s_vp = s_hist;                                   // [b_tied] stream positions of the tied samples
+        const uint32_t *sb = sbase + (size_t)q * (P + 2), *vb = vbase + (size_t)q * (P + 1);
+        for (uint32_t i = tid; i < 4 * n4; i += nt) {
+            if (s_vals[i] == v) {
+                uint32_t lo = 0, hi = P;   // token of sample slot i: largest r with sb[r] <= i
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (sb[mid] <= i) lo = mid; else hi = mid;
+                }
+                s_vp[atomicAdd(&s_cnt2[2], 1u)] = vb[lo] + (i - sb[lo]) * st;
+            }
+        }
+        __syncthreads();
+        const uint32_t need = J - a_less;                          // 1-based rank inside the tie group
+        for (uint32_t i = tid; i < b_tied; i += nt) {
+            const uint32_t x = s_vp[i];
+            uint32_t r = 0;
+            for (uint32_t j2 = 0; j2 < b_tied; ++j2) r += s_vp[j2] < x ? 1u : 0u;
+            if (r + 1 == need) s_cnt2[3] = x;                      // (positions are unique)
+        }
+        __syncthreads();
+        low = s_cnt2[3];
+    }
+    publish(((uint64_t)v << 32) | low);
 }
 
 // =====================================================================================
@@ -3909,9 +3964,13 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
         const SelCfg tcfg = sel_cfg(w.scap);
         const size_t lds_thr = ((size_t)((w.scap + 3u) & ~3u) + tcfg.bins + tcfg.list) * 4 + 48 * 8;
         const uint32_t nt = w.scap > 8192 ? kSelectThreads : 256u;
+        // SCANN_HIP_THR_TIES=0 (diagnostics / tests): bound on the distance alone, whole tie groups pass
+        bool thr_ties = true;
+        if (const char *e = std::getenv("SCANN_HIP_THR_TIES")) thr_ties = std::atoi(e) != 0;
         SCANN_TRY(set_dyn_lds(threshold_select_kernel, lds_thr));
         hipLaunchKernelGGL(threshold_select_kernel, dim3(w.nq), dim3(nt), lds_thr, st, w.P, w.m, w.st,
-                           w.no_threshold, w.sbase, w.samp, w.scap, w.slot_of, w.thr, w.pair_thr);
+                           w.no_threshold, w.sbase, w.samp, w.scap, w.slot_of, w.thr, w.pair_thr,
+                           thr_ties ? w.vbase : nullptr);
         LAUNCH_CHECK();
     }
     if constexpr (C::BITS == 4) {
@@ -3989,7 +4048,7 @@ static int launch_exact_scan(const TxhIndexDev &ix, const TxhWork &w, hipStream_
         const size_t lds_thr = ((size_t)((w.scap + 3u) & ~3u) + tcfg.bins + tcfg.list) * 4 + 48 * 8;
         SCANN_TRY(set_dyn_lds(threshold_select_kernel, lds_thr));
         hipLaunchKernelGGL(threshold_select_kernel, dim3(w.nq), dim3(256), lds_thr, st, w.P, w.m, w.st, 1, w.sbase,
-                           w.samp, w.scap, w.slot_of, w.thr, w.pair_thr);
+                           w.samp, w.scap, w.slot_of, w.thr, w.pair_thr, w.vbase);
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(stream_counts_kernel, dim3(ceil_div_u32(w.nq, 256)), dim3(256), 0, st, w.nq, w.P, w.vbase,

@@ -1469,3 +1469,59 @@ def test_partition_many_leaves(L, dim, P, kind):
         if i != 9:
             assert np.array_equal(bits(dist[i, :ot.size]), bits(od)), i
         assert np.array_equal(tok[i, :ot.size], ot), i
+
+
+# ---- the filter bound under massive ties of the approximate distance ---------------------------------------
+@pytest.mark.parametrize("mode", ["ah", "txh"])
+def test_threshold_ties_do_not_overflow_device_path(mode, monkeypatch):
+    """Coarse codes over clustered data give thousands of points the SAME approximate distance (here: every
+    row occurs 150 times).  The sampled filter bound is the J-th smallest sample KEY (distance, stream position),
+    not the distance alone -- with the distance alone the whole tie group passes and the candidate buffers of
+    the device entry point overflow (found with tools/sweep_txh.py on a 12.5M x 96 index).  The device path
+    must report no miss, and its rows must equal the host entry point's (which would have retried)."""
+    import ctypes
+    import torch
+    dim, S, copies, distinct = 32, 8, 3000, 60
+    rng = np.random.default_rng(21)
+    base = rng.standard_normal((distinct, dim)).astype(np.float32)
+    rows = base[rng.permutation(np.repeat(np.arange(distinct), copies))]
+    n = rows.shape[0]
+    data, stride = orc.to_strided(rows)
+    if mode == "ah":
+        ixa = trainer.build_ah_index(rows, S, K=16, seed=3, pq_iters=3)
+        kw = dict(data=data, n_rows=n, dim=dim, stride=stride, centers=None, leaf_offsets=None, leaf_ids=None,
+                  codebook=ixa["codebook"], codes=ixa["codes"], codes_packed4=False, use_residuals=False,
+                  partitions_to_search=1, pre_reorder_multiplier=1.0)
+        P = 1
+    else:
+        ixt = trainer.build_txh_index(rows, 12, S, K=16, use_residuals=True, seed=5, kmeans_iters=3, pq_iters=3)
+        kw = dict(data=data, n_rows=n, dim=dim, stride=stride, centers=ixt["centers"], leaf_offsets=ixt["leaf_off"],
+                  leaf_ids=ixt["leaf_ids"], codebook=ixt["codebook"], codes=ixt["codes"], codes_packed4=False,
+                  use_residuals=True, partitions_to_search=4, pre_reorder_multiplier=3.0)
+        P = 4
+    index = hip.txh_create(**kw)
+    nq, k = 96, 10
+    q = (base[rng.integers(0, distinct, nq)] + np.float32(0.05) * rng.standard_normal((nq, dim))).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    qd = torch.from_numpy(q).to(dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L = hip.load()
+    for m in (300, 2000):
+        o = hip.default_opts()
+        o.partitions_to_search, o.pre_reorder_k, o.exact_reorder = P, m, 1
+        want = index.search_batched(q, k, o)
+        oi_t = torch.empty((nq, k), dtype=torch.int32, device=dev)
+        od_t = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        oc_t = torch.empty((nq,), dtype=torch.int32, device=dev)
+        hip.check(L.scann_hip_search_batched_device(index.h, p(qd), nq, dim, k, ctypes.byref(o), p(oi_t), p(od_t),
+                                                    p(oc_t), sp))
+        hip.check(L.scann_hip_index_last_device_status(index.h, sp))        # no threshold / buffer miss
+        assert np.array_equal(oc_t.cpu().numpy().view(np.uint32), want[2])
+        assert np.array_equal(bits(od_t.cpu().numpy()), bits(want[1]))
+    # the same call with the bound on the distance alone: the tie group at the bound floods the buffer
+    monkeypatch.setenv("SCANN_HIP_THR_TIES", "0")
+    hip.check(L.scann_hip_search_batched_device(index.h, p(qd), nq, dim, k, ctypes.byref(o), p(oi_t), p(od_t), p(oc_t), sp))
+    with pytest.raises(hip.ScannError) as e:
+        hip.check(L.scann_hip_index_last_device_status(index.h, sp))
+    assert e.value.code == hip.RESOURCE_EXHAUSTED
