@@ -257,8 +257,42 @@ static void stress_tests() {
     }
 }
 
+// quantization/fp8.rs tests (:278-343) through the C++ mirror
+static void fp8_tests() {
+    const float e4[] = {0.0f, 1.0f, -1.0f, 0.5f, 2.0f, 100.0f, -0.1f};        // test_fp8_e4m3_roundtrip
+    {
+        Fp8Quantizer qz = Fp8Quantizer::e4m3();
+        std::vector<float> v(e4, e4 + 7);
+        const std::vector<float> r = qz.dequantize(qz.quantize(v));
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i] != 0.0f) EXPECT(std::fabs((v[i] - r[i]) / v[i]) < 0.2f);
+    }
+    const float e5[] = {0.0f, 1.0f, -1.0f, 0.5f, 2.0f, 4.0f, -0.125f};        // test_fp8_e5m2_roundtrip
+    {
+        Fp8Quantizer qz = Fp8Quantizer::e5m2();
+        std::vector<float> v(e5, e5 + 7);
+        const std::vector<float> r = qz.dequantize(qz.quantize(v));
+        for (size_t i = 0; i < v.size(); ++i)
+            if (std::fabs(v[i]) > 1e-6f) EXPECT(std::fabs((v[i] - r[i]) / v[i]) < 0.5f);
+    }
+    {                                                                            // test_fp8_quantizer
+        Fp8Quantizer qz = Fp8Quantizer::e4m3();
+        std::vector<float> v = {1.0f, 2.0f, 3.0f, 4.0f};
+        const std::vector<uint8_t> b = qz.quantize(v);
+        const std::vector<float> r = qz.dequantize(b);
+        for (size_t i = 0; i < v.size(); ++i) EXPECT(std::fabs(v[i] - r[i]) < 0.5f);
+        // test_simd_operations: dot and squared L2 of the query against its own FP8 image
+        const float dot = -one_to_many_fp8(v, b, 4, 1, DistanceMeasure::DotProduct)[0];
+        EXPECT(std::fabs(dot - 30.0f) < 1.0f);
+        EXPECT(one_to_many_fp8(v, b, 4, 1, DistanceMeasure::SquaredL2)[0] < 1.0f);
+        qz.calibrate_scale(2.0f);
+        EXPECT(qz.scale() == 224.0f && qz.bits() == 8 && qz.format() == Fp8Format::E4M3);
+    }
+}
+
 int main() {
     try {
+        fp8_tests();
         brute_force_tests();
         hasher_tests();
         tree_x_hybrid_tests();

@@ -61,6 +61,57 @@ inline scann_hip_ctx *context(int device = 0) {
     return ctxs[device];
 }
 
+// quantization/fp8.rs: the reference's FP8 codec and quantizer on the device (its own bit-level conversion,
+// restated bit for bit by scann_hip_fp8_quantize / _dequantize; see include/scann_hip.h).
+enum class Fp8Format : int { E4M3 = 0, E5M2 = 1 };               // fp8.rs:8-19
+
+struct Fp8Config {                                               // fp8.rs:22-62
+    Fp8Format format = Fp8Format::E4M3;
+    float scale = 1.0f;
+    static Fp8Config e4m3() { return Fp8Config{}; }
+    static Fp8Config e5m2() { return Fp8Config{Fp8Format::E5M2, 1.0f}; }
+    Fp8Config with_scale(float s) const { return Fp8Config{format, s}; }
+};
+
+class Fp8Quantizer {                                             // fp8.rs:206-273
+public:
+    explicit Fp8Quantizer(Fp8Config config = Fp8Config{}, int device = 0) : config_(config), device_(device) {}
+    static Fp8Quantizer e4m3() { return Fp8Quantizer(Fp8Config::e4m3()); }
+    static Fp8Quantizer e5m2() { return Fp8Quantizer(Fp8Config::e5m2()); }
+    Fp8Format format() const { return config_.format; }
+    float scale() const { return config_.scale; }
+    size_t bits() const { return 8; }
+    void calibrate_scale(float max_abs_value) {                  // :238-244
+        const float fp8_max = config_.format == Fp8Format::E4M3 ? 448.0f : 57344.0f;
+        config_.scale = fp8_max / std::max(max_abs_value, 1e-10f);
+    }
+    std::vector<uint8_t> quantize(const std::vector<float> &values) const {      // Quantizer::quantize
+        std::vector<uint8_t> out(values.size());
+        check(scann_hip_fp8_quantize(context(device_), values.data(), values.size(), config_.scale, (int)config_.format,
+                                     out.data()));
+        return out;
+    }
+    std::vector<float> dequantize(const std::vector<uint8_t> &bits) const {      // Quantizer::dequantize
+        std::vector<float> out(bits.size());
+        check(scann_hip_fp8_dequantize(context(device_), bits.data(), bits.size(), config_.scale, (int)config_.format,
+                                       out.data()));
+        return out;
+    }
+
+private:
+    Fp8Config config_;
+    int device_;
+};
+
+// one_to_many_fp8_float_{squared_l2,dot_product} (distance_measures/one_to_many_asymmetric.rs:327-377)
+inline std::vector<float> one_to_many_fp8(const std::vector<float> &query, const std::vector<uint8_t> &database,
+                                          size_t stride, size_t num_points, DistanceMeasure measure, int device = 0) {
+    std::vector<float> out(num_points);
+    check(scann_hip_fp8_distances(context(device), query.data(), (uint32_t)query.size(), database.data(), stride,
+                                  num_points, (int)measure, out.data()));
+    return out;
+}
+
 // data_format/dataset.rs: one row-major buffer, stride = align_up(dim, 16 floats).
 class DenseDataset {
 public:
