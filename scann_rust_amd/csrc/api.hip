@@ -44,6 +44,18 @@ struct TxhWorkspace {
         counters, pair_q, pair_leaf, pair_vbase, pair_thr, slot_of, lutq, thr, cand_cnt, cand, cand_key,
         cand_idx, cand_dist, cand_exact, cand_row, cand_count, out_idx, out_dist, out_count, allow,
         sbase, pair_sbase, stile_off, samp, lut8, lut8_meta, cand32, cand32_codes, cand32_cnt, mfma_thr1, rr_lb, rr_ub, small_tickets;
+    // Frees every buffer (hipFree waits for the device): a workspace that has to grow is rebuilt from scratch,
+    // in the order a fresh one is allocated.  Growing buffer by buffer (free one, allocate it larger, next)
+    // left rerank_short_kernel 3x slower than on a fresh workspace of the same sizes -- same instructions, same
+    // bytes fetched (PMC), a placement effect of the interleaved frees and allocations.
+    void release_all() {
+        DevBuf *all[] = {&queries, &cdist, &tokens, &token_dists, &vbase, &leaf_cnt, &leaf_cursor, &pair_off, &tile_off,
+                         &counters, &pair_q, &pair_leaf, &pair_vbase, &pair_thr, &slot_of, &lutq, &thr, &cand_cnt, &cand,
+                         &cand_key, &cand_idx, &cand_dist, &cand_exact, &cand_row, &cand_count, &out_idx, &out_dist,
+                         &out_count, &allow, &sbase, &pair_sbase, &stile_off, &samp, &lut8, &lut8_meta, &cand32,
+                         &cand32_codes, &cand32_cnt, &mfma_thr1, &rr_lb, &rr_ub, &small_tickets};
+        for (DevBuf *b : all) b->release();
+    }
 };
 
 // Pinned host memory the GPU reads and writes in place (grow-only).  Small host-side searches keep
@@ -660,6 +672,8 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
         return fail(SCANN_HIP_RESOURCE_EXHAUSTED, "batch x partitions_to_search exceeds the pair table (2^32 slots)");
     const uint32_t max_slots = (uint32_t)max_slots64;
     const uint32_t max_quads = max_slots / 4 + 1;
+    // growth of the per-candidate arrays: rebuild the whole workspace (see TxhWorkspace::release_all)
+    if (s.cand_key.p && s.cand_key.bytes < (size_t)nq * m * 8) s.release_all();
     if (own_queries) SCANN_TRY(s.queries.ensure((size_t)nq * q_stride * 4));
     if (!t.ah_mode) SCANN_TRY(s.cdist.ensure((size_t)nq * L * 4));
     SCANN_TRY(s.tokens.ensure((size_t)nq * P * 4));
