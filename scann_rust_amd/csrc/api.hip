@@ -673,7 +673,19 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
     const uint32_t max_slots = (uint32_t)max_slots64;
     const uint32_t max_quads = max_slots / 4 + 1;
     // growth of the per-candidate arrays: rebuild the whole workspace (see TxhWorkspace::release_all)
-    if (s.cand_key.p && s.cand_key.bytes < (size_t)nq * m * 8) s.release_all();
+    // Batches of 64 queries and more size their per-candidate arrays for the LARGEST pre_reorder_k right away:
+    // a handle that serves growing candidate counts otherwise reallocates its workspace piecemeal, which left
+    // rerank_short_kernel 3x slower (see TxhWorkspace::release_all); batch growth still rebuilds everything.
+    const uint32_t m_al = nq >= 64 ? std::max(m, kMaxPreReorderK) : m;
+    uint64_t cap_al = p.cap;
+    if (!p.no_threshold && m_al > m) {
+        const uint64_t ms_al = std::max<uint64_t>(1, max_stream(ix, P));
+        const uint32_t j_al = sample_rank(m_al, p.st);
+        uint64_t c_al = (uint64_t)((double)j_al + 8.0 * std::sqrt((double)j_al) + 16.0) * p.st + 256;
+        c_al = std::min(std::max<uint64_t>(c_al, m_al), ms_al);
+        cap_al = std::max<uint64_t>(cap_al, c_al);
+    }
+    if (s.cand_key.p && s.cand_key.bytes < (size_t)nq * m_al * 8) s.release_all();
     if (own_queries) SCANN_TRY(s.queries.ensure((size_t)nq * q_stride * 4));
     if (!t.ah_mode) SCANN_TRY(s.cdist.ensure((size_t)nq * L * 4));
     SCANN_TRY(s.tokens.ensure((size_t)nq * P * 4));
@@ -696,12 +708,12 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
     SCANN_TRY(s.lutq.ensure((size_t)max_quads * t.S * t.kp * 4 * 4));
     SCANN_TRY(s.thr.ensure((size_t)nq * 8));
     SCANN_TRY(s.cand_cnt.ensure((size_t)nq * 4));
-    SCANN_TRY(s.cand.ensure((size_t)nq * p.cap * 8));
-    SCANN_TRY(s.cand_key.ensure((size_t)nq * m * 8));
-    SCANN_TRY(s.cand_idx.ensure((size_t)nq * m * 4));
-    SCANN_TRY(s.cand_dist.ensure((size_t)nq * m * 4));
-    SCANN_TRY(s.cand_exact.ensure((size_t)nq * m * 4));
-    SCANN_TRY(s.cand_row.ensure((size_t)nq * m * 4));
+    SCANN_TRY(s.cand.ensure((size_t)nq * cap_al * 8));
+    SCANN_TRY(s.cand_key.ensure((size_t)nq * m_al * 8));
+    SCANN_TRY(s.cand_idx.ensure((size_t)nq * m_al * 4));
+    SCANN_TRY(s.cand_dist.ensure((size_t)nq * m_al * 4));
+    SCANN_TRY(s.cand_exact.ensure((size_t)nq * m_al * 4));
+    SCANN_TRY(s.cand_row.ensure((size_t)nq * m_al * 4));
     SCANN_TRY(s.cand_count.ensure((size_t)nq * 4));
     if (own_outputs) {
         SCANN_TRY(s.out_idx.ensure((size_t)nq * k * 4));
@@ -798,8 +810,8 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
         w->use_i8 = (t.rows8 && p.exact_reorder && p.m >= min_m && p.m > 4 * p.k) ? 1u : 0u;
         w->rr_lb = w->rr_ub = nullptr;
         if (w->use_i8) {
-            SCANN_TRY(s.rr_lb.ensure((size_t)nq * m * 4));
-            SCANN_TRY(s.rr_ub.ensure((size_t)nq * m * 4));
+            SCANN_TRY(s.rr_lb.ensure((size_t)nq * m_al * 4));
+            SCANN_TRY(s.rr_ub.ensure((size_t)nq * m_al * 4));
             w->rr_lb = s.rr_lb.as<uint32_t>();
             w->rr_ub = s.rr_ub.as<uint32_t>();
         }
@@ -820,8 +832,9 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
         SCANN_TRY(s.lut8.ensure((size_t)max_slots * t.S * 16 + 64));
         SCANN_TRY(s.lut8_meta.ensure((size_t)(max_slots + 4) * 16));
         SCANN_TRY(s.mfma_thr1.ensure((size_t)(max_slots + 4) * 4));
-        SCANN_TRY(s.cand32.ensure((size_t)nq * cap32 * 4));
-        if (t.ah_mode) SCANN_TRY(s.cand32_codes.ensure((size_t)nq * cap32 * (t.S / 8) * 4));   // flat hashers: the survivors' packed codes
+        const uint64_t cap32_al = std::min<uint64_t>(ms2, cap_al * 4 + 16384);   // (allocation; the stride stays cap32)
+        SCANN_TRY(s.cand32.ensure((size_t)nq * cap32_al * 4));
+        if (t.ah_mode) SCANN_TRY(s.cand32_codes.ensure((size_t)nq * cap32_al * (t.S / 8) * 4));   // flat hashers: the survivors' packed codes
         SCANN_TRY(s.cand32_cnt.ensure((size_t)nq * 4));
         w->lut8 = s.lut8.as<int8_t>();
         w->lut8_meta = s.lut8_meta.p;
