@@ -132,7 +132,7 @@ struct scann_hip_index {
 
     // ---- tree-x-hybrid / AH ----
     TxhIndexDev tx{};
-    DevBuf d_centers, d_centers_t, d_leaf_off, d_leaf_gsize, d_leaf_ids, d_codes, d_rows, d_codebook, d_rows8, d_rows8_meta;
+    DevBuf d_centers, d_centers_t, d_leaf_off, d_leaf_gsize, d_leaf_ids, d_codes, d_codes_sp, d_rows, d_codebook, d_rows8, d_rows8_meta;
     std::vector<uint32_t> local_sizes_desc;  // local leaf sizes, descending, prefix-summed
     uint32_t default_P = 0;
     float multiplier = 3.0f;
@@ -497,6 +497,19 @@ int scann::txh_create_checked(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, s
     t.leaf_gsize = ix->d_leaf_gsize.as<uint32_t>();
     t.leaf_ids = ah ? nullptr : ix->d_leaf_ids.as<uint32_t>();
     t.codes = exact ? nullptr : ix->d_codes.as<uint32_t>();
+    t.codes_sp = nullptr;
+    // operand planes of the sparse-MFMA prefilter (txh.hip K6e): a second copy of the 4-bit codes, S/2 .. 2 S bytes
+    // per point.  SCANN_HIP_SMFMAC=0: not built, the dense integer-MFMA prefilter is used instead.
+    {
+        const char *e = std::getenv("SCANN_HIP_SMFMAC");
+        if (!exact && bits == 4 && !(e && std::atoi(e) == 0)) {
+            if ((s = ix->d_codes_sp.ensure((size_t)n * sp_words(S) * 4)) != SCANN_HIP_OK) return bail(s);
+            if ((s = launch_codes_sp_build(ix->d_codes.as<uint32_t>(), n, S, ix->d_codes_sp.as<uint32_t>(), ix->stream)) != SCANN_HIP_OK)
+                return bail(s);
+            if (hipStreamSynchronize(ix->stream) != hipSuccess) return bail(fail(SCANN_HIP_INTERNAL, "code plane build failed"));
+            t.codes_sp = ix->d_codes_sp.as<uint32_t>();
+        }
+    }
     t.measure = d->distance_measure;
     t.exact_scan = exact ? 1 : 0;
     t.rows = d->data ? ix->d_rows.as<float>() : nullptr;
@@ -801,6 +814,12 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
             if (v == 2) w->mfma = mfma_ok ? 1u : 0u;
             if (v == 3) w->mfma = mfma_ok ? 2u : 0u;
         }
+        // the 32-pair form runs on the 2:4-sparse MFMA when the index holds the operand planes (SCANN_HIP_SMFMAC=0
+        // at this call keeps the dense instruction: tests compare the two)
+        if (w->mfma == 1 && t.codes_sp) {
+            const char *e = std::getenv("SCANN_HIP_SMFMAC");
+            if (!(e && std::atoi(e) == 0)) w->mfma = 3u;
+        }
         if (w->mfma) w->resident = 0u;
     }
     // int8 re-rank filter: lists of a few hundred candidates and more (SCANN_HIP_RERANK_I8_MIN overrides)
@@ -1038,7 +1057,7 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
         SCANN_TRY(txh_launch_search(ix->tx, w, false, stream, sl.primary ? ix->ev0 : nullptr,
                                     sl.primary ? ix->ev1 : nullptr));
         if (sl.primary) ix->timing_valid = ix->timing;
-        if (sl.primary) ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.mfma == 2 ? "adc_mfma16_kernel" : w.mfma ? "adc_mfma_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
+        if (sl.primary) ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.mfma == 2 ? "adc_mfma16_kernel" : w.mfma == 3 ? "adc_smfmac_kernel" : w.mfma ? "adc_mfma_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
         uint32_t counters[CNT_N];
         SCANN_HIP_CHECK(hipMemcpyAsync(counters, w.counters, sizeof(counters), hipMemcpyDeviceToHost,
                                        stream));
@@ -1224,7 +1243,7 @@ int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries,
     SCANN_TRY(txh_launch_search(ix->tx, w, false, st, ix->ev0,
                                 ix->ev1));
     ix->timing_valid = ix->timing;
-    ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.mfma == 2 ? "adc_mfma16_kernel" : w.mfma ? "adc_mfma_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
+    ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.mfma == 2 ? "adc_mfma16_kernel" : w.mfma == 3 ? "adc_smfmac_kernel" : w.mfma ? "adc_mfma_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
     return SCANN_HIP_OK;
 }
 
@@ -1276,7 +1295,7 @@ int scann_hip_txh_search_local_device(scann_hip_index *ix, const float *d_querie
     SCANN_TRY(txh_launch_search(ix->tx, w, true, st, ix->ev0,
                                 ix->ev1));
     ix->timing_valid = ix->timing;
-    ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.mfma == 2 ? "adc_mfma16_kernel" : w.mfma ? "adc_mfma_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
+    ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.mfma == 2 ? "adc_mfma16_kernel" : w.mfma == 3 ? "adc_smfmac_kernel" : w.mfma ? "adc_mfma_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
     return SCANN_HIP_OK;
 }
 

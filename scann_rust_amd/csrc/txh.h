@@ -93,6 +93,8 @@ struct TxhIndexDev {
     const uint32_t *leaf_gsize;   // [L] global leaf sizes (== local when unsharded)
     const uint32_t *leaf_ids;     // [n_local] datapoint index of CSR row; nullptr = identity
     const uint32_t *codes;        // [n_local][nw] packed 4-bit codes, 8 subspaces per word
+    const uint32_t *codes_sp;     // [n_local][sp_words(S)] the same codes as operand planes of the 2:4-sparse MFMA prefilter
+                                  // (txh.hip K6e; 4-bit codes only), or nullptr
     const float *rows;            // re-rank rows; CSR order if rows_csr else by datapoint idx
     const int8_t *rows8;          // the same rows as int8 (per-row scale) for the re-rank filter, or nullptr
     int rows8_fmt;                // 0 = int8, 1 = the reference's FP8 E4M3 codes (quantization/fp8.rs)
@@ -140,7 +142,8 @@ struct TxhWork {
     uint32_t small_max_leaf;   // longest local leaf (grid of the small scan)
     uint32_t use_i8;           // int8 row filter in front of the exact re-rank (needs ix.rows8)
     uint32_t *rr_lb, *rr_ub;   // [nq][m] ordered lower / upper bounds of the candidates' exact distances
-    uint32_t mfma;             // integer-MFMA prefilter + exact refine instead of the f32 LDS-gather scan
+    uint32_t mfma;             // integer-MFMA prefilter + exact refine instead of the f32 LDS-gather scan:
+                               // 1 = 32-pair dense tiles, 2 = 16-pair dense tiles, 3 = 32-pair tiles on the sparse MFMA
     int8_t *lut8;              // [max_slots][S][16] quantised tables (value - 128)
     void *lut8_meta;           // [max_slots] {f64 bias_sum, f64 scale}
     int *mfma_thr1;            // [max_slots] integer pass bound + 1 of every pair slot
@@ -223,6 +226,11 @@ int launch_rows_i8_build(const float *d_rows, uint64_t n, uint32_t dim, uint32_t
 
 int launch_lut16_quantize(const float *d_tables, uint32_t S, uint8_t *d_lut8, float *d_bias_mult,
                           hipStream_t stream);
+
+// Operand planes of the sparse-MFMA prefilter (txh.hip K6e) from the packed 4-bit codes: words per point and the
+// build kernel.
+static inline uint32_t sp_words(uint32_t S) { return 4u * ((((S - 4u) / 4u + 1u) + 7u) / 8u); }
+int launch_codes_sp_build(const uint32_t *d_codes, uint64_t n, uint32_t S, uint32_t *d_codes_sp, hipStream_t stream);
 
 int launch_encode(const float *d_codebook, uint32_t S, uint32_t K, uint32_t dsub,
                   const float *d_rows, uint64_t n, uint32_t stride, const float *d_centers,

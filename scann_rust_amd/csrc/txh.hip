@@ -1137,14 +1137,25 @@ __device__ __forceinline__ int mfma_pass_bound(uint32_t S, uint32_t pq, uint64_t
     return thr + 1;
 }
 
+// fold != 0 (adc_smfmac_kernel): the pass bound is folded INTO the tables, so that a point passes iff its integer sum
+// is negative (the sparse MFMA accumulates in place: there is no free zero / bound operand, and the sign test is one
+// vector instruction per result instead of two).  With qmax = the largest quantised sum a passing point can have (as
+// in mfma_pass_bound), D = 128 S - 1 - qmax >= 0 is spread over the subspaces, d_s = D / S (+ 1 for the first D % S),
+// and the entries are e = min(127, q - 128 + d_s): sum(q - 128 + d_s) = sum q - qmax - 1 < 0 <=> sum q <= qmax; the
+// clamp at 127 only lowers sums (more points pass, never fewer) and d_s >= 0 means no entry is clamped from below.
+// A bound with qmax > 128 S - 1 (more than half of the table range: a very loose filter) gets a coarser scale first,
+// sc' = (T' - bias) / (127.5 S - 3): every entry still satisfies |v - (mn_s + sc' q)| <= sc' (0.5 + 1e-9), q <= 255.
+// All-pass pairs (no bound, unquantisable table) store -128 everywhere, padding slots of a quad and bounds no point
+// can meet store 127 (sums >= 0).
 __global__ __launch_bounds__(256) void lut8_build_kernel(uint32_t S, const float *__restrict__ lutq,
                                                         const uint32_t *__restrict__ counters,
                                                         int8_t *__restrict__ lut8, Lut8Meta *__restrict__ meta,
                                                         const uint32_t *__restrict__ pair_q,
-                                                        const uint64_t *__restrict__ pair_thr, int *__restrict__ thr1) {
+                                                        const uint64_t *__restrict__ pair_thr, int *__restrict__ thr1,
+                                                        int fold) {
     __shared__ float s_min[4][64], s_rng[4][64];
     __shared__ double s_scale[4];
-    __shared__ int s_bad[4];
+    __shared__ int s_bad[4], s_mode[4], s_dbase[4], s_drem[4];   // fold: 0 = quantise, 1 = all pass, 2 = none pass
     const uint32_t quad = blockIdx.x, tid = threadIdx.x;
     if (quad >= counters[CNT_TOTAL_QUADS]) return;
     const float4 *src = reinterpret_cast<const float4 *>(lutq) + (size_t)quad * S * 16;
@@ -1176,15 +1187,47 @@ __global__ __launch_bounds__(256) void lut8_build_kernel(uint32_t S, const float
             bias += (double)s_min[tid][j];
             r = fmaxf(r, s_rng[tid][j]);
         }
-        const double sc = (s_bad[tid] || !(r > 0.0f)) ? 0.0 : (double)r / 255.0;
+        double sc = (s_bad[tid] || !(r > 0.0f)) ? 0.0 : (double)r / 255.0;
+        const size_t slot = (size_t)quad * 4 + tid;
+        if (fold) {
+            int mode = 1, dbase = 0, drem = 0;
+            const uint64_t T = pair_thr[slot];
+            if (pair_q[slot] == kInvalid) {
+                mode = 2;
+            } else if (T != SCANN_KEY_MAX && sc > 0.0) {
+                const double Tf = (double)ordered_to_f32((uint32_t)(T >> 32));
+                const double tq = Tf * (1.0 + (double)S * 1.1920928955078125e-07) - bias;
+                const double lim = 128.0 * (double)S - 1.0;
+                if (tq < 3.0e38) {   // (false for a NaN bound: everything passes)
+                    double qmax = floor(tq / sc + 0.5 * (double)S + 1.0);
+                    if (qmax > lim) {
+                        const double sc2 = tq / (lim - 0.5 * (double)S - 2.0) * (1.0 + 1e-12);
+                        sc = sc2 > sc ? sc2 : sc;
+                        qmax = floor(tq / sc + 0.5 * (double)S + 1.0);
+                    }
+                    if (qmax < 0.0) {
+                        mode = 2;
+                    } else if (qmax <= lim) {
+                        const int delta = (int)(lim - qmax);
+                        mode = 0;
+                        dbase = delta / (int)S;
+                        drem = delta % (int)S;
+                    }
+                }
+            }
+            s_mode[tid] = mode;
+            s_dbase[tid] = dbase;
+            s_drem[tid] = drem;
+            thr1[slot] = 0;
+        } else {
+            // (the pair's pass bound right away: the filter bounds are known by now -- one launch less)
+            thr1[slot] = mfma_pass_bound(S, pair_q[slot], pair_thr[slot], bias, sc);
+        }
         s_scale[tid] = sc;
         Lut8Meta m;
         m.bias_sum = bias;
         m.scale = sc;
-        meta[(size_t)quad * 4 + tid] = m;
-        // (the pair's pass bound right away: the filter bounds are known by now -- one launch less)
-        const size_t slot = (size_t)quad * 4 + tid;
-        thr1[slot] = mfma_pass_bound(S, pair_q[slot], pair_thr[slot], bias, sc);
+        meta[slot] = m;
     }
     __syncthreads();
     if (sub < S) {
@@ -1198,7 +1241,13 @@ __global__ __launch_bounds__(256) void lut8_build_kernel(uint32_t S, const float
                 q = (int)floor(t + 0.5);
                 q = q < 0 ? 0 : (q > 255 ? 255 : q);
             }
-            w[c >> 2] |= (uint32_t)((q - 128) & 0xFF) << (8 * (c & 3));
+            int e = q - 128;
+            if (fold) {
+                const int mode = s_mode[p];
+                e += s_dbase[p] + ((int)sub < s_drem[p] ? 1 : 0);
+                e = mode == 1 ? -128 : mode == 2 ? 127 : (e > 127 ? 127 : e);
+            }
+            w[c >> 2] |= (uint32_t)(e & 0xFF) << (8 * (c & 3));
         }
         *reinterpret_cast<uint4 *>(lut8 + (((size_t)quad * 4 + p) * S + sub) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     }
@@ -1411,6 +1460,303 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
         };
         // (tile 0 is peeled: inside the loop t >= 1 is known, so the compiler keeps the mask build between
         // the MFMAs in BOTH instances instead of sinking it below a `t == 0` branch)
+        v16i accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA;
+        step(accA, accB, 0u);
+        for (uint32_t tl = 1; tl <= ntile; tl += 2) {
+            step(accB, accA, tl);
+            if (tl + 1 <= ntile) step(accA, accB, tl + 1);
+        }
+        flush(true);
+        tile = __builtin_amdgcn_readfirstlane(next_tile);
+    }
+}
+
+// =====================================================================================
+// K6e: the 32-pair prefilter on the 2:4 STRUCTURED-SPARSE MFMA (v_smfmac_i32_32x32x64_i8).
+//
+// A one-hot row has one non-zero per 16 K-elements, so it satisfies 2:4 sparsity by construction: the
+// sparse instruction multiplies a COMPRESSED A (two values per group of four K-elements + a 2-bit position
+// each) with a dense 64-deep B in the time the dense instruction takes for K = 32 -- four subspaces per MFMA
+// slot instead of two (tools/micro/smfmac_probe.hip: 21.5-26 ns against 19.4-25 ns per instruction per SIMD).
+// Operand layout (probed on the hardware, same tool): A lane (m, ha) holds row m; its compressed byte b (value slot
+// b & 1 of group (b >> 1) & 3 of half b >> 3) with position i multiplies B lane (n, hb = b >> 3), byte 16 ha + 4
+// ((b >> 1) & 3) + i; the selection is a plain mux (equal or descending positions of a group's two values work).
+// Sparse MFMA kt therefore covers subspaces s0 .. s0 + 3 (s0 = 4 + 4 kt): B lane (n, hb) = the 32 table bytes of
+// subspaces s0 + 2 hb, s0 + 2 hb + 1 of pair n (contiguous in lut8), A lane (m, ha) = the codes ca = code[s0 + ha]
+// (bytes 0..7) and cb = code[s0 + 2 + ha] (bytes 8..15) of point m: value 1 at byte 2 (ca >> 2) / 8 + 2 (cb >> 2),
+// positions (ca & 3) / (cb & 3) replicated over the half's four groups (the other groups hold zeros).
+//
+// The sparse instruction accumulates in place (no C operand), so a tile starts with two DENSE MFMAs (subspaces 0..3,
+// C = the inline constant 0: no accumulator clearing on the vector pipe) followed by (S - 4) / 4 sparse ones: 9 MFMA
+// slots per 32 x 32 tile at S = 32 instead of 16.  Both A operands come from 16-row LDS tables (conflict-free
+// ds_read_b128 / ds_read_b32: lanes with equal rows broadcast); their row numbers are precomputed per point at index
+// creation as two nibble PLANES (codes_sp: V = (ca >> 2) | (cb >> 2) << 2 picks the value row, N = (ca & 3) |
+// (cb & 3) << 2 the position word; the last nibble of each plane is the raw code of dense MFMA 0 / 1), so a tile
+// costs 7 unpack instructions + 2 byte extractions per sparse MFMA.  The pass bound lives in the tables
+// (lut8_build_kernel, fold): a point passes iff its sum is negative -- one v_alignbit per result.
+// Items, survivor staging, flush and lists as in adc_mfma_kernel; candidate lists identical (the refine is exact).
+// =====================================================================================
+template <int S_>
+struct SpLayout {
+    static constexpr int NS = (S_ - 4) / 4;      // sparse MFMAs per tile
+    static constexpr int NIB = NS + 1;           // nibbles per plane (the last one: a dense MFMA's raw code)
+    static constexpr int NWP = (NIB + 7) / 8;    // words per plane
+    static constexpr int SPW = 4 * NWP;          // words per point: [ha][plane V, N][word]
+};
+
+__global__ __launch_bounds__(256) void codes_sp_build_kernel(const uint32_t *__restrict__ codes, uint64_t n, uint32_t S,
+                                                            uint32_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t nw = S / 8, ns = (S - 4) / 4, nwp = (ns + 1 + 7) / 8;
+    const uint32_t *w = codes + i * nw;
+    auto code = [&](uint32_t sub) { return (w[sub >> 3] >> (4 * (sub & 7u))) & 15u; };
+    uint32_t *o = out + i * 4 * nwp;
+    for (uint32_t ha = 0; ha < 2; ++ha)
+        for (uint32_t wi = 0; wi < nwp; ++wi) {
+            uint32_t v = 0, nn = 0;
+            for (uint32_t j = 8 * wi; j < 8 * wi + 8 && j <= ns; ++j) {
+                uint32_t vn, nb;
+                if (j < ns) {
+                    const uint32_t ca = code(4 + 4 * j + ha), cb = code(4 + 4 * j + 2 + ha);
+                    vn = (ca >> 2) | ((cb >> 2) << 2);
+                    nb = (ca & 3u) | ((cb & 3u) << 2);
+                } else {   // dense MFMA 0 scores subspace ha, dense MFMA 1 subspace 2 + ha
+                    vn = code(ha);
+                    nb = code(2 + ha);
+                }
+                v |= vn << (4 * (j & 7u));
+                nn |= nb << (4 * (j & 7u));
+            }
+            o[(ha * 2 + 0) * nwp + wi] = v;
+            o[(ha * 2 + 1) * nwp + wi] = nn;
+        }
+}
+
+template <int S_>
+__global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) void adc_smfmac_kernel(TxhIndexDev ix, MfmaArgs a) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef int v8i __attribute__((ext_vector_type(8)));
+    typedef int v16i __attribute__((ext_vector_type(16)));
+    typedef SpLayout<S_> SP;
+    constexpr int S = S_, NS = SP::NS, KT = NS + 2, NW = S / 8, NWP = SP::NWP, SPW = SP::SPW;
+    __shared__ __attribute__((aligned(16))) uint32_t s_ident[64];   // dense A: 16 one-hot rows of 16 bytes
+    __shared__ __attribute__((aligned(16))) uint32_t s_vtab[64];    // sparse A values: row V = (ga | gb << 2)
+    __shared__ uint32_t s_ntab[16];                                 // sparse A positions: word N = (ia | ib << 2)
+    __shared__ uint32_t s_stage[kMfmaWaves][32][kMfmaStage];
+    __shared__ uint32_t s_cnt[kMfmaWaves][32];
+    __shared__ uint32_t s_fpre[kMfmaWaves][32], s_fq[kMfmaWaves][32], s_fgb[kMfmaWaves][32], s_fvb[kMfmaWaves][32];   // flush: per pair
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t col = lane & 31u, h = lane >> 5;
+    if (tid < 64) {
+        const uint32_t c = tid >> 2, wsel = tid & 3u;
+        s_ident[tid] = (wsel == (c >> 2)) ? (1u << (8 * (c & 3u))) : 0u;
+        // row V, word wsel: words 0, 1 = bytes 0..7 (group ga = V & 3: value 1 at byte 2 ga), words 2, 3 = bytes 8..15 (gb = V >> 2)
+        const uint32_t g = wsel < 2 ? (c & 3u) : (c >> 2);
+        s_vtab[tid] = ((g >> 1) == (wsel & 1u)) ? (1u << (16 * (g & 1u))) : 0u;
+        if (tid < 16) s_ntab[tid] = (tid & 3u) * 0x1111u | (tid >> 2) * 0x11110000u;
+    }
+    __syncthreads();
+    const uint32_t total_tiles = a.counters[CNT_TOTAL_TILES];
+    const char *ident = reinterpret_cast<const char *>(s_ident);
+    const char *vtab = reinterpret_cast<const char *>(s_vtab);
+    const char *ntab = reinterpret_cast<const char *>(s_ntab);
+
+    uint32_t tile = 0;
+    if (lane == 0) tile = grab_tile(a.counters + CNT_XQ, total_tiles);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    while (tile != kInvalid) {
+        uint32_t next_tile = 0;
+        if (lane == 0) next_tile = grab_tile(a.counters + CNT_XQ, total_tiles);
+        uint32_t lo = 0, hi = ix.L;            // leaf = largest l with tile_off[l] <= tile
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (uniform_load(a.tile_off + mid) <= tile) lo = mid; else hi = mid;
+        }
+        const uint32_t leaf = lo;
+        const uint32_t lb = uniform_load(ix.leaf_off + leaf);
+        const uint32_t size = uniform_load(ix.leaf_off + leaf + 1) - lb;
+        const uint32_t nranges = (size + kMfmaRange - 1) / kMfmaRange;
+        const uint32_t local = tile - uniform_load(a.tile_off + leaf);
+        const uint32_t range = local % nranges, pt = local / nranges;
+        const uint32_t slot0 = uniform_load(a.pair_off + leaf);
+        const uint32_t slot_end = uniform_load(a.pair_off + leaf + 1);
+        const uint32_t c0 = range * kMfmaRange;
+        const uint32_t npts = min(kMfmaRange, size - c0);
+
+        // this lane's pair (column): tables (the pass bound is folded into them), key base
+        const uint32_t slot = slot0 + pt * 32u + col;
+        const bool pair_ok = slot < slot_end;
+        const uint32_t pq = pair_ok ? a.pair_q[slot] : kInvalid;
+        const uint32_t vb = pair_ok ? a.pair_vbase[slot] : 0u;
+        v4i bd[2];
+        v8i bs[NS];
+        {
+            const int8_t *bsrc = a.lut8 + (size_t)(pair_ok ? slot : slot0) * S * 16;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) bd[d] = *reinterpret_cast<const v4i *>(bsrc + (size_t)(2 * d + h) * 16);
+#pragma unroll
+            for (int kt = 0; kt < NS; ++kt) {
+                const v4i x0 = *reinterpret_cast<const v4i *>(bsrc + (size_t)(4 + 4 * kt + 2 * h) * 16);
+                const v4i x1 = *reinterpret_cast<const v4i *>(bsrc + (size_t)(4 + 4 * kt + 2 * h) * 16 + 16);
+                bs[kt] = v8i{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            }
+            if (!pair_ok) {   // padding columns: every entry 127, sums stay positive (nothing passes)
+                const int k7 = 0x7F7F7F7F;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) bd[d] = v4i{k7, k7, k7, k7};
+#pragma unroll
+                for (int kt = 0; kt < NS; ++kt) bs[kt] = v8i{k7, k7, k7, k7, k7, k7, k7, k7};
+            }
+        }
+        if (lane < 32) s_cnt[wave][lane] = 0;
+        // (s_cnt / s_stage are private to the wave: no workgroup barrier anywhere in this loop)
+
+        const uint32_t ntile = (npts + 31u) >> 5;
+        uint32_t wv[NWP], wn[NWP];
+        auto load_planes = [&](uint32_t j) {
+            const uint32_t *src = ix.codes_sp + (size_t)(lb + (j < size ? j : 0u)) * SPW + h * 2u * NWP;
+            if constexpr (NWP == 1) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(src);
+                wv[0] = v.x; wn[0] = v.y;
+            } else {
+                const uint4 v = *reinterpret_cast<const uint4 *>(src);
+                wv[0] = v.x; wv[1] = v.y; wn[0] = v.z; wn[1] = v.w;
+            }
+        };
+        static_assert(NWP == 1 || NWP == 2, "plane words");
+        load_planes(c0 + col);
+        auto flush = [&](bool all) {
+            uint32_t n = 0, gbase = 0;
+            if (lane < 32) {
+                n = min(s_cnt[wave][lane], kMfmaStage);
+                if (!all && n + 32u <= kMfmaStage) n = 0;
+                if (n) {
+                    gbase = atomicAdd(&a.cand32_cnt[pq], n);
+                    s_cnt[wave][lane] = 0;
+                }
+            }
+            uint32_t incl = n;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+                if ((int)lane >= o) incl += up;
+            }
+            const uint32_t total = (uint32_t)__shfl((int)incl, 31);
+            if (total == 0) return;
+            if (lane < 32) {
+                s_fpre[wave][lane] = incl - n;
+                s_fq[wave][lane] = pq == kInvalid ? 0u : pq;
+                s_fgb[wave][lane] = gbase;
+                s_fvb[wave][lane] = vb;
+            }
+            for (uint32_t e = lane; e < total; e += 64u) {
+                uint32_t c = 0;
+#pragma unroll
+                for (uint32_t stp = 16; stp; stp >>= 1)
+                    if (s_fpre[wave][c + stp] <= e) c += stp;
+                const uint32_t idx = e - s_fpre[wave][c];
+                const uint32_t j = s_stage[wave][c][idx];
+                const uint32_t dst = s_fgb[wave][c] + idx;
+                if (dst < a.cap32) {
+                    const size_t o = (size_t)s_fq[wave][c] * a.cap32 + dst;
+                    a.cand32[o] = s_fvb[wave][c] + j;
+                    if (a.cand32_codes) {   // (wave-uniform)
+                        uint32_t cw[NW];
+                        Codec<S, 4>::load_words(ix.codes + (size_t)(lb + j) * NW, cw);
+                        Codec<S, 4>::store_words(a.cand32_codes + o * NW, cw);
+                    }
+                }
+            }
+        };
+        auto step = [&](v16i &accN, const v16i &accO, uint32_t t) {
+            // planes -> LDS byte offsets: nibble j of the V plane times 16 (a 16-byte row), of the N plane times 4
+            uint32_t ve[NWP], vo[NWP], ne[NWP], no[NWP];
+#pragma unroll
+            for (int wi = 0; wi < NWP; ++wi) {
+                ve[wi] = wv[wi] & 0xF0F0F0F0u;
+                vo[wi] = (wv[wi] << 4) & 0xF0F0F0F0u;
+                ne[wi] = (wn[wi] >> 2) & 0x3C3C3C3Cu;
+                no[wi] = (wn[wi] << 2) & 0x3C3C3C3Cu;
+                // (opaque to the optimiser: it would otherwise re-derive every offset from the plane word with a
+                // shift and a mask of its own -- two vector instructions per offset instead of one byte extraction)
+                asm volatile("" : "+v"(ve[wi]), "+v"(vo[wi]), "+v"(ne[wi]), "+v"(no[wi]));
+            }
+            const uint32_t d1off = ((wn[NS >> 3] >> (4 * (NS & 7))) & 15u) << 4;   // dense MFMA 1: raw code, N plane
+            if (t + 1 < ntile) load_planes(c0 + (t + 1) * 32u + col);
+            auto voff = [&](int j) { return (((j & 1) ? ve[j >> 3] : vo[j >> 3]) >> (8 * ((j & 7) >> 1))) & 0xFFu; };
+            auto noff = [&](int j) { return (((j & 1) ? ne[j >> 3] : no[j >> 3]) >> (8 * ((j & 7) >> 1))) & 0xFFu; };
+            // operands of MFMA oi: 0, 1 dense (identity rows), 2 .. sparse (value row + position word)
+            constexpr int D = kMfmaDepth < KT ? kMfmaDepth : KT;
+            v4i av[D + 1];
+            int iv[D + 1];
+            auto fetch = [&](int oi, int sl) {
+                if (oi == 0) {
+                    av[sl] = *reinterpret_cast<const v4i *>(ident + voff(NS));
+                } else if (oi == 1) {
+                    av[sl] = *reinterpret_cast<const v4i *>(ident + d1off);
+                } else {
+                    av[sl] = *reinterpret_cast<const v4i *>(vtab + voff(oi - 2));
+                    iv[sl] = *reinterpret_cast<const int *>(ntab + noff(oi - 2));
+                }
+            };
+#pragma unroll
+            for (int oi = 0; oi < D; ++oi) fetch(oi, oi);
+            // lane (col, h), register r: point row (r & 3) + 8 * (r >> 2) + 4 * h of the tile; result r's sign
+            // (negative = passes) ends up at bit 15 - r of the mask
+            uint32_t m16 = 0;
+            __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+            for (int oi = 0; oi < KT; ++oi) {
+                if (oi + D < KT) fetch(oi + D, (oi + D) % (D + 1));
+                if (oi == 0)
+                    accN = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[0], bd[0], v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+                else if (oi == 1)
+                    accN = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[1 % (D + 1)], bd[1], accN, 0, 0, 0);
+                else
+                    accN = __builtin_amdgcn_smfmac_i32_32x32x64_i8(av[oi % (D + 1)], bs[oi - 2], accN, iv[oi % (D + 1)], 0, 0);
+#pragma unroll
+                for (int r = oi * 16 / KT; r < (oi + 1) * 16 / KT; ++r)
+                    m16 = __builtin_amdgcn_alignbit(m16, (uint32_t)accO[r], 31);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (t == 0) return;                // nothing before the first tile (wave-uniform)
+            const uint32_t base = c0 + (t - 1) * 32u + 4u * h;
+            if (t == ntile && (npts & 31u)) {  // partial last tile: rows past the leaf's end are padding
+                uint32_t okm = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    okm |= (base + (uint32_t)((r & 3) + 8 * (r >> 2)) < size ? 1u : 0u) << (15 - r);
+                m16 &= okm;
+            }
+            bool risk = false;                 // this lane's pair could overflow its stage in the next tile
+            if (m16) {
+                uint32_t sl = atomicAdd(&s_cnt[wave][col], (uint32_t)__popc(m16));   // one LDS atomic per lane
+                do {
+                    const uint32_t r = 15u - ((uint32_t)__ffs((int)m16) - 1u);
+                    m16 &= m16 - 1u;
+                    const uint32_t j = base + (r & 3u) + ((r >> 2) << 3);
+                    if (sl < kMfmaStage) {
+                        s_stage[wave][col][sl] = j;
+                    } else {   // stage full: direct (slow) append
+                        const uint32_t pos = atomicAdd(&a.cand32_cnt[pq], 1u);
+                        if (pos < a.cap32) {
+                            const size_t o = (size_t)pq * a.cap32 + pos;
+                            a.cand32[o] = vb + j;
+                            if (a.cand32_codes) {
+                                uint32_t cw[NW];
+                                Codec<S, 4>::load_words(ix.codes + (size_t)(lb + j) * NW, cw);
+                                Codec<S, 4>::store_words(a.cand32_codes + o * NW, cw);
+                            }
+                        }
+                    }
+                    ++sl;
+                } while (m16);
+                risk = sl + 32u > kMfmaStage;   // (the lane that appended last to a pair saw its full count)
+            }
+            if (__any(risk)) flush(false);
+        };
         v16i accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA;
         step(accA, accB, 0u);
         for (uint32_t tl = 1; tl <= ntile; tl += 2) {
@@ -3977,7 +4323,7 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
         if (w.mfma) {
             hipLaunchKernelGGL(lut8_build_kernel, dim3(w.max_quads), dim3(256), 0, st, (uint32_t)C::S, w.lutq,
                                w.counters, w.lut8, reinterpret_cast<Lut8Meta *>(w.lut8_meta), w.pair_q, w.pair_thr,
-                               w.mfma_thr1);
+                               w.mfma_thr1, w.mfma == 3 ? 1 : 0);
             LAUNCH_CHECK();
             // The survivors' codes travel with their positions for flat hashers: their ~12 k survivors per query
             // are spread over the whole code array (random 16-byte gathers from 16 MB: refine 145 -> 65 us at
@@ -3996,6 +4342,8 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
             if (const char *e = std::getenv("SCANN_HIP_MFMA_WGS")) mwgs = (uint32_t)std::max(1, std::atoi(e));
             if (w.mfma == 2)
                 hipLaunchKernelGGL(adc_mfma16_kernel<C::S>, dim3((uint32_t)cus * mwgs), dim3(kMfmaWaves * 64), 0, st, ix, ma);
+            else if (w.mfma == 3)
+                hipLaunchKernelGGL(adc_smfmac_kernel<C::S>, dim3((uint32_t)cus * mwgs), dim3(kMfmaWaves * 64), 0, st, ix, ma);
             else
                 hipLaunchKernelGGL(adc_mfma_kernel<C::S>, dim3((uint32_t)cus * mwgs), dim3(kMfmaWaves * 64), 0, st, ix, ma);
             LAUNCH_CHECK();
@@ -4634,6 +4982,13 @@ int launch_lut16_quantize(const float *d_tables, uint32_t S, uint8_t *d_lut8, fl
                           hipStream_t st) {
     if (S == 0) return SCANN_HIP_OK;
     hipLaunchKernelGGL(lut16_quantize_kernel, dim3(1), dim3(256), 0, st, d_tables, S, d_lut8, d_bias_mult);
+    LAUNCH_CHECK();
+    return SCANN_HIP_OK;
+}
+
+int launch_codes_sp_build(const uint32_t *d_codes, uint64_t n, uint32_t S, uint32_t *d_codes_sp, hipStream_t st) {
+    if (n == 0) return SCANN_HIP_OK;
+    hipLaunchKernelGGL(codes_sp_build_kernel, dim3((uint32_t)ceil_div_u64(n, 256)), dim3(256), 0, st, d_codes, n, S, d_codes_sp);
     LAUNCH_CHECK();
     return SCANN_HIP_OK;
 }

@@ -1136,7 +1136,8 @@ def test_scan_paths_agree(mode, monkeypatch):
     got = {}
     for name, env in (("chunk", {"SCANN_HIP_MFMA": "0", "SCANN_HIP_RESIDENT": "0"}),
                       ("resident", {"SCANN_HIP_MFMA": "0", "SCANN_HIP_RESIDENT": "2"}),
-                      ("mfma", {"SCANN_HIP_MFMA": "2"}),          # 32-pair tiles (v_mfma_i32_32x32x32_i8)
+                      ("smfmac", {"SCANN_HIP_MFMA": "2"}),        # 32-pair tiles on v_smfmac_i32_32x32x64_i8 (default form)
+                      ("mfma", {"SCANN_HIP_MFMA": "2", "SCANN_HIP_SMFMAC": "0"}),   # 32-pair tiles (v_mfma_i32_32x32x32_i8)
                       ("mfma16", {"SCANN_HIP_MFMA": "3"})):       # 16-pair tiles (v_mfma_i32_16x16x64_i8)
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
@@ -1145,8 +1146,22 @@ def test_scan_paths_agree(mode, monkeypatch):
         o.allow_bitmap, o.allow_bitmap_bits = None, 0
         got[name] = (plain, filt)
         monkeypatch.delenv("SCANN_HIP_RESIDENT", raising=False)
+        monkeypatch.delenv("SCANN_HIP_SMFMAC", raising=False)
     ref_plain, ref_filt = got["chunk"]
-    for name in ("resident", "mfma", "mfma16"):
+    # the reference path against the oracle (every other path is then compared with it bit for bit)
+    for i in range(0, q.shape[0], 5):
+        cnt_i = ref_plain[2][i]
+        if mode == "ah":
+            wi, wd = orc.ah_search_with_reordering(ix["codebook"], ix["codes"], data, stride, q[i], 10, o.pre_reorder_k)
+            assert cnt_i == wi.size
+            H.assert_topk_equal_up_to_ties(ref_plain[0][i, :cnt_i], ref_plain[1][i, :cnt_i], wi, wd, what="oracle q%d" % i)
+        else:
+            tok, tokd, ci, cd, cc = ref_plain[3]
+            oix = orc.TxhIndex(data, stride, kw["dim"], ix["centers"], ix["leaf_off"], ix["leaf_ids"], ix["codebook"],
+                               ix["codes"], partitions_to_search=6, pre_reorder_multiplier=25.0)   # m = 250
+            H.check_txh_query(oix, q[i], 10, ref_plain[0][i, :cnt_i], ref_plain[1][i, :cnt_i], tok[i], tokd[i],
+                              ci[i, :cc[i]], cd[i, :cc[i]], what="oracle q%d" % i)
+    for name in ("resident", "smfmac", "mfma", "mfma16"):
         plain, filt = got[name]
         assert np.array_equal(plain[0], ref_plain[0]) and np.array_equal(bits(plain[1]), bits(ref_plain[1])), name
         assert np.array_equal(plain[2], ref_plain[2]), name
