@@ -60,7 +60,7 @@ def log(*a):
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--steps", type=int, default=500)
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--workload", default=None, choices=["ah", "bf_dot", "txh"],
                    help="default: ah at N = 1, the leaf-sharded Tree-X-Hybrid at N > 1")
@@ -135,6 +135,11 @@ def lib_sha256(hip):
         for blk in iter(lambda: f.read(1 << 20), b""):
             h.update(blk)
     return h.hexdigest()
+
+
+def src_sha256():
+    from scann_rust_amd import build as hip_build
+    return hip_build.src_sha256()
 
 
 def cpu_model():
@@ -291,12 +296,13 @@ def build_txh_shard(args, torch, dist, hip, device, local_rank, rank, world, str
 # =====================================================================================================
 def traffic_for(hip, workload, kernel_name):
     """PMC-measured HBM bytes per launch from profiles/traffic.json -- only when the entry was recorded
-    for THIS kernel of THIS build of the library (keyed by kernel name + sha256 of libscann_hip.so by
-    tools/prof_refresh.sh); anything else would be a stale constant, so null."""
+    for THIS kernel of THESE sources of the library (keyed by kernel name + sha256 over csrc/, the headers and the
+    compile flags: scann_rust_amd/build.py src_sha256 -- a rebuild in another directory keeps the key, an edit of any
+    kernel drops it); anything else would be a stale constant, so null."""
     tr = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         ent = json.load(open(tr)).get(workload)
-        if isinstance(ent, dict) and ent.get("kernel") == kernel_name and ent.get("lib_sha256") == lib_sha256(hip):
+        if isinstance(ent, dict) and ent.get("kernel") == kernel_name and ent.get("src_sha256") == src_sha256():
             return {"bytes": ent["bytes"], "source": ent.get("source")}
     except Exception:
         pass
@@ -388,27 +394,41 @@ def main():
         # with more than one rank before the driver's scaling run), every rank falls back to the replica
         # layout together and the JSON line says so -- a number with a note instead of a dead run.
         err = ""
-        try:
-            if os.environ.get("SCANN_BENCH_FAIL_COMM"):   # (rehearsal of the fallback)
-                raise RuntimeError("forced by SCANN_BENCH_FAIL_COMM")
-            uid = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
-                uid = torch.frombuffer(bytearray(hip.Comm.unique_id()), dtype=torch.uint8).clone()
-            if nproc > 1:
-                dist.broadcast(uid, 0)
-            # RCCL prints a version banner on STDOUT when the first communicator is created; rank 0's stdout
-            # must carry exactly one JSON line, so the banner is sent to stderr
-            sys.stdout.flush()
-            saved_stdout = os.dup(1)
-            os.dup2(2, 1)
+        # Step 1, every rank the same collectives whatever fails: rank 0 makes the id (or fails to: RCCL not loadable)
+        # and broadcasts [ok, id]; a failed rank 0 still broadcasts, so no peer is left waiting in the broadcast.
+        # SCANN_BENCH_FAIL_COMM rehearses the fallback: "rank0" fails the id on rank 0 only, anything else fails the
+        # communicator on every rank.
+        fail_mode = os.environ.get("SCANN_BENCH_FAIL_COMM", "")
+        msg = torch.zeros(129, dtype=torch.uint8)
+        if rank == 0:
             try:
-                comm = hip.Comm(uid.numpy().tobytes(), rank, nproc, device=local_rank)
-            finally:
+                if fail_mode == "rank0":
+                    raise RuntimeError("forced by SCANN_BENCH_FAIL_COMM=rank0")
+                msg[1:] = torch.frombuffer(bytearray(hip.Comm.unique_id()), dtype=torch.uint8)
+                msg[0] = 1
+            except Exception as e:   # noqa: BLE001
+                err = "%s: %s" % (type(e).__name__, e)
+        if nproc > 1:
+            dist.broadcast(msg, 0)
+        if int(msg[0].item()) == 0:
+            err = err or "rank 0 could not create the RCCL unique id"
+        else:
+            try:
+                if fail_mode and fail_mode != "rank0":
+                    raise RuntimeError("forced by SCANN_BENCH_FAIL_COMM")
+                # RCCL prints a version banner on STDOUT when the first communicator is created; rank 0's stdout
+                # must carry exactly one JSON line, so the banner is sent to stderr
                 sys.stdout.flush()
-                os.dup2(saved_stdout, 1)
-                os.close(saved_stdout)
-        except Exception as e:   # noqa: BLE001 (any failure of the bring-up takes the fallback)
-            err = "%s: %s" % (type(e).__name__, e)
+                saved_stdout = os.dup(1)
+                os.dup2(2, 1)
+                try:
+                    comm = hip.Comm(msg[1:].numpy().tobytes(), rank, nproc, device=local_rank)
+                finally:
+                    sys.stdout.flush()
+                    os.dup2(saved_stdout, 1)
+                    os.close(saved_stdout)
+            except Exception as e:   # noqa: BLE001 (any failure of the bring-up takes the fallback)
+                err = "%s: %s" % (type(e).__name__, e)
         ok = torch.tensor([0 if err else 1], dtype=torch.int32)
         if nproc > 1:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -477,11 +497,16 @@ def main():
              torch.empty((Q,), dtype=torch.int32, device=device)) for _ in range(2)]
     hip.check(L.scann_hip_index_reserve(index.h, Q, k, ctypes.byref(opts)))
 
+    two_streams = os.environ.get("SCANN_BENCH_STREAMS", "2") != "1"
+
     def step(i, qd=None, nq=Q):
         qd = qdev[i % nbatches] if qd is None else qd
         b = i & 1
         oi, od, oc = outs[b]
-        sp = ctypes.c_void_p(streams[b if sharded else 0].cuda_stream)
+        # Two caller streams alternate (SCANN_BENCH_STREAMS=1: one): the library binds a workspace to each caller stream
+        # (scann_hip.h "device entry points and streams"), so step i+1's matrix-core-bound scan runs under step i's
+        # HBM-/latency-bound select + re-rank kernels; sharded: step i's exchange overlaps step i+1's local stage.
+        sp = ctypes.c_void_p(streams[b if two_streams else 0].cuda_stream)
         if sharded:
             # two caller streams alternate: step i's exchange (on the library's stream) overlaps
             # step i+1's local stage (the library orders its own buffers with events)
@@ -495,7 +520,8 @@ def main():
     def device_status():
         if sharded:
             comm.last_status()
-        hip.check(L.scann_hip_index_last_device_status(index.h, ctypes.c_void_p(streams[0].cuda_stream)))
+        for st_ in streams[:2 if two_streams else 1]:
+            hip.check(L.scann_hip_index_last_device_status(index.h, ctypes.c_void_p(st_.cuda_stream)))
 
     def barrier():
         if nproc > 1:
@@ -537,6 +563,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0].item())
+    if elapsed < 0.2:
+        log("WARNING: the timed region is only %.3f s (%d steps); raise --steps for a stable number" % (elapsed, args.steps))
     qps = Q * args.steps * (nproc if replica else 1) / elapsed
     last_out = tuple(t.clone() for t in outs[(args.steps - 1) & 1])   # the sweep below reuses the buffers
     last_q = queries_all[((args.steps - 1) % nbatches) * Q:][:Q]
@@ -704,7 +732,8 @@ def main():
             roof["warning"] = "fraction above 1: the assumed bound is not the binding one"
         line = {
             "metric": METRIC, "value": qps, "unit": "queries/s", "n_gpus": nproc, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "timed_region_s": elapsed,
+            "higher_is_better": True,
             "scaling": "weak" if (replica or nproc == 1) else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name, "n": n * (nproc if sharded else 1), "n_per_gpu": n, "dim": dim,
@@ -724,7 +753,7 @@ def main():
                                       ("1 process/GPU, %d query-parallel replicas of the index (no data-path "
                                        "collective)" % nproc) if replica else "single GPU"},
             "roofline": roof, "algorithmic_hbm": algo, "cpu_baseline": cpu, "batch_sweep": sweep,
-            "secondary": secondary, "lib_sha256": lib_sha256(hip),
+            "secondary": secondary, "lib_sha256": lib_sha256(hip), "src_sha256": src_sha256(),
         }
         if shard_fallback:
             line["config"]["note"] = ("the leaf-sharded layout could not start (%s): replica layout measured "

@@ -23,8 +23,16 @@
  *    tree_x_hybrid/mod.rs:360-363).  Unused slots: idx 0xFFFFFFFF, dist +inf.
  *  - any thread may call search functions concurrently on one handle (Searcher:
  *    Send + Sync, searcher.rs:148): host-side searches draw a stream + workspace from a small
- *    per-handle pool (SCANN_HIP_SEARCH_SLOTS, default 4) and run side by side; the *_device
- *    entry points share the primary slot.  create/destroy need external synchronisation.
+ *    per-handle pool (SCANN_HIP_SEARCH_SLOTS, default 4) and run side by side.  create/destroy need
+ *    external synchronisation.
+ *  - device entry points and streams: every *_device search call works in a per-handle workspace that is
+ *    bound to the CALLER'S STREAM (SCANN_HIP_DEVICE_SLOTS workspaces per handle, default 2, at most 4; the
+ *    first one is the handle's primary workspace).  Calls enqueued on the same stream reuse its workspace in
+ *    stream order; calls on different streams use different workspaces and may overlap on the device -- a
+ *    caller alternating two streams runs batch i+1's scan under batch i's re-rank.  With more streams than
+ *    workspaces the least recently used workspace changes hands, and the library orders the new call behind
+ *    the old stream's last call with an event (correct, no overlap for that pair).
+ *    scann_hip_index_last_device_status(index, stream) reports the calls enqueued on that stream.
  */
 #ifndef SCANN_HIP_H
 #define SCANN_HIP_H

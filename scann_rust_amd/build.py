@@ -21,6 +21,21 @@ CFLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-f
 LDFLAGS = ["-shared", "-fPIC", "--offload-arch=gfx950", "-ldl"]
 
 
+def src_sha256():
+    """sha256 over the library's sources, headers and compile flags: identifies a build of the library whatever
+    directory or machine it was compiled in (the .so itself embeds build paths, so its own hash changes with them)."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(SOURCES) + sorted(os.path.normpath(os.path.join(CSRC, f)) for f in HEADERS)
+    for f in names:
+        p = f if os.path.isabs(f) else os.path.join(CSRC, f)
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(CFLAGS + LDFLAGS).encode())
+    return h.hexdigest()
+
+
 def _sources():
     return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 

@@ -39,22 +39,78 @@ struct scann_hip_ctx {
 
 enum IndexKind { KIND_BF = 1, KIND_TXH = 2 };
 
+// A buffer of a search workspace: a range of the workspace's ARENA (one device allocation, sub-allocated at 256-byte
+// granularity in declaration order).
+struct WsBuf {
+    void *p = nullptr;
+    size_t bytes = 0;   // capacity assigned in the arena
+    size_t need = 0;    // largest size any call has asked for
+    template <typename T>
+    T *as() const { return static_cast<T *>(p); }
+};
+
+// Per-call scratch of the Tree-X-Hybrid pipeline.  Every buffer lives in ONE device allocation: a call first states
+// what it needs (want), then commit() rebuilds the arena if any buffer has to grow -- one hipFree (which waits for the
+// device) + one hipMalloc, every buffer re-placed in declaration order at the largest size seen so far.  Placement
+// is therefore a function of the sizes alone, never of the order in which a handle met its batch sizes and
+// pre_reorder_k values: round 2 allocated every buffer separately, and a workspace that had grown buffer by buffer
+// (free one, allocate it larger, next) left rerank_short_kernel 3x slower than a fresh one of the same sizes.
 struct TxhWorkspace {
-    DevBuf queries, cdist, tokens, token_dists, vbase, leaf_cnt, leaf_cursor, pair_off, tile_off,
+    WsBuf queries, cdist, tokens, token_dists, vbase, leaf_cnt, leaf_cursor, pair_off, tile_off,
         counters, pair_q, pair_leaf, pair_vbase, pair_thr, slot_of, lutq, thr, cand_cnt, cand, cand_key,
         cand_idx, cand_dist, cand_exact, cand_row, cand_count, out_idx, out_dist, out_count, allow,
         sbase, pair_sbase, stile_off, samp, lut8, lut8_meta, cand32, cand32_codes, cand32_cnt, mfma_thr1, rr_lb, rr_ub, small_tickets;
-    // Frees every buffer (hipFree waits for the device): a workspace that has to grow is rebuilt from scratch,
-    // in the order a fresh one is allocated.  Growing buffer by buffer (free one, allocate it larger, next)
-    // left rerank_short_kernel 3x slower than on a fresh workspace of the same sizes -- same instructions, same
-    // bytes fetched (PMC), a placement effect of the interleaved frees and allocations.
+    void *arena = nullptr;
+    size_t arena_bytes = 0;
+    bool dirty = false;
+    uint32_t rebuilds = 0;
+    TxhWorkspace() = default;
+    TxhWorkspace(const TxhWorkspace &) = delete;
+    TxhWorkspace &operator=(const TxhWorkspace &) = delete;
+    ~TxhWorkspace() { release_all(); }
+    template <typename F>
+    void for_each(F f) {
+        WsBuf *all[] = {&queries, &cdist, &tokens, &token_dists, &vbase, &leaf_cnt, &leaf_cursor, &pair_off, &tile_off,
+                        &counters, &pair_q, &pair_leaf, &pair_vbase, &pair_thr, &slot_of, &lutq, &thr, &cand_cnt, &cand,
+                        &cand_key, &cand_idx, &cand_dist, &cand_exact, &cand_row, &cand_count, &out_idx, &out_dist,
+                        &out_count, &allow, &sbase, &pair_sbase, &stile_off, &samp, &lut8, &lut8_meta, &cand32,
+                        &cand32_codes, &cand32_cnt, &mfma_thr1, &rr_lb, &rr_ub, &small_tickets};
+        for (WsBuf *b : all) f(*b);
+    }
+    void want(WsBuf &b, size_t bytes) {
+        if (bytes == 0) bytes = 16;
+        if (bytes > b.need) b.need = bytes;
+        if (b.need > b.bytes) dirty = true;
+    }
+    int commit() {
+        if (!dirty) return SCANN_HIP_OK;
+        size_t total = 0;
+        for_each([&](WsBuf &b) { total += (b.need + 255) & ~(size_t)255; });
+        if (arena) (void)hipFree(arena);   // (waits for the device: kernels of earlier calls may still read it)
+        arena = nullptr;
+        arena_bytes = 0;
+        for_each([&](WsBuf &b) { b.p = nullptr; b.bytes = 0; });
+        SCANN_HIP_CHECK(hipMalloc(&arena, total ? total : 256));
+        arena_bytes = total;
+        size_t off = 0;
+        for_each([&](WsBuf &b) {
+            if (!b.need) return;
+            b.p = static_cast<char *>(arena) + off;
+            b.bytes = (b.need + 255) & ~(size_t)255;
+            off += b.bytes;
+        });
+        // ticket counters of small_fused_kernel: zero between launches (the kernel leaves them zero)
+        if (small_tickets.p) SCANN_HIP_CHECK(hipMemset(small_tickets.p, 0, small_tickets.bytes));
+        dirty = false;
+        ++rebuilds;
+        return SCANN_HIP_OK;
+    }
     void release_all() {
-        DevBuf *all[] = {&queries, &cdist, &tokens, &token_dists, &vbase, &leaf_cnt, &leaf_cursor, &pair_off, &tile_off,
-                         &counters, &pair_q, &pair_leaf, &pair_vbase, &pair_thr, &slot_of, &lutq, &thr, &cand_cnt, &cand,
-                         &cand_key, &cand_idx, &cand_dist, &cand_exact, &cand_row, &cand_count, &out_idx, &out_dist,
-                         &out_count, &allow, &sbase, &pair_sbase, &stile_off, &samp, &lut8, &lut8_meta, &cand32,
-                         &cand32_codes, &cand32_cnt, &mfma_thr1, &rr_lb, &rr_ub, &small_tickets};
-        for (DevBuf *b : all) b->release();
+        if (arena) (void)hipFree(arena);
+        arena = nullptr;
+        arena_bytes = 0;
+        for_each([&](WsBuf &b) { b = WsBuf(); });
+        dirty = false;
     }
 };
 
@@ -139,6 +195,22 @@ struct scann_hip_index {
     TxhWorkspace ws;
     PinBuf pin;               // primary slot's pinned staging
     TxhWork last_work{};
+    // Workspaces of the `_device` entry points, one per CALLER STREAM (scann_hip.h "Device entry points"): slot 0 is
+    // the primary workspace (ws / bfw above), further ones are created on demand.  A slot that changes streams is
+    // ordered behind its previous stream's last call with an event.
+    struct DeviceSlot {
+        hipStream_t key = nullptr;
+        bool used = false, done_valid = false;
+        hipEvent_t done = nullptr;
+        uint64_t tick = 0;
+        TxhWorkspace *ws = nullptr;
+        BfWorkspace *bfw = nullptr;
+        std::unique_ptr<TxhWorkspace> ws_own;
+        std::unique_ptr<BfWorkspace> bfw_own;
+    };
+    static constexpr int kMaxDeviceSlots = 4;
+    DeviceSlot dslots[kMaxDeviceSlots];
+    uint64_t dslot_tick = 0;
     bool sharded = false;     // created with leaf_sizes_global: local leaves are a subset of the global stream
 };
 
@@ -216,6 +288,9 @@ void scann_hip_index_destroy(scann_hip_index *ix) {
         if (ix->evs[i][1]) (void)hipEventDestroy(ix->evs[i][1]);
     }
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    (void)hipDeviceSynchronize();   // device entry points enqueue on caller streams
+    for (auto &ds : ix->dslots)
+        if (ds.done) (void)hipEventDestroy(ds.done);
     for (auto &sl : ix->slots)
         if (sl->stream) {
             (void)hipStreamSynchronize(sl->stream);
@@ -665,19 +740,10 @@ int scann::txh_resolve_m(scann_hip_index *ix, uint32_t k, const scann_hip_search
 
 extern "C" {
 
-// ticket counters of small_fused_kernel: zeroed once, the kernel leaves them zero
-static int ensure_small_tickets(TxhWorkspace &s, uint32_t **out) {
-    if (!s.small_tickets.p) {
-        SCANN_TRY(s.small_tickets.ensure(64 * 4));
-        SCANN_HIP_CHECK(hipMemset(s.small_tickets.p, 0, 64 * 4));
-    }
-    *out = s.small_tickets.as<uint32_t>();
-    return SCANN_HIP_OK;
-}
-
+// allow_bytes: size of an allow-bitmap the caller will copy into s.allow (0 = none)
 static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t nq, const TxhCallParams &p,
                                 bool own_queries, uint32_t q_stride, bool own_outputs,
-                                TxhWork *w) {
+                                TxhWork *w, size_t allow_bytes = 0) {
     const TxhIndexDev &t = ix->tx;
     const uint32_t L = t.L, P = p.P, m = std::max(1u, p.m), k = std::max(1u, p.k);
     const uint64_t max_slots64 = (uint64_t)nq * P + 3ull * L + 4;
@@ -685,53 +751,43 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
         return fail(SCANN_HIP_RESOURCE_EXHAUSTED, "batch x partitions_to_search exceeds the pair table (2^32 slots)");
     const uint32_t max_slots = (uint32_t)max_slots64;
     const uint32_t max_quads = max_slots / 4 + 1;
-    // growth of the per-candidate arrays: rebuild the whole workspace (see TxhWorkspace::release_all)
-    // Batches of 64 queries and more size their per-candidate arrays for the LARGEST pre_reorder_k right away:
-    // a handle that serves growing candidate counts otherwise reallocates its workspace piecemeal, which left
-    // rerank_short_kernel 3x slower (see TxhWorkspace::release_all); batch growth still rebuilds everything.
-    const uint32_t m_al = nq >= 64 ? std::max(m, kMaxPreReorderK) : m;
-    uint64_t cap_al = p.cap;
-    if (!p.no_threshold && m_al > m) {
-        const uint64_t ms_al = std::max<uint64_t>(1, max_stream(ix, P));
-        const uint32_t j_al = sample_rank(m_al, p.st);
-        uint64_t c_al = (uint64_t)((double)j_al + 8.0 * std::sqrt((double)j_al) + 16.0) * p.st + 256;
-        c_al = std::min(std::max<uint64_t>(c_al, m_al), ms_al);
-        cap_al = std::max<uint64_t>(cap_al, c_al);
-    }
-    if (s.cand_key.p && s.cand_key.bytes < (size_t)nq * m_al * 8) s.release_all();
-    if (own_queries) SCANN_TRY(s.queries.ensure((size_t)nq * q_stride * 4));
-    if (!t.ah_mode) SCANN_TRY(s.cdist.ensure((size_t)nq * L * 4));
-    SCANN_TRY(s.tokens.ensure((size_t)nq * P * 4));
-    SCANN_TRY(s.token_dists.ensure((size_t)nq * P * 4));
-    SCANN_TRY(s.vbase.ensure((size_t)nq * (P + 1) * 4));
-    SCANN_TRY(s.sbase.ensure((size_t)nq * (P + 2) * 4));
-    SCANN_TRY(s.pair_sbase.ensure((size_t)max_slots * 4));
-    SCANN_TRY(s.stile_off.ensure((size_t)(L + 1) * 4));
-    SCANN_TRY(s.samp.ensure((size_t)nq * p.scap * 4));
-    SCANN_TRY(s.leaf_cnt.ensure((size_t)L * 4));
-    SCANN_TRY(s.leaf_cursor.ensure((size_t)L * 4));
-    SCANN_TRY(s.pair_off.ensure((size_t)(L + 1) * 4));
-    SCANN_TRY(s.tile_off.ensure((size_t)(L + 1) * 4));
-    SCANN_TRY(s.counters.ensure(CNT_WORDS * 4));
-    SCANN_TRY(s.pair_q.ensure((size_t)max_slots * 4));
-    SCANN_TRY(s.pair_leaf.ensure((size_t)max_slots * 4));
-    SCANN_TRY(s.pair_vbase.ensure((size_t)max_slots * 4));
-    SCANN_TRY(s.pair_thr.ensure((size_t)max_slots * 8));
-    SCANN_TRY(s.slot_of.ensure((size_t)nq * P * 4));
-    SCANN_TRY(s.lutq.ensure((size_t)max_quads * t.S * t.kp * 4 * 4));
-    SCANN_TRY(s.thr.ensure((size_t)nq * 8));
-    SCANN_TRY(s.cand_cnt.ensure((size_t)nq * 4));
-    SCANN_TRY(s.cand.ensure((size_t)nq * cap_al * 8));
-    SCANN_TRY(s.cand_key.ensure((size_t)nq * m_al * 8));
-    SCANN_TRY(s.cand_idx.ensure((size_t)nq * m_al * 4));
-    SCANN_TRY(s.cand_dist.ensure((size_t)nq * m_al * 4));
-    SCANN_TRY(s.cand_exact.ensure((size_t)nq * m_al * 4));
-    SCANN_TRY(s.cand_row.ensure((size_t)nq * m_al * 4));
-    SCANN_TRY(s.cand_count.ensure((size_t)nq * 4));
+    // (per-candidate arrays sized for THIS call's pre_reorder_k; the arena re-places everything when one grows)
+    const uint32_t m_al = m;
+    const uint64_t cap_al = p.cap;
+    if (allow_bytes) s.want(s.allow, allow_bytes);
+    if (own_queries) s.want(s.queries, (size_t)nq * q_stride * 4);
+    if (!t.ah_mode) s.want(s.cdist, (size_t)nq * L * 4);
+    s.want(s.tokens, (size_t)nq * P * 4);
+    s.want(s.token_dists, (size_t)nq * P * 4);
+    s.want(s.vbase, (size_t)nq * (P + 1) * 4);
+    s.want(s.sbase, (size_t)nq * (P + 2) * 4);
+    s.want(s.pair_sbase, (size_t)max_slots * 4);
+    s.want(s.stile_off, (size_t)(L + 1) * 4);
+    s.want(s.samp, (size_t)nq * p.scap * 4);
+    s.want(s.leaf_cnt, (size_t)L * 4);
+    s.want(s.leaf_cursor, (size_t)L * 4);
+    s.want(s.pair_off, (size_t)(L + 1) * 4);
+    s.want(s.tile_off, (size_t)(L + 1) * 4);
+    s.want(s.counters, CNT_WORDS * 4);
+    s.want(s.pair_q, (size_t)max_slots * 4);
+    s.want(s.pair_leaf, (size_t)max_slots * 4);
+    s.want(s.pair_vbase, (size_t)max_slots * 4);
+    s.want(s.pair_thr, (size_t)max_slots * 8);
+    s.want(s.slot_of, (size_t)nq * P * 4);
+    s.want(s.lutq, (size_t)max_quads * t.S * t.kp * 4 * 4);
+    s.want(s.thr, (size_t)nq * 8);
+    s.want(s.cand_cnt, (size_t)nq * 4);
+    s.want(s.cand, (size_t)nq * cap_al * 8);
+    s.want(s.cand_key, (size_t)nq * m_al * 8);
+    s.want(s.cand_idx, (size_t)nq * m_al * 4);
+    s.want(s.cand_dist, (size_t)nq * m_al * 4);
+    s.want(s.cand_exact, (size_t)nq * m_al * 4);
+    s.want(s.cand_row, (size_t)nq * m_al * 4);
+    s.want(s.cand_count, (size_t)nq * 4);
     if (own_outputs) {
-        SCANN_TRY(s.out_idx.ensure((size_t)nq * k * 4));
-        SCANN_TRY(s.out_dist.ensure((size_t)nq * k * 4));
-        SCANN_TRY(s.out_count.ensure((size_t)nq * 4));
+        s.want(s.out_idx, (size_t)nq * k * 4);
+        s.want(s.out_dist, (size_t)nq * k * 4);
+        s.want(s.out_count, (size_t)nq * 4);
     }
     w->nq = nq;
     w->q_stride = q_stride;
@@ -745,16 +801,10 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
     w->small_done = nullptr;
     w->small_seq = 0;
     w->small_tickets = nullptr;
-    if (p.small) SCANN_TRY(ensure_small_tickets(s, &w->small_tickets));
     w->small_max_leaf = ix->local_sizes_desc.empty() ? 0u : ix->local_sizes_desc[0];
     w->need_sorted_cands = 0;
     w->allow = nullptr;
     w->allow_bits = 0;
-    w->queries = s.queries.as<float>();
-    w->cdist = s.cdist.as<float>();
-    w->tokens = s.tokens.as<uint32_t>();
-    w->token_dists = s.token_dists.as<float>();
-    w->vbase = s.vbase.as<uint32_t>();
     w->st = p.st;
     w->scap = p.scap;
     {   // sample tiles: enough of them to fill the chip (the sample pass is 1/st of the scan)
@@ -829,10 +879,8 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
         w->use_i8 = (t.rows8 && p.exact_reorder && p.m >= min_m && p.m > 4 * p.k) ? 1u : 0u;
         w->rr_lb = w->rr_ub = nullptr;
         if (w->use_i8) {
-            SCANN_TRY(s.rr_lb.ensure((size_t)nq * m_al * 4));
-            SCANN_TRY(s.rr_ub.ensure((size_t)nq * m_al * 4));
-            w->rr_lb = s.rr_lb.as<uint32_t>();
-            w->rr_ub = s.rr_ub.as<uint32_t>();
+            s.want(s.rr_lb, (size_t)nq * m_al * 4);
+            s.want(s.rr_ub, (size_t)nq * m_al * 4);
         }
     }
     w->lut8 = nullptr;
@@ -848,21 +896,35 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
         // (the margin's share is independent of m -- the points within 17 table steps above the bound -- and in
         // the dense nearest leaves of a tree index it can be several thousand: a generous floor)
         const uint64_t cap32 = std::min<uint64_t>(ms2, (uint64_t)p.cap * 4 + 16384);
-        SCANN_TRY(s.lut8.ensure((size_t)max_slots * t.S * 16 + 64));
-        SCANN_TRY(s.lut8_meta.ensure((size_t)(max_slots + 4) * 16));
-        SCANN_TRY(s.mfma_thr1.ensure((size_t)(max_slots + 4) * 4));
+        s.want(s.lut8, (size_t)max_slots * t.S * 16 + 64);
+        s.want(s.lut8_meta, (size_t)(max_slots + 4) * 16);
+        s.want(s.mfma_thr1, (size_t)(max_slots + 4) * 4);
         const uint64_t cap32_al = std::min<uint64_t>(ms2, cap_al * 4 + 16384);   // (allocation; the stride stays cap32)
-        SCANN_TRY(s.cand32.ensure((size_t)nq * cap32_al * 4));
-        if (t.ah_mode) SCANN_TRY(s.cand32_codes.ensure((size_t)nq * cap32_al * (t.S / 8) * 4));   // flat hashers: the survivors' packed codes
-        SCANN_TRY(s.cand32_cnt.ensure((size_t)nq * 4));
+        s.want(s.cand32, (size_t)nq * cap32_al * 4);
+        if (t.ah_mode) s.want(s.cand32_codes, (size_t)nq * cap32_al * (t.S / 8) * 4);   // flat hashers: the survivors' packed codes
+        s.want(s.cand32_cnt, (size_t)nq * 4);
+        w->cap32 = (uint32_t)cap32;
+    }
+    if (p.small) s.want(s.small_tickets, 64 * 4);
+    SCANN_TRY(s.commit());
+    w->queries = s.queries.as<float>();
+    w->cdist = s.cdist.as<float>();
+    w->tokens = s.tokens.as<uint32_t>();
+    w->token_dists = s.token_dists.as<float>();
+    w->vbase = s.vbase.as<uint32_t>();
+    if (w->use_i8) {
+        w->rr_lb = s.rr_lb.as<uint32_t>();
+        w->rr_ub = s.rr_ub.as<uint32_t>();
+    }
+    if (w->mfma) {
         w->lut8 = s.lut8.as<int8_t>();
         w->lut8_meta = s.lut8_meta.p;
         w->mfma_thr1 = s.mfma_thr1.as<int>();
         w->cand32 = s.cand32.as<uint32_t>();
         w->cand32_codes = t.ah_mode ? s.cand32_codes.as<uint32_t>() : nullptr;
         w->cand32_cnt = s.cand32_cnt.as<uint32_t>();
-        w->cap32 = (uint32_t)cap32;
     }
+    if (p.small) w->small_tickets = s.small_tickets.as<uint32_t>();
     w->sbase = s.sbase.as<uint32_t>();
     w->pair_sbase = s.pair_sbase.as<uint32_t>();
     w->stile_off = s.stile_off.as<uint32_t>();
@@ -903,6 +965,69 @@ static void fill_empty(uint32_t nq, uint32_t k, uint32_t *out_idx, float *out_di
     }
     for (uint32_t i = 0; i < nq; ++i)
         if (out_count) out_count[i] = 0;
+}
+
+// ---- workspaces of the device entry points: one per caller stream (ix->mu held) ---------------------------------
+static int device_slot_count() {
+    static const int v = [] {
+        const char *e = std::getenv("SCANN_HIP_DEVICE_SLOTS");
+        return std::max(1, std::min((int)scann_hip_index::kMaxDeviceSlots, e ? std::atoi(e) : 2));
+    }();
+    return v;
+}
+
+// The workspace of a call that will be enqueued on `st`: the one bound to that stream, else an unused one, else the
+// least recently used one -- ordered behind its previous stream's last call.
+static int device_slot(scann_hip_index *ix, hipStream_t st, scann_hip_index::DeviceSlot **out) {
+    auto &ds = ix->dslots;
+    if (!ds[0].ws) {
+        ds[0].ws = &ix->ws;
+        ds[0].bfw = &ix->bfw;
+    }
+    const int n = device_slot_count();
+    scann_hip_index::DeviceSlot *pick = nullptr;
+    for (int i = 0; i < n && !pick; ++i)
+        if (ds[i].used && ds[i].key == st) pick = &ds[i];
+    for (int i = 0; i < n && !pick; ++i)
+        if (!ds[i].used) pick = &ds[i];
+    if (!pick) {
+        pick = &ds[0];
+        for (int i = 1; i < n; ++i)
+            if (ds[i].tick < pick->tick) pick = &ds[i];
+    }
+    if (!pick->ws) {
+        pick->ws_own.reset(new TxhWorkspace());
+        pick->bfw_own.reset(new BfWorkspace());
+        pick->ws = pick->ws_own.get();
+        pick->bfw = pick->bfw_own.get();
+    }
+    if (!pick->done) SCANN_HIP_CHECK(hipEventCreateWithFlags(&pick->done, hipEventDisableTiming));
+    if (pick->used && pick->key != st && pick->done_valid) SCANN_HIP_CHECK(hipStreamWaitEvent(st, pick->done, 0));
+    pick->used = true;
+    pick->key = st;
+    pick->tick = ++ix->dslot_tick;
+    *out = pick;
+    return SCANN_HIP_OK;
+}
+
+// after the call's last enqueue on `st`
+static int device_slot_done(scann_hip_index::DeviceSlot *sl, hipStream_t st) {
+    SCANN_HIP_CHECK(hipEventRecord(sl->done, st));
+    sl->done_valid = true;
+    return SCANN_HIP_OK;
+}
+
+// Host-side users of the primary workspace (they run on ix->stream and synchronise before they return): wait for a
+// device-entry call that may still be using it on another stream.
+static int claim_primary_workspace(scann_hip_index *ix) {
+    auto &d0 = ix->dslots[0];
+    if (d0.used && d0.key != ix->stream) {
+        if (d0.done_valid) SCANN_HIP_CHECK(hipStreamWaitEvent(ix->stream, d0.done, 0));
+        d0.used = false;
+        d0.done_valid = false;
+        d0.key = nullptr;
+    }
+    return SCANN_HIP_OK;
 }
 
 // A search slot for a host-side call: the primary one if it is free, else a free extra slot (created
@@ -958,6 +1083,7 @@ static int acquire_slot(scann_hip_index *ix, SlotLock *out) {
         lk.lock();   // every slot busy: queue on the primary
     }
     out->lock = std::move(lk);
+    SCANN_TRY(claim_primary_workspace(ix));
     out->stream = ix->stream;
     out->ws = &ix->ws;
     out->bfw = &ix->bfw;
@@ -1009,7 +1135,8 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
             return SCANN_HIP_OK;
         }
         TxhWork w;
-        SCANN_TRY(ensure_txh_workspace(ix, ws, nq, p, true, q_stride, true, &w));
+        const size_t allow_words = (opts && opts->allow_bitmap) ? (size_t)((opts->allow_bitmap_bits + 63) / 64) : 0;
+        SCANN_TRY(ensure_txh_workspace(ix, ws, nq, p, true, q_stride, true, &w, allow_words * 8));
         // (cand_count alone also takes the staged pipeline: the small-batch one keeps no candidate counts)
         w.need_sorted_cands = (opts && (opts->cand_idx || opts->cand_dist || opts->cand_count)) ? 1 : 0;
         const bool stage_outputs = opts && (opts->tokens || opts->token_dists || opts->cand_idx || opts->cand_dist ||
@@ -1023,7 +1150,10 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
             SCANN_TRY(sl.pin->ensure(off_flag + (size_t)nq * 4 + 256));
             char *hp = static_cast<char *>(sl.pin->host), *dp = static_cast<char *>(sl.pin->dev);
             std::memcpy(hp, queries, qb);
-            const uint32_t seq = ++sl.pin->seq ? sl.pin->seq : ++sl.pin->seq;   // (never 0: fresh memory)
+            const uint32_t seq = ++sl.pin->seq ? sl.pin->seq : ++sl.pin->seq;   // (never 0)
+            // The flag words sit wherever THIS call's layout puts them: an earlier call (other nq / k / stride) may
+            // have left result words there, and any of those can equal seq.  Zero them before the launch.
+            std::memset(hp + off_flag, 0, (size_t)nq * 4);
             w.queries = reinterpret_cast<const float *>(dp);
             w.out_idx = reinterpret_cast<uint32_t *>(dp + off_idx);
             w.out_dist = reinterpret_cast<float *>(dp + off_dist);
@@ -1044,9 +1174,7 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
             return SCANN_HIP_OK;   // (dense candidate lists: this pipeline has no overflow / retry case)
         }
         if (opts && opts->allow_bitmap) {   // search_with_filter(Some(allow-list))
-            const size_t words = (size_t)((opts->allow_bitmap_bits + 63) / 64);
-            SCANN_TRY(ws.allow.ensure(words * 8));
-            SCANN_HIP_CHECK(hipMemcpyAsync(ws.allow.p, opts->allow_bitmap, words * 8,
+            SCANN_HIP_CHECK(hipMemcpyAsync(ws.allow.p, opts->allow_bitmap, allow_words * 8,
                                            hipMemcpyHostToDevice, stream));
             w.allow = ws.allow.as<uint64_t>();
             w.allow_bits = opts->allow_bitmap_bits;
@@ -1106,12 +1234,14 @@ static int bf_small_search_host(scann_hip_index *ix, SlotLock &sl, const float *
                                 uint32_t *out_count) {
     TxhWorkspace &ws = *sl.ws;
     const uint32_t n = (uint32_t)ix->bf.n, kk = std::min(k, n);
-    SCANN_TRY(ws.tokens.ensure((size_t)nq * 4));
-    SCANN_TRY(ws.token_dists.ensure((size_t)nq * 4));
-    SCANN_TRY(ws.vbase.ensure((size_t)nq * 2 * 4));
-    SCANN_TRY(ws.sbase.ensure((size_t)nq * 3 * 4));
-    SCANN_TRY(ws.counters.ensure(CNT_WORDS * 4));
-    SCANN_TRY(ws.cand.ensure((size_t)nq * n * 8));
+    ws.want(ws.tokens, (size_t)nq * 4);
+    ws.want(ws.token_dists, (size_t)nq * 4);
+    ws.want(ws.vbase, (size_t)nq * 2 * 4);
+    ws.want(ws.sbase, (size_t)nq * 3 * 4);
+    ws.want(ws.counters, CNT_WORDS * 4);
+    ws.want(ws.cand, (size_t)nq * n * 8);
+    ws.want(ws.small_tickets, 64 * 4);
+    SCANN_TRY(ws.commit());
     const size_t qb = (size_t)nq * q_stride * 4, ob = (size_t)nq * k * 4;
     const size_t off_idx = (qb + 255) & ~(size_t)255, off_dist = off_idx + ((ob + 255) & ~(size_t)255),
                  off_cnt = off_dist + ((ob + 255) & ~(size_t)255);
@@ -1120,6 +1250,7 @@ static int bf_small_search_host(scann_hip_index *ix, SlotLock &sl, const float *
     char *hp = static_cast<char *>(sl.pin->host), *dp = static_cast<char *>(sl.pin->dev);
     std::memcpy(hp, queries, qb);
     const uint32_t seq = ++sl.pin->seq ? sl.pin->seq : ++sl.pin->seq;
+    std::memset(hp + off_flag, 0, (size_t)nq * 4);   // (stale words of an earlier call's layout: see txh_search_host)
     TxhWork w{};
     w.nq = nq; w.q_stride = q_stride; w.P = 1; w.m = kk; w.k = k; w.cap = n; w.exact_reorder = 0;
     w.no_threshold = 1; w.need_sorted_cands = 0; w.allow = nullptr; w.allow_bits = 0;
@@ -1131,7 +1262,7 @@ static int bf_small_search_host(scann_hip_index *ix, SlotLock &sl, const float *
     w.out_dist = reinterpret_cast<float *>(dp + off_dist);
     w.out_count = reinterpret_cast<uint32_t *>(dp + off_cnt);
     w.small = 1; w.small_max_leaf = n;
-    SCANN_TRY(ensure_small_tickets(ws, &w.small_tickets));
+    w.small_tickets = ws.small_tickets.as<uint32_t>();
     w.small_done = reinterpret_cast<uint32_t *>(dp + off_flag);
     w.small_seq = seq;
     SCANN_TRY(txh_launch_search(ix->bfx, w, false, sl.stream, nullptr, nullptr));
@@ -1215,11 +1346,14 @@ int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries,
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     std::lock_guard<std::mutex> lock(ix->mu);
     SCANN_TRY(set_device(ix->ctx));
+    scann_hip_index::DeviceSlot *dsl = nullptr;
+    SCANN_TRY(device_slot(ix, st, &dsl));
     if (ix->kind == KIND_BF) {
         ix->next_events();
         const bool exact_only = opts && opts->bf_exact;
-        int s = bf_search_device(ix->bf, ix->bfw, d_queries, nq, q_stride, k, exact_only, d_out_idx,
+        int s = bf_search_device(ix->bf, *dsl->bfw, d_queries, nq, q_stride, k, exact_only, d_out_idx,
                                  d_out_dist, d_out_count, st, ix->ev0, ix->ev1);
+        if (s == SCANN_HIP_OK) s = device_slot_done(dsl, st);
         ix->timing_valid = ix->timing && s == SCANN_HIP_OK;
         ix->timed_kernel = (!exact_only && bf_shortlist_eligible(ix->bf, nq, k)) ? "bf_bf16_kernel"
                                                                                 : bf_pass_kernel_name(ix->bf, nq);
@@ -1229,7 +1363,7 @@ int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries,
     SCANN_TRY(resolve_params(ix, k, opts, false, &p, nq));
     if (p.m == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "pre-reorder candidate count is 0");
     TxhWork w;
-    SCANN_TRY(ensure_txh_workspace(ix, ix->ws, nq, p, false, q_stride, false, &w));
+    SCANN_TRY(ensure_txh_workspace(ix, *dsl->ws, nq, p, false, q_stride, false, &w));
     w.queries = d_queries;
     w.out_idx = d_out_idx;
     w.out_dist = d_out_dist;
@@ -1242,6 +1376,7 @@ int scann_hip_search_batched_device(scann_hip_index *ix, const float *d_queries,
     ix->next_events();
     SCANN_TRY(txh_launch_search(ix->tx, w, false, st, ix->ev0,
                                 ix->ev1));
+    SCANN_TRY(device_slot_done(dsl, st));
     ix->timing_valid = ix->timing;
     ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.mfma == 2 ? "adc_mfma16_kernel" : w.mfma == 3 ? "adc_smfmac_kernel" : w.mfma ? "adc_mfma_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
     return SCANN_HIP_OK;
@@ -1251,10 +1386,19 @@ int scann_hip_index_last_device_status(scann_hip_index *ix, void *hip_stream) {
     if (!ix) return fail(SCANN_HIP_INVALID_ARGUMENT, "index is null");
     SCANN_TRY(set_device(ix->ctx));
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    if (ix->kind == KIND_BF) return bf_last_status(ix->bfw, st);
-    if (ix->kind != KIND_TXH || !ix->ws.counters.p) return SCANN_HIP_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    // the workspace bound to this stream (else the primary one)
+    const TxhWorkspace *ws = &ix->ws;
+    const BfWorkspace *bfw = &ix->bfw;
+    for (auto &d : ix->dslots)
+        if (d.used && d.key == st && d.ws) {
+            ws = d.ws;
+            bfw = d.bfw;
+        }
+    if (ix->kind == KIND_BF) return bf_last_status(*bfw, st);
+    if (ix->kind != KIND_TXH || !ws->counters.p) return SCANN_HIP_OK;
     uint32_t counters[CNT_N];
-    SCANN_HIP_CHECK(hipMemcpyAsync(counters, ix->ws.counters.p, sizeof(counters),
+    SCANN_HIP_CHECK(hipMemcpyAsync(counters, ws->counters.p, sizeof(counters),
                                    hipMemcpyDeviceToHost, st));
     SCANN_HIP_CHECK(hipStreamSynchronize(st));
     if (counters[CNT_STATUS] != SCANN_HIP_OK)
@@ -1279,8 +1423,10 @@ int scann_hip_txh_search_local_device(scann_hip_index *ix, const float *d_querie
     SCANN_TRY(resolve_params(ix, k, opts, false, &p));
     if (!p.exact_reorder) return fail(SCANN_HIP_INVALID_ARGUMENT, "local stage needs exact_reorder");
     if (p.m == 0) return fail(SCANN_HIP_INVALID_ARGUMENT, "pre-reorder candidate count is 0");
+    scann_hip_index::DeviceSlot *dsl = nullptr;
+    SCANN_TRY(device_slot(ix, st, &dsl));
     TxhWork w;
-    SCANN_TRY(ensure_txh_workspace(ix, ix->ws, nq, p, false, q_stride, false, &w));
+    SCANN_TRY(ensure_txh_workspace(ix, *dsl->ws, nq, p, false, q_stride, false, &w));
     w.queries = d_queries;
     w.cand_key = d_keys;
     w.cand_idx = d_idx;
@@ -1294,6 +1440,7 @@ int scann_hip_txh_search_local_device(scann_hip_index *ix, const float *d_querie
     ix->next_events();
     SCANN_TRY(txh_launch_search(ix->tx, w, true, st, ix->ev0,
                                 ix->ev1));
+    SCANN_TRY(device_slot_done(dsl, st));
     ix->timing_valid = ix->timing;
     ix->timed_kernel = ix->tx.exact_scan ? "leaf_exact_scan_kernel" : w.mfma == 2 ? "adc_mfma16_kernel" : w.mfma == 3 ? "adc_smfmac_kernel" : w.mfma ? "adc_mfma_kernel" : w.resident ? "adc_scan_res_kernel" : "adc_scan_kernel";
     return SCANN_HIP_OK;
@@ -1359,6 +1506,7 @@ int scann_hip_txh_partition(scann_hip_index *ix, const float *queries, uint32_t 
     TxhCallParams p;
     SCANN_TRY(resolve_params(ix, 1, &o, false, &p));
     TxhWork w;
+    SCANN_TRY(claim_primary_workspace(ix));
     SCANN_TRY(ensure_txh_workspace(ix, ix->ws, nq, p, true, q_stride, true, &w));
     SCANN_HIP_CHECK(hipMemcpyAsync(ix->ws.queries.p, queries, (size_t)nq * q_stride * 4,
                                    hipMemcpyHostToDevice, ix->stream));
@@ -1541,6 +1689,7 @@ int scann_hip_bf_distances(scann_hip_index *ix, const float *queries, uint32_t n
     if (nq == 0 || ix->bf.n == 0) return SCANN_HIP_OK;
     std::lock_guard<std::mutex> lock(ix->mu);
     SCANN_TRY(set_device(ix->ctx));
+    SCANN_TRY(claim_primary_workspace(ix));
     return bf_distances_host(ix->bf, ix->bfw, queries, nq, q_stride, out, ix->stream);
 }
 
@@ -1556,6 +1705,7 @@ int scann_hip_bf_search_radius(scann_hip_index *ix, const float *query, uint32_t
     if (capacity && (!out_idx || !out_dist)) return fail(SCANN_HIP_INVALID_ARGUMENT, "null outputs");
     std::lock_guard<std::mutex> lock(ix->mu);
     SCANN_TRY(set_device(ix->ctx));
+    SCANN_TRY(claim_primary_workspace(ix));
     return bf_search_radius_host(ix->bf, ix->bfw, query, q_dim, radius, out_idx, out_dist, capacity,
                                  out_count, ix->stream);
 }

@@ -11,6 +11,8 @@
 // All arithmetic that the reference performs in a fixed order is performed in the same
 // order here; this file is compiled with -ffp-contract=off and uses fmaf() only where
 // the reference uses _mm256_fmadd_ps.
+#include <type_traits>
+
 #include "txh.h"
 
 namespace scann {
@@ -1540,12 +1542,15 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
     typedef int v16i __attribute__((ext_vector_type(16)));
     typedef SpLayout<S_> SP;
     constexpr int S = S_, NS = SP::NS, KT = NS + 2, NW = S / 8, NWP = SP::NWP, SPW = SP::SPW;
+    constexpr int D = kMfmaDepth < KT ? kMfmaDepth : KT;      // operands in flight ahead of the MFMA that consumes them
+    constexpr uint32_t kTT = kMfmaRange / 64;                   // tile pairs per item
     __shared__ __attribute__((aligned(16))) uint32_t s_ident[64];   // dense A: 16 one-hot rows of 16 bytes
     __shared__ __attribute__((aligned(16))) uint32_t s_vtab[64];    // sparse A values: row V = (ga | gb << 2)
     __shared__ uint32_t s_ntab[16];                                 // sparse A positions: word N = (ia | ib << 2)
-    __shared__ uint32_t s_stage[kMfmaWaves][32][kMfmaStage];
-    __shared__ uint32_t s_cnt[kMfmaWaves][32];
-    __shared__ uint32_t s_fpre[kMfmaWaves][32], s_fq[kMfmaWaves][32], s_fgb[kMfmaWaves][32], s_fvb[kMfmaWaves][32];   // flush: per pair
+    // survivor bitmap of the wave's item: word [tt][h][col] = the 16-bit masks of tiles 2 tt (low half) and 2 tt + 1 of
+    // lane (col, h).  Written once per two tiles with one conflict-free ds_write_b32; no atomics, no branches and no
+    // waits in the tile loop -- the item's flush turns it into list entries.
+    __shared__ uint32_t s_bits[kMfmaWaves][kTT][64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t col = lane & 31u, h = lane >> 5;
     if (tid < 64) {
@@ -1561,6 +1566,15 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
     const char *ident = reinterpret_cast<const char *>(s_ident);
     const char *vtab = reinterpret_cast<const char *>(s_vtab);
     const char *ntab = reinterpret_cast<const char *>(s_ntab);
+    uint32_t *bits = &s_bits[wave][0][lane];
+
+    struct Planes {   // one tile's operand planes as LDS byte offsets (see step)
+        uint32_t ve[NWP], vo[NWP], ne[NWP], no[NWP], d1;
+    };
+    struct Ops {      // the first D operands of a tile, fetched during the previous tile's MFMA chain
+        v4i av[D];
+        int iv[D];
+    };
 
     uint32_t tile = 0;
     if (lane == 0) tile = grab_tile(a.counters + CNT_XQ, total_tiles);
@@ -1609,161 +1623,156 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
                 for (int kt = 0; kt < NS; ++kt) bs[kt] = v8i{k7, k7, k7, k7, k7, k7, k7, k7};
             }
         }
-        if (lane < 32) s_cnt[wave][lane] = 0;
-        // (s_cnt / s_stage are private to the wave: no workgroup barrier anywhere in this loop)
 
         const uint32_t ntile = (npts + 31u) >> 5;
-        uint32_t wv[NWP], wn[NWP];
-        auto load_planes = [&](uint32_t j) {
+        static_assert(NWP == 1 || NWP == 2, "plane words");
+        struct Raw {
+            uint32_t wv[NWP], wn[NWP];
+        };
+        auto load_planes = [&](uint32_t t) {   // raw planes of tile t (rows past the leaf's end: any row, masked later)
+            const uint32_t j = c0 + t * 32u + col;
             const uint32_t *src = ix.codes_sp + (size_t)(lb + (j < size ? j : 0u)) * SPW + h * 2u * NWP;
+            Raw r;
             if constexpr (NWP == 1) {
                 const uint2 v = *reinterpret_cast<const uint2 *>(src);
-                wv[0] = v.x; wn[0] = v.y;
+                r.wv[0] = v.x; r.wn[0] = v.y;
             } else {
                 const uint4 v = *reinterpret_cast<const uint4 *>(src);
-                wv[0] = v.x; wv[1] = v.y; wn[0] = v.z; wn[1] = v.w;
+                r.wv[0] = v.x; r.wv[1] = v.y; r.wn[0] = v.z; r.wn[1] = v.w;
             }
+            return r;
         };
-        static_assert(NWP == 1 || NWP == 2, "plane words");
-        load_planes(c0 + col);
-        auto flush = [&](bool all) {
-            uint32_t n = 0, gbase = 0;
-            if (lane < 32) {
-                n = min(s_cnt[wave][lane], kMfmaStage);
-                if (!all && n + 32u <= kMfmaStage) n = 0;
-                if (n) {
-                    gbase = atomicAdd(&a.cand32_cnt[pq], n);
-                    s_cnt[wave][lane] = 0;
-                }
-            }
-            uint32_t incl = n;
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) {
-                const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
-                if ((int)lane >= o) incl += up;
-            }
-            const uint32_t total = (uint32_t)__shfl((int)incl, 31);
-            if (total == 0) return;
-            if (lane < 32) {
-                s_fpre[wave][lane] = incl - n;
-                s_fq[wave][lane] = pq == kInvalid ? 0u : pq;
-                s_fgb[wave][lane] = gbase;
-                s_fvb[wave][lane] = vb;
-            }
-            for (uint32_t e = lane; e < total; e += 64u) {
-                uint32_t c = 0;
-#pragma unroll
-                for (uint32_t stp = 16; stp; stp >>= 1)
-                    if (s_fpre[wave][c + stp] <= e) c += stp;
-                const uint32_t idx = e - s_fpre[wave][c];
-                const uint32_t j = s_stage[wave][c][idx];
-                const uint32_t dst = s_fgb[wave][c] + idx;
-                if (dst < a.cap32) {
-                    const size_t o = (size_t)s_fq[wave][c] * a.cap32 + dst;
-                    a.cand32[o] = s_fvb[wave][c] + j;
-                    if (a.cand32_codes) {   // (wave-uniform)
-                        uint32_t cw[NW];
-                        Codec<S, 4>::load_words(ix.codes + (size_t)(lb + j) * NW, cw);
-                        Codec<S, 4>::store_words(a.cand32_codes + o * NW, cw);
-                    }
-                }
-            }
-        };
-        auto step = [&](v16i &accN, const v16i &accO, uint32_t t) {
-            // planes -> LDS byte offsets: nibble j of the V plane times 16 (a 16-byte row), of the N plane times 4
-            uint32_t ve[NWP], vo[NWP], ne[NWP], no[NWP];
+        // planes -> LDS byte offsets: nibble j of the V plane times 16 (a 16-byte row), of the N plane times 4
+        auto unpack = [&](const Raw &r) {
+            Planes p;
 #pragma unroll
             for (int wi = 0; wi < NWP; ++wi) {
-                ve[wi] = wv[wi] & 0xF0F0F0F0u;
-                vo[wi] = (wv[wi] << 4) & 0xF0F0F0F0u;
-                ne[wi] = (wn[wi] >> 2) & 0x3C3C3C3Cu;
-                no[wi] = (wn[wi] << 2) & 0x3C3C3C3Cu;
+                p.ve[wi] = r.wv[wi] & 0xF0F0F0F0u;
+                p.vo[wi] = (r.wv[wi] << 4) & 0xF0F0F0F0u;
+                p.ne[wi] = (r.wn[wi] >> 2) & 0x3C3C3C3Cu;
+                p.no[wi] = (r.wn[wi] << 2) & 0x3C3C3C3Cu;
                 // (opaque to the optimiser: it would otherwise re-derive every offset from the plane word with a
                 // shift and a mask of its own -- two vector instructions per offset instead of one byte extraction)
-                asm volatile("" : "+v"(ve[wi]), "+v"(vo[wi]), "+v"(ne[wi]), "+v"(no[wi]));
+                asm volatile("" : "+v"(p.ve[wi]), "+v"(p.vo[wi]), "+v"(p.ne[wi]), "+v"(p.no[wi]));
             }
-            const uint32_t d1off = ((wn[NS >> 3] >> (4 * (NS & 7))) & 15u) << 4;   // dense MFMA 1: raw code, N plane
-            if (t + 1 < ntile) load_planes(c0 + (t + 1) * 32u + col);
-            auto voff = [&](int j) { return (((j & 1) ? ve[j >> 3] : vo[j >> 3]) >> (8 * ((j & 7) >> 1))) & 0xFFu; };
-            auto noff = [&](int j) { return (((j & 1) ? ne[j >> 3] : no[j >> 3]) >> (8 * ((j & 7) >> 1))) & 0xFFu; };
-            // operands of MFMA oi: 0, 1 dense (identity rows), 2 .. sparse (value row + position word)
-            constexpr int D = kMfmaDepth < KT ? kMfmaDepth : KT;
-            v4i av[D + 1];
-            int iv[D + 1];
-            auto fetch = [&](int oi, int sl) {
-                if (oi == 0) {
-                    av[sl] = *reinterpret_cast<const v4i *>(ident + voff(NS));
-                } else if (oi == 1) {
-                    av[sl] = *reinterpret_cast<const v4i *>(ident + d1off);
-                } else {
-                    av[sl] = *reinterpret_cast<const v4i *>(vtab + voff(oi - 2));
-                    iv[sl] = *reinterpret_cast<const int *>(ntab + noff(oi - 2));
-                }
-            };
+            p.d1 = ((r.wn[NS >> 3] >> (4 * (NS & 7))) & 15u) << 4;   // dense MFMA 1: raw code, last nibble of the N plane
+            return p;
+        };
+        auto voff = [&](const Planes &p, int j) { return (((j & 1) ? p.ve[j >> 3] : p.vo[j >> 3]) >> (8 * ((j & 7) >> 1))) & 0xFFu; };
+        auto noff = [&](const Planes &p, int j) { return (((j & 1) ? p.ne[j >> 3] : p.no[j >> 3]) >> (8 * ((j & 7) >> 1))) & 0xFFu; };
+        // operands of MFMA oi: 0, 1 dense (identity rows), 2 .. sparse (value row + position word)
+        auto fetch = [&](const Planes &p, int oi, v4i &av, int &iv) {
+            if (oi == 0) {
+                av = *reinterpret_cast<const v4i *>(ident + voff(p, NS));
+            } else if (oi == 1) {
+                av = *reinterpret_cast<const v4i *>(ident + p.d1);
+            } else {
+                av = *reinterpret_cast<const v4i *>(vtab + voff(p, oi - 2));
+                iv = *reinterpret_cast<const int *>(ntab + noff(p, oi - 2));
+            }
+        };
+        // Software pipeline over the item's tiles.  step(t): the MFMA chain of tile t into accN; between its MFMAs
+        // the survivor mask of tile t - 1 from accO (the sign of each result), the operand reads of the chain's
+        // later MFMAs and -- in its last D slots -- of the FIRST D MFMAs of tile t + 1, so that no chain starts with
+        // an exposed LDS round trip; the global load of tile t + 2's planes is issued at the top.  One extra step
+        // drains the last tile (its MFMAs run on stale operands and are dropped).
+        Raw rawn = load_planes(ntile > 1 ? 1u : 0u);
+        Planes pl = unpack(load_planes(0u));
+        Ops ops;
 #pragma unroll
-            for (int oi = 0; oi < D; ++oi) fetch(oi, oi);
+        for (int oi = 0; oi < D; ++oi) fetch(pl, oi, ops.av[oi], ops.iv[oi]);
+        uint32_t mlo = 0;
+        auto step = [&](v16i &accN, const v16i &accO, uint32_t t, auto hi_half) {
+            const Planes pn = unpack(rawn);                        // tile t + 1 (loaded during step t - 1)
+            if (t + 2 < ntile) rawn = load_planes(t + 2);
+            v4i av[KT];
+            int iv[KT];
+            Ops nops;
+#pragma unroll
+            for (int oi = 0; oi < D; ++oi) {
+                av[oi] = ops.av[oi];
+                iv[oi] = ops.iv[oi];
+            }
             // lane (col, h), register r: point row (r & 3) + 8 * (r >> 2) + 4 * h of the tile; result r's sign
             // (negative = passes) ends up at bit 15 - r of the mask
             uint32_t m16 = 0;
             __builtin_amdgcn_s_setprio(2);
 #pragma unroll
             for (int oi = 0; oi < KT; ++oi) {
-                if (oi + D < KT) fetch(oi + D, (oi + D) % (D + 1));
+                if (oi + D < KT) fetch(pl, oi + D, av[oi + D], iv[oi + D]);
+                else fetch(pn, oi + D - KT, nops.av[oi + D - KT], nops.iv[oi + D - KT]);
                 if (oi == 0)
                     accN = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[0], bd[0], v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
                 else if (oi == 1)
-                    accN = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[1 % (D + 1)], bd[1], accN, 0, 0, 0);
+                    accN = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[1], bd[1], accN, 0, 0, 0);
                 else
-                    accN = __builtin_amdgcn_smfmac_i32_32x32x64_i8(av[oi % (D + 1)], bs[oi - 2], accN, iv[oi % (D + 1)], 0, 0);
+                    accN = __builtin_amdgcn_smfmac_i32_32x32x64_i8(av[oi], bs[oi - 2], accN, iv[oi], 0, 0);
 #pragma unroll
                 for (int r = oi * 16 / KT; r < (oi + 1) * 16 / KT; ++r)
                     m16 = __builtin_amdgcn_alignbit(m16, (uint32_t)accO[r], 31);
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_s_setprio(0);
+            ops = nops;
+            pl = pn;
             if (t == 0) return;                // nothing before the first tile (wave-uniform)
-            const uint32_t base = c0 + (t - 1) * 32u + 4u * h;
             if (t == ntile && (npts & 31u)) {  // partial last tile: rows past the leaf's end are padding
+                const uint32_t base = c0 + (t - 1) * 32u + 4u * h;
                 uint32_t okm = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     okm |= (base + (uint32_t)((r & 3) + 8 * (r >> 2)) < size ? 1u : 0u) << (15 - r);
                 m16 &= okm;
             }
-            bool risk = false;                 // this lane's pair could overflow its stage in the next tile
-            if (m16) {
-                uint32_t sl = atomicAdd(&s_cnt[wave][col], (uint32_t)__popc(m16));   // one LDS atomic per lane
-                do {
-                    const uint32_t r = 15u - ((uint32_t)__ffs((int)m16) - 1u);
-                    m16 &= m16 - 1u;
-                    const uint32_t j = base + (r & 3u) + ((r >> 2) << 3);
-                    if (sl < kMfmaStage) {
-                        s_stage[wave][col][sl] = j;
-                    } else {   // stage full: direct (slow) append
-                        const uint32_t pos = atomicAdd(&a.cand32_cnt[pq], 1u);
-                        if (pos < a.cap32) {
-                            const size_t o = (size_t)pq * a.cap32 + pos;
-                            a.cand32[o] = vb + j;
-                            if (a.cand32_codes) {
-                                uint32_t cw[NW];
-                                Codec<S, 4>::load_words(ix.codes + (size_t)(lb + j) * NW, cw);
-                                Codec<S, 4>::store_words(a.cand32_codes + o * NW, cw);
-                            }
+            if constexpr (decltype(hi_half)::value) {
+                bits[((t - 1) >> 1) * 64u] = mlo | (m16 << 16);
+            } else {
+                mlo = m16;
+            }
+        };
+        // (tile 0 is peeled: inside the loop t >= 1 is known, so the compiler keeps the mask build between
+        // the MFMAs in BOTH instances instead of sinking it below a `t == 0` branch)
+        v16i accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA;
+        step(accA, accB, 0u, std::false_type());
+        for (uint32_t tl = 1; tl <= ntile; tl += 2) {
+            step(accB, accA, tl, std::false_type());                          // mask of tile tl - 1 (even): low half
+            if (tl + 1 <= ntile) step(accA, accB, tl + 1, std::true_type());  // mask of tile tl (odd): high half, write
+        }
+        if (ntile & 1u) bits[(ntile >> 1) * 64u] = mlo;   // the last tile had an even number: its word has no high half
+
+        // ---- flush: the item's bitmap -> the queries' lists.  Lane (col, hh) owns the words [tt][hh][col]; the two
+        // lanes of a pair share ONE returning atomic for the pair's segment and append their survivors to it.
+        {
+            const uint32_t ntt = (ntile + 1u) >> 1;
+            uint32_t cnt = 0;
+            for (uint32_t tt = 0; tt < ntt; ++tt) cnt += (uint32_t)__popc(bits[tt * 64u]);
+            const uint32_t other = (uint32_t)__shfl_xor((int)cnt, 32);
+            uint32_t gbase = 0;
+            if (h == 0 && cnt + other) gbase = atomicAdd(&a.cand32_cnt[pq], cnt + other);   // (padding pairs: no bits)
+            gbase = (uint32_t)__shfl((int)gbase, (int)col);
+            uint32_t pos = gbase + (h ? other : 0u);
+            const size_t lbase = (size_t)(pq == kInvalid ? 0u : pq) * a.cap32;
+            for (uint32_t tt = 0; tt < ntt && cnt; ++tt) {
+                uint32_t w = bits[tt * 64u];
+                while (w) {
+                    const uint32_t bpos = (uint32_t)__ffs((int)w) - 1u;
+                    w &= w - 1u;
+                    const uint32_t r = 15u - (bpos & 15u);
+                    const uint32_t j = c0 + (2u * tt + (bpos >> 4)) * 32u + 4u * h + (r & 3u) + ((r >> 2) << 3);
+                    if (pos < a.cap32) {
+                        const size_t o = lbase + pos;
+                        a.cand32[o] = vb + j;
+                        if (a.cand32_codes) {   // (wave-uniform)
+                            uint32_t cw[NW];
+                            Codec<S, 4>::load_words(ix.codes + (size_t)(lb + j) * NW, cw);
+                            Codec<S, 4>::store_words(a.cand32_codes + o * NW, cw);
                         }
                     }
-                    ++sl;
-                } while (m16);
-                risk = sl + 32u > kMfmaStage;   // (the lane that appended last to a pair saw its full count)
+                    ++pos;
+                    --cnt;
+                }
             }
-            if (__any(risk)) flush(false);
-        };
-        v16i accA = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accB = accA;
-        step(accA, accB, 0u);
-        for (uint32_t tl = 1; tl <= ntile; tl += 2) {
-            step(accB, accA, tl);
-            if (tl + 1 <= ntile) step(accA, accB, tl + 1);
         }
-        flush(true);
         tile = __builtin_amdgcn_readfirstlane(next_tile);
     }
 }

@@ -267,9 +267,17 @@ class Index:
             o.tokens, o.token_dists = ptr(tok, u32p), ptr(tokd, f32p)
             o.cand_idx, o.cand_dist, o.cand_count = ptr(ci, u32p), ptr(cd, f32p), ptr(cc, u32p)
             extra = (tok, tokd, ci, cd, cc)
-        check(load().scann_hip_search_batched(self.h, ptr(q, f32p), nq, qs, qd, k, C.byref(o),
-                                              ptr(out_idx, u32p), ptr(out_dist, f32p),
-                                              ptr(out_cnt, u32p)))
+        try:
+            check(load().scann_hip_search_batched(self.h, ptr(q, f32p), nq, qs, qd, k, C.byref(o),
+                                                  ptr(out_idx, u32p), ptr(out_dist, f32p),
+                                                  ptr(out_cnt, u32p)))
+        finally:
+            # the caller's opts must not keep pointers into this call's arrays: a later call with the same opts
+            # would write its stage outputs / read its filter through them
+            if stages:
+                o.tokens = o.token_dists = o.cand_idx = o.cand_dist = o.cand_count = None
+            if allow is not None:
+                o.allow_bitmap, o.allow_bitmap_bits = None, 0
         if stages:
             return out_idx[:, :k], out_dist[:, :k], out_cnt, extra
         return out_idx[:, :k], out_dist[:, :k], out_cnt

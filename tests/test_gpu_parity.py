@@ -1270,6 +1270,36 @@ def _small_cases():
         yield "bf", m_
 
 
+@pytest.mark.parametrize("kind", ["txh", "bf"])
+def test_small_batch_flags_survive_changing_layouts(kind, monkeypatch):
+    """The small-batch host path polls completion flags in pinned memory whose offset moves with nq / k: a flag word
+    of one call is a result word (count, index or distance bits) of another.  More than 64 calls alternating nq and k
+    on ONE handle (sequence numbers run through small integers such as 10 = a count at k = 10) must each return exactly
+    the rows of the staged pipeline."""
+    if kind == "txh":
+        rows, data, stride, ix, oix, kw = H.make_txh_case(9000, 64, 12, 16, seed=91, P=4, mult=10.0, kmeans_iters=3, pq_iters=3)
+        index = hip.txh_create(**kw)
+        o = hip.default_opts()
+        o.partitions_to_search, o.pre_reorder_k = 4, 100
+    else:
+        rows = synth.uniform_f32(6000, 64, 92)
+        data, stride = orc.to_strided(rows)
+        index = hip.bf_create(data, 6000, 64, stride, hip.SQUARED_L2)
+        o = None
+    q = synth.uniform_f32(16, 64, 93)
+    monkeypatch.setenv("SCANN_HIP_SMALL", "0")
+    want = {(nq, k): index.search_batched(q[:nq], k, o) for nq in (1, 2, 3, 16) for k in (1, 10, 11)}
+    monkeypatch.delenv("SCANN_HIP_SMALL", raising=False)
+    shapes = [(2, 10), (1, 10), (16, 11), (1, 1), (3, 10), (1, 11), (2, 1), (1, 10)]
+    for it in range(96):
+        nq, k = shapes[it % len(shapes)]
+        got = index.search_batched(q[:nq], k, o)
+        w = want[(nq, k)]
+        assert np.array_equal(got[2], w[2]), (it, nq, k)
+        assert np.array_equal(got[0], w[0]), (it, nq, k)
+        assert np.array_equal(bits(got[1]), bits(w[1])), (it, nq, k)
+
+
 @pytest.mark.parametrize("kind,measure", list(_small_cases()))
 def test_small_batch_pipeline_matches_staged_pipeline(kind, measure, monkeypatch):
     """Calls of <= 16 queries run select_leaves (inline centroid scoring) -> small_scan -> small_finish -- as ONE
@@ -1540,3 +1570,69 @@ def test_threshold_ties_do_not_overflow_device_path(mode, monkeypatch):
     with pytest.raises(hip.ScannError) as e:
         hip.check(L.scann_hip_index_last_device_status(index.h, sp))
     assert e.value.code == hip.RESOURCE_EXHAUSTED
+
+
+# ---- device entry points: one workspace per caller stream ---------------------------------------------------
+@pytest.mark.parametrize("kind", ["ah", "txh", "bf"])
+def test_device_calls_on_two_streams_match_oracle(kind):
+    """scann_hip_search_batched_device binds a workspace to the caller's stream (include/scann_hip.h "device entry
+    points and streams"): calls issued back to back on two streams, with no synchronisation between them, must not share
+    LUTs, candidate lists or counters.  Every row is compared with the host entry point (pinned to the oracle by the
+    tests above) and a few with the oracle directly; a third stream takes over the least recently used workspace."""
+    import ctypes
+
+    import torch
+    dev = torch.device("cuda:0")
+    k = 10
+    o = hip.default_opts()
+    if kind == "ah":
+        rows, data, stride, ix, kw = H.make_ah_case(70000, 64, 16, seed=71, pq_iters=3)
+        index = hip.txh_create(**kw)
+        o.pre_reorder_k = 600
+        dim = 64
+        oracle = lambda qv: orc.ah_search_with_reordering(ix["codebook"], ix["codes"], data, stride, qv, k, 600)
+    elif kind == "txh":
+        rows, data, stride, ix, oix, kw = H.make_txh_case(66000, 96, 24, 24, seed=72, P=5, mult=30.0, kmeans_iters=3, pq_iters=3)
+        index = hip.txh_create(**kw)
+        o.partitions_to_search, o.pre_reorder_k = 5, 300
+        dim = 96
+        oracle = lambda qv: orc.txh_search(oix, qv, k)
+    else:
+        rows = synth.uniform_f32(20000, 64, 73)
+        data, stride = orc.to_strided(rows)
+        index = hip.bf_create(data, 20000, 64, stride, hip.SQUARED_L2)
+        dim = 64
+        o = None
+        oracle = lambda qv: orc.bf_search(data, 20000, 64, stride, hip.SQUARED_L2, qv, k)
+    L = hip.load()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    nqs = [192, 77, 130]
+    qs = [synth.uniform_f32(nq, dim, 700 + i) for i, nq in enumerate(nqs)]
+    want = [index.search_batched(q, k, o) for q in qs]
+    qd = [torch.from_numpy(q).to(dev) for q in qs]
+    outs = [(torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev),
+             torch.empty((nq,), dtype=torch.int32, device=dev)) for nq in nqs]
+    torch.cuda.synchronize()
+    ob = ctypes.byref(o) if o is not None else None
+    for rep in range(4):
+        order = [0, 1] if rep < 2 else [2, 0, 1, 2]      # rep >= 2: three streams over two workspaces
+        for oi_, od_, oc_ in outs:
+            oi_.fill_(-1); od_.zero_(); oc_.zero_()
+        torch.cuda.synchronize()
+        for s in order:
+            hip.check(L.scann_hip_search_batched_device(index.h, p(qd[s]), nqs[s], dim, k, ob, p(outs[s][0]), p(outs[s][1]),
+                                                        p(outs[s][2]), ctypes.c_void_p(streams[s].cuda_stream)))
+        for s in set(order):
+            hip.check(L.scann_hip_index_last_device_status(index.h, ctypes.c_void_p(streams[s].cuda_stream)))
+        torch.cuda.synchronize()
+        for s in set(order):
+            wi, wd, wc = want[s]
+            assert np.array_equal(outs[s][2].cpu().numpy().view(np.uint32), wc), (kind, rep, s)
+            assert np.array_equal(bits(outs[s][1].cpu().numpy()), bits(wd)), (kind, rep, s)
+            assert np.array_equal(outs[s][0].cpu().numpy().view(np.uint32), wi), (kind, rep, s)
+    for s in range(3):
+        for i in range(0, nqs[s], 37):
+            wi, wd = oracle(qs[s][i])[:2]
+            H.assert_topk_equal_up_to_ties(outs[s][0][i].cpu().numpy().view(np.uint32)[:wi.size],
+                                           outs[s][1][i].cpu().numpy()[:wi.size], wi, wd, what="%s s%d q%d" % (kind, s, i))
