@@ -901,7 +901,8 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
         s.want(s.mfma_thr1, (size_t)(max_slots + 4) * 4);
         const uint64_t cap32_al = std::min<uint64_t>(ms2, cap_al * 4 + 16384);   // (allocation; the stride stays cap32)
         s.want(s.cand32, (size_t)nq * cap32_al * 4);
-        if (t.ah_mode) s.want(s.cand32_codes, (size_t)nq * cap32_al * (t.S / 8) * 4);   // flat hashers: the survivors' packed codes
+        // flat hashers: the survivors' packed codes (dense prefilter) or plane rows (sparse prefilter) travel with them
+        if (t.ah_mode) s.want(s.cand32_codes, (size_t)nq * cap32_al * std::max(t.S / 8, w->mfma == 3 ? sp_words(t.S) : 0u) * 4);
         s.want(s.cand32_cnt, (size_t)nq * 4);
         w->cap32 = (uint32_t)cap32;
     }

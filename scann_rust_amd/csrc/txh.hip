@@ -1498,6 +1498,9 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
 // (lut8_build_kernel, fold): a point passes iff its sum is negative -- one v_alignbit per result.
 // Items, survivor staging, flush and lists as in adc_mfma_kernel; candidate lists identical (the refine is exact).
 // =====================================================================================
+constexpr uint32_t kSpStage = 512;   // adc_smfmac_kernel: list entries staged per flush round (per wave)
+constexpr uint32_t kSpU = 8;         // ... and code rows in flight per lane in the copy phase
+
 template <int S_>
 struct SpLayout {
     static constexpr int NS = (S_ - 4) / 4;      // sparse MFMAs per tile
@@ -1535,13 +1538,121 @@ __global__ __launch_bounds__(256) void codes_sp_build_kernel(const uint32_t *__r
         }
 }
 
+// The flush of adc_smfmac_kernel: the item's survivor bitmap -> the queries' lists.  Lane (col, h) owns the words
+// [tt][h][col]; the two lanes of a pair share ONE returning atomic for the pair's segment of the query's list.
+//   1. every lane reads its words into registers and counts its survivors; a wave scan orders the pairs' segments;
+//      the atomics are issued and travel while
+//   2. every lane walks its words and stages (position in the pair's segment, pair, point) of its survivors in LDS,
+//      pair-major, at most kSpStage entries per round;
+//   3. the 64 lanes copy the staged entries to the lists side by side, each with up to kSpU code-row loads in flight.
+//      What travels with a position is the point's PLANE row (codes_sp: the lines the tile loop has just read, still in
+//      L2 -- the packed codes themselves were last touched at index creation: copying those cost 0.1 ms per launch
+//      at C3); adc_refine_kernel decodes it (a.planes).
+// A lane copying only its own survivors pays one dependent load round trip per survivor -- 24 of them in the fullest
+// lane of an item, as long as the item's MFMAs themselves.  Its own function, so that its registers are allocated
+// apart from the tile loop's (inlined, the loop spilled its table fragments).
+template <int S>
+__device__ __attribute__((noinline)) void sp_flush_item(const uint32_t *__restrict__ codes_sp, uint32_t *__restrict__ cand32_cnt,
+                                                        uint32_t *__restrict__ cand32, uint32_t *__restrict__ cand32_codes,
+                                                        uint32_t cap32, const uint32_t *bits, uint2 *stage, uint32_t *s_fq,
+                                                        uint32_t *s_fvb, uint32_t *s_fgb, uint32_t ntile, uint32_t c0,
+                                                        uint32_t lb, uint32_t pq, uint32_t vb) {
+    constexpr int SPW = SpLayout<S>::SPW;
+    constexpr int TTM = (int)(kMfmaRange / 64);
+    const uint32_t lane = threadIdx.x & 63u, col = lane & 31u, h = lane >> 5;
+    const uint32_t ntt = (ntile + 1u) >> 1;
+    uint32_t w[TTM];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int tt = 0; tt < TTM; ++tt) {
+        w[tt] = (uint32_t)tt < ntt ? bits[tt * 64] : 0u;
+        cnt += (uint32_t)__popc(w[tt]);
+    }
+    const uint32_t other = (uint32_t)__shfl_xor((int)cnt, 32);
+    const uint32_t n_pair = cnt + other;
+    uint32_t incl = n_pair;   // prefix over the pairs, computed alike in both halves of the wave
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 32);
+        if ((int)col >= o) incl += up;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 31, 32);
+    if (total == 0) return;
+    uint32_t gbase = 0;
+    if (h == 0 && n_pair) gbase = atomicAdd(&cand32_cnt[pq], n_pair);   // (padding pairs have no bits)
+    if (lane < 32) {
+        s_fq[lane] = pq == kInvalid ? 0u : pq;
+        s_fvb[lane] = vb;
+    }
+    uint32_t sq = incl - n_pair + (h ? other : 0u);   // this lane's first entry in the wave's staging order
+    uint32_t rel = h ? other : 0u;                    // ... and its position in the pair's segment
+    for (uint32_t base = 0; base < total; base += kSpStage) {
+        const uint32_t lim = base + kSpStage;
+#pragma unroll
+        for (int tt = 0; tt < TTM; ++tt) {
+            while (w[tt] && sq < lim) {
+                const uint32_t bpos = (uint32_t)__ffs((int)w[tt]) - 1u;
+                w[tt] &= w[tt] - 1u;
+                const uint32_t r = 15u - (bpos & 15u);
+                const uint32_t jrel = (2u * (uint32_t)tt + (bpos >> 4)) * 32u + 4u * h + (r & 3u) + ((r >> 2) << 3);
+                stage[sq - base] = make_uint2(rel, (col << 16) | jrel);
+                ++sq;
+                ++rel;
+            }
+        }
+        if (base == 0 && lane < 32) s_fgb[lane] = gbase;   // (the atomics have travelled under the walk)
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t n = min(kSpStage, total - base);
+        for (uint32_t e0 = 0; e0 < n; e0 += 64u * kSpU) {
+            uint2 ent[kSpU];
+            uint4 cw[kSpU][SPW / 4];
+#pragma unroll
+            for (int u = 0; u < (int)kSpU; ++u) {
+                const uint32_t e = e0 + lane + 64u * (uint32_t)u;
+                ent[u] = e < n ? stage[e] : make_uint2(0xFFFFFFFFu, 0u);
+            }
+#ifndef SCANN_SP_EXPERIMENT
+#define SCANN_SP_EXPERIMENT 0   // timing experiments only (1: no row loads, 2: no row stores, 3: neither) -- wrong results
+#endif
+            if (cand32_codes && !(SCANN_SP_EXPERIMENT & 1)) {   // (wave-uniform)
+#pragma unroll
+                for (int u = 0; u < (int)kSpU; ++u)
+#pragma unroll
+                    for (int x = 0; x < SPW / 4; ++x)
+                        cw[u][x] = reinterpret_cast<const uint4 *>(codes_sp + (size_t)(lb + c0 + (ent[u].y & 0xFFFFu)) * SPW)[x];
+            } else {
+#pragma unroll
+                for (int u = 0; u < (int)kSpU; ++u)
+#pragma unroll
+                    for (int x = 0; x < SPW / 4; ++x) cw[u][x] = make_uint4(ent[u].x, ent[u].y, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < (int)kSpU; ++u) {
+                if (ent[u].x != 0xFFFFFFFFu) {
+                    const uint32_t c = ent[u].y >> 16;
+                    const uint32_t dst = s_fgb[c] + ent[u].x;
+                    if (dst < cap32) {
+                        const size_t o = (size_t)s_fq[c] * cap32 + dst;
+                        cand32[o] = s_fvb[c] + c0 + (ent[u].y & 0xFFFFu);
+                        if (cand32_codes && !(SCANN_SP_EXPERIMENT & 2)) {
+#pragma unroll
+                            for (int x = 0; x < SPW / 4; ++x) reinterpret_cast<uint4 *>(cand32_codes + o * SPW)[x] = cw[u][x];
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int S_>
 __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) void adc_smfmac_kernel(TxhIndexDev ix, MfmaArgs a) {
     typedef int v4i __attribute__((ext_vector_type(4)));
     typedef int v8i __attribute__((ext_vector_type(8)));
     typedef int v16i __attribute__((ext_vector_type(16)));
     typedef SpLayout<S_> SP;
-    constexpr int S = S_, NS = SP::NS, KT = NS + 2, NW = S / 8, NWP = SP::NWP, SPW = SP::SPW;
+    constexpr int S = S_, NS = SP::NS, KT = NS + 2, NWP = SP::NWP, SPW = SP::SPW;
     constexpr int D = kMfmaDepth < KT ? kMfmaDepth : KT;      // operands in flight ahead of the MFMA that consumes them
     constexpr uint32_t kTT = kMfmaRange / 64;                   // tile pairs per item
     __shared__ __attribute__((aligned(16))) uint32_t s_ident[64];   // dense A: 16 one-hot rows of 16 bytes
@@ -1551,6 +1662,8 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
     // lane (col, h).  Written once per two tiles with one conflict-free ds_write_b32; no atomics, no branches and no
     // waits in the tile loop -- the item's flush turns it into list entries.
     __shared__ uint32_t s_bits[kMfmaWaves][kTT][64];
+    __shared__ uint2 s_stage[kMfmaWaves][kSpStage];                                  // flush: staged list entries
+    __shared__ uint32_t s_fq[kMfmaWaves][32], s_fvb[kMfmaWaves][32], s_fgb[kMfmaWaves][32];   // flush: per pair
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t col = lane & 31u, h = lane >> 5;
     if (tid < 64) {
@@ -1740,39 +1853,10 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
         }
         if (ntile & 1u) bits[(ntile >> 1) * 64u] = mlo;   // the last tile had an even number: its word has no high half
 
-        // ---- flush: the item's bitmap -> the queries' lists.  Lane (col, hh) owns the words [tt][hh][col]; the two
-        // lanes of a pair share ONE returning atomic for the pair's segment and append their survivors to it.
-        {
-            const uint32_t ntt = (ntile + 1u) >> 1;
-            uint32_t cnt = 0;
-            for (uint32_t tt = 0; tt < ntt; ++tt) cnt += (uint32_t)__popc(bits[tt * 64u]);
-            const uint32_t other = (uint32_t)__shfl_xor((int)cnt, 32);
-            uint32_t gbase = 0;
-            if (h == 0 && cnt + other) gbase = atomicAdd(&a.cand32_cnt[pq], cnt + other);   // (padding pairs: no bits)
-            gbase = (uint32_t)__shfl((int)gbase, (int)col);
-            uint32_t pos = gbase + (h ? other : 0u);
-            const size_t lbase = (size_t)(pq == kInvalid ? 0u : pq) * a.cap32;
-            for (uint32_t tt = 0; tt < ntt && cnt; ++tt) {
-                uint32_t w = bits[tt * 64u];
-                while (w) {
-                    const uint32_t bpos = (uint32_t)__ffs((int)w) - 1u;
-                    w &= w - 1u;
-                    const uint32_t r = 15u - (bpos & 15u);
-                    const uint32_t j = c0 + (2u * tt + (bpos >> 4)) * 32u + 4u * h + (r & 3u) + ((r >> 2) << 3);
-                    if (pos < a.cap32) {
-                        const size_t o = lbase + pos;
-                        a.cand32[o] = vb + j;
-                        if (a.cand32_codes) {   // (wave-uniform)
-                            uint32_t cw[NW];
-                            Codec<S, 4>::load_words(ix.codes + (size_t)(lb + j) * NW, cw);
-                            Codec<S, 4>::store_words(a.cand32_codes + o * NW, cw);
-                        }
-                    }
-                    ++pos;
-                    --cnt;
-                }
-            }
-        }
+        // ---- flush: the item's bitmap -> the queries' lists (sp_flush_item: its own function, so that its registers
+        // are allocated apart from the tile loop's -- inlined, the loop spilled its table fragments)
+        sp_flush_item<S>(ix.codes_sp, a.cand32_cnt, a.cand32, a.cand32_codes, a.cap32, bits, s_stage[wave], s_fq[wave], s_fvb[wave],
+                         s_fgb[wave], ntile, c0, lb, pq, vb);
         tile = __builtin_amdgcn_readfirstlane(next_tile);
     }
 }
@@ -1999,6 +2083,34 @@ struct RefineArgs {
     uint32_t *counters;
     const uint64_t *allow;
     uint64_t allow_bits;
+    int planes;   // cand32_codes holds codes_sp plane rows (adc_smfmac_kernel), not packed codes
+};
+
+// code of subspace s from a point's plane row (SpLayout: [ha][plane V, N][word]); ca / cb = the code nibbles of the
+// first / second subspace each sparse MFMA takes from parity ha, rebuilt word-parallel by sp_row_decode
+template <int S>
+struct SpRow {
+    static constexpr int NWP = SpLayout<S>::NWP, NS = SpLayout<S>::NS;
+    uint32_t ca[2][NWP], cb[2][NWP], dv[2], dn[2];   // dv / dn: the dense MFMAs' raw codes (subspaces ha, 2 + ha)
+    __device__ __forceinline__ void decode(const uint32_t *row) {
+#pragma unroll
+        for (int ha = 0; ha < 2; ++ha) {
+#pragma unroll
+            for (int wi = 0; wi < NWP; ++wi) {
+                const uint32_t v = row[(ha * 2 + 0) * NWP + wi], n = row[(ha * 2 + 1) * NWP + wi];
+                ca[ha][wi] = ((v & 0x33333333u) << 2) | (n & 0x33333333u);
+                cb[ha][wi] = (v & 0xCCCCCCCCu) | ((n >> 2) & 0x33333333u);
+            }
+            dv[ha] = (row[(ha * 2 + 0) * NWP + (NS >> 3)] >> (4 * (NS & 7))) & 15u;
+            dn[ha] = (row[(ha * 2 + 1) * NWP + (NS >> 3)] >> (4 * (NS & 7))) & 15u;
+        }
+    }
+    __device__ __forceinline__ uint32_t code(int s) const {   // s: compile-time after unrolling
+        if (s < 4) return (s >> 1) ? dn[s & 1] : dv[s & 1];
+        const int kt = (s - 4) >> 2, q = (s - 4) & 3, ha = q & 1;
+        const uint32_t src = (q >> 1) ? cb[ha][kt >> 3] : ca[ha][kt >> 3];
+        return (src >> (4 * (kt & 7))) & 15u;
+    }
 };
 
 #ifndef SCANN_REFINE_THREADS
@@ -2012,6 +2124,11 @@ constexpr uint32_t kRefineThreads = SCANN_REFINE_THREADS;
 template <typename C>
 __global__ __launch_bounds__(kRefineThreads) void adc_refine_kernel(TxhIndexDev ix, RefineArgs a) {
     constexpr int S = C::S, NW = C::NWORDS;
+    // words per list entry: packed codes, or (4-bit codes behind the sparse-MFMA prefilter) the point's plane row
+    constexpr int SPW = C::BITS == 4 ? (int)(4 * ((((S - 4) / 4 + 1) + 7) / 8)) : NW;
+    constexpr int RW = SPW > NW ? SPW : NW;
+    const bool planes = C::BITS == 4 && a.planes;   // (block-uniform)
+    const uint32_t ew = planes ? (uint32_t)SPW : (uint32_t)NW;
     extern __shared__ __attribute__((aligned(16))) float s_tab[];       // [min(P, kRefineTablesMax)][S][16]
     __shared__ uint32_t s_dvb[kDecodeStage], s_drow[kDecodeStage], s_slot[kDecodeStage], s_out;
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
@@ -2046,16 +2163,30 @@ __global__ __launch_bounds__(kRefineThreads) void adc_refine_kernel(TxhIndexDev 
     }
     uint64_t *out = a.cand + (size_t)q * a.cap;
     const uint32_t *list = a.cand32 + (size_t)q * a.cap32;
-    const uint32_t *list_codes = a.cand32_codes ? a.cand32_codes + (size_t)q * a.cap32 * NW : nullptr;
+    const uint32_t *list_codes = a.cand32_codes ? a.cand32_codes + (size_t)q * a.cap32 * ew : nullptr;
     constexpr int U = SCANN_REFINE_U;   // entries per thread per pass: their dependent loads (position -> codes) overlap
     for (uint32_t b0 = 0; b0 < cnt; b0 += kRefineThreads * U) {
         uint32_t vpos[U], csr[U], lo_[U];
-        uint32_t w[U][NW];
+        uint32_t w[U][RW];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t e = b0 + tid + kRefineThreads * u;
             vpos[u] = e < cnt ? list[e] : 0xFFFFFFFFu;
-            if (a.cand32_codes) C::load_words(list_codes + (size_t)(e < cnt ? e : 0u) * NW, w[u]);   // (written with the position)
+            if (a.cand32_codes) {   // (written with the position)
+                const uint32_t *src = list_codes + (size_t)(e < cnt ? e : 0u) * ew;
+                if (planes) {
+#pragma unroll
+                    for (int x = 0; x < SPW / 4; ++x) {
+                        const uint4 v = reinterpret_cast<const uint4 *>(src)[x];
+                        w[u][4 * x] = v.x; w[u][4 * x + 1] = v.y; w[u][4 * x + 2] = v.z; w[u][4 * x + 3] = v.w;
+                    }
+                } else {
+                    uint32_t t[NW];
+                    C::load_words(src, t);
+#pragma unroll
+                    for (int x = 0; x < NW; ++x) w[u][x] = t[x];
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -2067,7 +2198,12 @@ __global__ __launch_bounds__(kRefineThreads) void adc_refine_kernel(TxhIndexDev 
             }
             lo_[u] = lo;
             csr[u] = (staged ? s_drow[lo] : ix.leaf_off[a.tokens[(size_t)q * P + lo]]) + (vp - (staged ? s_dvb[lo] : vbq[lo]));
-            if (!a.cand32_codes) C::load_words(ix.codes + (size_t)(vpos[u] == 0xFFFFFFFFu ? 0u : csr[u]) * NW, w[u]);
+            if (!a.cand32_codes) {
+                uint32_t t[NW];
+                C::load_words(ix.codes + (size_t)(vpos[u] == 0xFFFFFFFFu ? 0u : csr[u]) * NW, t);
+#pragma unroll
+                for (int x = 0; x < NW; ++x) w[u][x] = t[x];
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -2075,7 +2211,33 @@ __global__ __launch_bounds__(kRefineThreads) void adc_refine_kernel(TxhIndexDev 
             uint64_t key = 0;
             if (vpos[u] != 0xFFFFFFFFu) {
                 float acc = 0.0f;
-                if (tabs) {
+                bool done = false;
+                if constexpr (C::BITS == 4) {
+                    if (planes && tabs) {   // (the sparse prefilter runs with staged tables: P <= kRefineTablesMax or not, both forms)
+                        SpRow<S> row;
+                        row.decode(w[u]);
+                        const float *tb = s_tab + lo_[u] * (S * 16);
+#pragma unroll
+                        for (int s2 = 0; s2 < S; ++s2) {
+                            const float tv = tb[s2 * 16 + row.code(s2)];
+                            acc = s2 == 0 ? tv : acc + tv;
+                        }
+                        done = true;
+                    } else if (planes) {
+                        SpRow<S> row;
+                        row.decode(w[u]);
+                        const uint32_t slot = staged ? s_slot[lo_[u]] : a.slot_of[(size_t)q * P + lo_[u]];
+                        const float *tb = a.lutq + (size_t)(slot >> 2) * S * 64 + (slot & 3u);
+#pragma unroll
+                        for (int s2 = 0; s2 < S; ++s2) {
+                            const float tv = tb[(s2 * 16 + row.code(s2)) * 4];
+                            acc = s2 == 0 ? tv : acc + tv;
+                        }
+                        done = true;
+                    }
+                }
+                if (done) {
+                } else if (tabs) {
                     const float *tb = s_tab + lo_[u] * (S * 16);
 #pragma unroll
                     for (int s2 = 0; s2 < S; ++s2) {
@@ -4362,6 +4524,7 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
             ra.slot_of = w.slot_of; ra.lutq = w.lutq; ra.thr = w.thr; ra.cand32_cnt = w.cand32_cnt;
             ra.cand32 = w.cand32; ra.cand32_codes = codes_in_list ? w.cand32_codes : nullptr; ra.cand_cnt = w.cand_cnt; ra.cand = w.cand; ra.counters = w.counters;
             ra.allow = w.allow; ra.allow_bits = w.allow_bits;
+            ra.planes = (w.mfma == 3 && ra.cand32_codes) ? 1 : 0;
             const size_t lds_rf = w.P <= kRefineTablesMax ? (size_t)w.P * C::S * 16 * sizeof(float) : 16;
             SCANN_TRY(set_dyn_lds(adc_refine_kernel<C>, lds_rf));
             hipLaunchKernelGGL(adc_refine_kernel<C>, dim3(w.nq), dim3(kRefineThreads), lds_rf, st, ix, ra);
