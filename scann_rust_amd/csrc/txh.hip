@@ -2505,6 +2505,127 @@ __global__ __launch_bounds__(kSelectThreads) void threshold_select_kernel(
     publish(((uint64_t)v << 32) | low);
 }
 
+// K5c: the same bound from the LOW TAIL of the sample only.  The bound is the J-th smallest of ~32 k sample keys with
+// J a few hundred: the full histogram select above stages all of them in LDS (128 KB: one workgroup per compute unit,
+// 1024 threads, ~10 workgroup barriers per pass) and makes five passes over them.  Here a 256-thread workgroup (eight
+// per compute unit: every query of a 1024-query batch is resident at once) reads the sample from global memory (L2-hot:
+// the sample pass has just written it) with 16-byte loads; every thread keeps the TWO smallest of its samples, and
+// the J-th smallest of those 512 kept values is a pivot at or above the J-th smallest sample (any subset's J-th
+// smallest is) and within a few percent of it; one more pass collects the (value, slot) keys at or under the pivot --
+// a little over J of them -- and the J-th smallest of THOSE is the bound.  Sample slots grow with the stream position
+// (sbase and vbase are prefixes in the same token order, samples of a leaf are st points apart), so ordering by
+// (value, slot) IS ordering by the merge key (value, position): no separate ranking of the tie group.  If ties flood
+// the list (more than kThrTailList samples at or under the pivot) the bound is (pivot, MAX): valid (pivot >= the J-th
+// smallest), merely looser.
+constexpr uint32_t kThrTailThreads = 256;
+constexpr uint32_t kThrTailList = 2048;
+constexpr uint32_t kThrTailMaxRank = 384;   // J above this takes threshold_select_kernel
+
+__global__ __launch_bounds__(kThrTailThreads) void threshold_tail_kernel(
+    uint32_t P, uint32_t m, uint32_t st, const uint32_t *__restrict__ sbase, const uint32_t *__restrict__ samp,
+    uint32_t scap, const uint32_t *__restrict__ slot_of, uint64_t *__restrict__ thr, uint64_t *__restrict__ pair_thr,
+    const uint32_t *__restrict__ vbase) {
+    __shared__ uint32_t s_kept[2 * kThrTailThreads];
+    __shared__ uint32_t s_hist[1024];
+    __shared__ uint64_t s_slist[256];
+    __shared__ uint64_t s_red[48];
+    __shared__ uint64_t s_keys[kThrTailList];
+    __shared__ uint32_t s_cnt[2];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = kThrTailThreads;
+    const uint32_t ns = min(sbase[(size_t)q * (P + 2) + P], scap);
+    const uint32_t total = sbase[(size_t)q * (P + 2) + P + 1];
+    const uint32_t J = total <= m ? 0u : sample_rank(m, st);
+    auto publish = [&](uint64_t T) {
+        if (tid == 0) thr[q] = T;
+        for (uint32_t r = tid; r < P; r += nt) {
+            const uint32_t sl = slot_of[(size_t)q * P + r];
+            if (sl != kInvalid) pair_thr[sl] = T;
+        }
+    };
+    if (J == 0 || ns < J) {   // block-uniform
+        publish(SCANN_KEY_MAX);
+        return;
+    }
+    // rows of samp are 16-byte aligned (scap % 4 == 0); entries past ns count as absent
+    const uint4 *src = reinterpret_cast<const uint4 *>(samp + (size_t)q * scap);
+    const uint32_t n4 = (ns + 3u) >> 2;
+    auto load4 = [&](uint32_t i) {
+        uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if (i < n4) {
+            v = src[i];
+            if (4 * i + 1 >= ns) v.y = ~0u;
+            if (4 * i + 2 >= ns) v.z = ~0u;
+            if (4 * i + 3 >= ns) v.w = ~0u;
+        }
+        return v;
+    };
+    uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu;   // the two smallest of this thread's samples, m0 <= m1
+    auto keep = [&](uint32_t x) {
+        const uint32_t hi = x > m0 ? x : m0;
+        m0 = x < m0 ? x : m0;
+        m1 = hi < m1 ? hi : m1;
+    };
+    for (uint32_t i0 = 0; i0 < n4; i0 += 4 * nt) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = load4(i0 + u * nt + tid);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            keep(v[u].x); keep(v[u].y); keep(v[u].z); keep(v[u].w);
+        }
+    }
+    s_kept[2 * tid] = m0;
+    s_kept[2 * tid + 1] = m1;
+    if (tid < 2) s_cnt[tid] = 0;
+    __syncthreads();
+    const SelCfg cfg = sel_cfg(kThrTailList);   // bins 1024, list 256
+    uint32_t pivot = block_select<uint32_t>(s_kept, 2 * nt, J, cfg, s_hist, reinterpret_cast<uint32_t *>(s_slist), s_red);
+    __syncthreads();
+    // (absent samples -- rejected by the allow-bitmap -- sort last: with fewer than J kept values present the pivot is
+    // "every present value")
+    if (pivot == 0xFFFFFFFFu) pivot = 0xFFFFFFFEu;
+    for (uint32_t i0 = 0; i0 < n4; i0 += 4 * nt) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = load4(i0 + u * nt + tid);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = 4 * (i0 + u * nt + tid);
+            const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (x[c] <= pivot) {
+                    const uint32_t pos = atomicAdd(&s_cnt[0], 1u);
+                    if (pos < kThrTailList) s_keys[pos] = ((uint64_t)x[c] << 32) | (i + c);
+                }
+        }
+    }
+    __syncthreads();
+    const uint32_t n_le = s_cnt[0];
+    if (n_le < J) {   // fewer than J present samples in all: no bound
+        publish(SCANN_KEY_MAX);
+        return;
+    }
+    if (n_le > kThrTailList) {   // ties flood the list: the pivot is >= the J-th smallest value; all of that distance pass
+        publish(((uint64_t)pivot << 32) | 0xFFFFFFFFu);
+        return;
+    }
+    const uint64_t key = block_select<uint64_t>(s_keys, n_le, J, cfg, s_hist, s_slist, s_red);
+    const uint32_t v = (uint32_t)(key >> 32), slot = (uint32_t)key;
+    if (!vbase) {   // diagnostic mode: the bound on the distance alone, whole tie group
+        publish(((uint64_t)v << 32) | 0xFFFFFFFFu);
+        return;
+    }
+    // stream position of that sample: token r = the largest with sb[r] <= slot
+    const uint32_t *sb = sbase + (size_t)q * (P + 2), *vb = vbase + (size_t)q * (P + 1);
+    uint32_t lo = 0, hi = P;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sb[mid] <= slot) lo = mid; else hi = mid;
+    }
+    publish(((uint64_t)v << 32) | (vb[lo] + (slot - sb[lo]) * st));
+}
+
 // =====================================================================================
 // K6c: exact leaf scan -- Scann::search_partitioned (scann.rs:213-252).  Every row of the P
 // selected leaves is scored with the configured measure's single-pair kernel
@@ -4484,10 +4605,21 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
         // SCANN_HIP_THR_TIES=0 (diagnostics / tests): bound on the distance alone, whole tie groups pass
         bool thr_ties = true;
         if (const char *e = std::getenv("SCANN_HIP_THR_TIES")) thr_ties = std::atoi(e) != 0;
-        SCANN_TRY(set_dyn_lds(threshold_select_kernel, lds_thr));
-        hipLaunchKernelGGL(threshold_select_kernel, dim3(w.nq), dim3(nt), lds_thr, st, w.P, w.m, w.st,
-                           w.no_threshold, w.sbase, w.samp, w.scap, w.slot_of, w.thr, w.pair_thr,
-                           thr_ties ? w.vbase : nullptr);
+        // a bound in the low tail of a long sample: threshold_tail_kernel (SCANN_HIP_THR_TAIL=0: the full select)
+        static const bool tail_ok = [] {
+            const char *e = std::getenv("SCANN_HIP_THR_TAIL");
+            return !e || std::atoi(e) != 0;
+        }();
+        const uint32_t J = sample_rank(w.m, w.st);
+        if (tail_ok && !w.no_threshold && J <= kThrTailMaxRank && w.scap > 4096) {
+            hipLaunchKernelGGL(threshold_tail_kernel, dim3(w.nq), dim3(kThrTailThreads), 0, st, w.P, w.m, w.st, w.sbase,
+                               w.samp, w.scap, w.slot_of, w.thr, w.pair_thr, thr_ties ? w.vbase : nullptr);
+        } else {
+            SCANN_TRY(set_dyn_lds(threshold_select_kernel, lds_thr));
+            hipLaunchKernelGGL(threshold_select_kernel, dim3(w.nq), dim3(nt), lds_thr, st, w.P, w.m, w.st,
+                               w.no_threshold, w.sbase, w.samp, w.scap, w.slot_of, w.thr, w.pair_thr,
+                               thr_ties ? w.vbase : nullptr);
+        }
         LAUNCH_CHECK();
     }
     if constexpr (C::BITS == 4) {
