@@ -1110,7 +1110,7 @@ constexpr uint32_t kMfmaWaves = 4;        // waves per workgroup
 #define SCANN_MFMA_MINW 3
 #endif
 #ifndef SCANN_MFMA_DEPTH
-#define SCANN_MFMA_DEPTH 4
+#define SCANN_MFMA_DEPTH 3
 #endif
 constexpr int kMfmaDepth = SCANN_MFMA_DEPTH;   // one-hot LDS reads in flight per wave
 constexpr uint32_t kRefineTablesMax = 40; // pair tables (2 KB each at S = 32) staged in LDS by the refine
@@ -1551,8 +1551,14 @@ __global__ __launch_bounds__(256) void codes_sp_build_kernel(const uint32_t *__r
 // A lane copying only its own survivors pays one dependent load round trip per survivor -- 24 of them in the fullest
 // lane of an item, as long as the item's MFMAs themselves.  Its own function, so that its registers are allocated
 // apart from the tile loop's (inlined, the loop spilled its table fragments).
+#ifndef SCANN_SP_VGPRS
+#define SCANN_SP_VGPRS 144   // registers of a wave of adc_smfmac_kernel (S <= 32): see the kernel
+#endif
+#ifndef SCANN_SP_FLUSH_INLINE
+#define SCANN_SP_FLUSH_INLINE __forceinline__
+#endif
 template <int S>
-__device__ __attribute__((noinline)) void sp_flush_item(const uint32_t *__restrict__ codes_sp, uint32_t *__restrict__ cand32_cnt,
+__device__ SCANN_SP_FLUSH_INLINE void sp_flush_item(const uint32_t *__restrict__ codes_sp, uint32_t *__restrict__ cand32_cnt,
                                                         uint32_t *__restrict__ cand32, uint32_t *__restrict__ cand32_codes,
                                                         uint32_t cap32, const uint32_t *bits, uint2 *stage, uint32_t *s_fq,
                                                         uint32_t *s_fvb, uint32_t *s_fgb, uint32_t ntile, uint32_t c0,
@@ -1647,7 +1653,7 @@ __device__ __attribute__((noinline)) void sp_flush_item(const uint32_t *__restri
 }
 
 template <int S_>
-__global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) void adc_smfmac_kernel(TxhIndexDev ix, MfmaArgs a) {
+__device__ __forceinline__ void adc_smfmac_body(const TxhIndexDev &ix, const MfmaArgs &a) {
     typedef int v4i __attribute__((ext_vector_type(4)));
     typedef int v8i __attribute__((ext_vector_type(8)));
     typedef int v16i __attribute__((ext_vector_type(16)));
@@ -1859,6 +1865,20 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
                          s_fgb[wave], ntile, c0, lb, pq, vb);
         tile = __builtin_amdgcn_readfirstlane(next_tile);
     }
+}
+
+// S <= 32: three waves per SIMD in SCANN_SP_VGPRS registers each.  Fewer than the 168 three waves could have: the
+// registers (and LDS) left over on every SIMD take a wave of ANOTHER kernel -- with two caller streams (scann_hip.h
+// "device entry points and streams") the HBM- and latency-bound kernels of one batch (sample, select, 8-bit row
+// filter, re-rank) run inside the matrix-core-bound scan of the next instead of behind it.
+template <int S_>
+__global__ __launch_bounds__(kMfmaWaves * 64, SCANN_MFMA_MINW) __attribute__((amdgpu_num_vgpr(SCANN_SP_VGPRS)))
+void adc_smfmac_kernel(TxhIndexDev ix, MfmaArgs a) {
+    adc_smfmac_body<S_>(ix, a);
+}
+template <int S_>
+__global__ __launch_bounds__(kMfmaWaves * 64, 2) void adc_smfmac_wide_kernel(TxhIndexDev ix, MfmaArgs a) {   // S = 48, 64
+    adc_smfmac_body<S_>(ix, a);
 }
 
 // The prefilter with 16-pair tiles on v_mfma_i32_16x16x64_i8, for leaves scanned by 8-24 queries of the batch
@@ -4645,8 +4665,10 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
             if (const char *e = std::getenv("SCANN_HIP_MFMA_WGS")) mwgs = (uint32_t)std::max(1, std::atoi(e));
             if (w.mfma == 2)
                 hipLaunchKernelGGL(adc_mfma16_kernel<C::S>, dim3((uint32_t)cus * mwgs), dim3(kMfmaWaves * 64), 0, st, ix, ma);
-            else if (w.mfma == 3)
+            else if (w.mfma == 3 && C::S <= 32)
                 hipLaunchKernelGGL(adc_smfmac_kernel<C::S>, dim3((uint32_t)cus * mwgs), dim3(kMfmaWaves * 64), 0, st, ix, ma);
+            else if (w.mfma == 3)
+                hipLaunchKernelGGL(adc_smfmac_wide_kernel<C::S>, dim3((uint32_t)cus * mwgs), dim3(kMfmaWaves * 64), 0, st, ix, ma);
             else
                 hipLaunchKernelGGL(adc_mfma_kernel<C::S>, dim3((uint32_t)cus * mwgs), dim3(kMfmaWaves * 64), 0, st, ix, ma);
             LAUNCH_CHECK();
