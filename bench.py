@@ -89,7 +89,9 @@ def parse():
     p.add_argument("--force-sharded", action="store_true",
                    help="rehearsal: run the sharded path (library RCCL exchange included) with however many "
                         "ranks there are, even one")
-    p.add_argument("--m-local", type=int, default=0, help="sharded: candidates sent per (rank, query); 0 = all m")
+    p.add_argument("--m-local", type=int, default=-1,
+                   help="sharded: candidates sent per (rank, query); -1 (default) = all m in compact destination blocks "
+                        "(verified; the run repeats with 0 if a block overflows), 0 = all m in worst-case blocks")
     p.add_argument("--kmeans-iters", type=int, default=8)
     p.add_argument("--bf-exact", action="store_true",
                    help="bf_dot: exact f32-MFMA kernels only (no bf16 shortlist)")
@@ -498,6 +500,8 @@ def main():
     hip.check(L.scann_hip_index_reserve(index.h, Q, k, ctypes.byref(opts)))
 
     two_streams = os.environ.get("SCANN_BENCH_STREAMS", "2") != "1"
+    if sharded and args.m_local < 0:
+        args.m_local = m   # every rank's full list, compact destination blocks
 
     def step(i, qd=None, nq=Q):
         qd = qdev[i % nbatches] if qd is None else qd
@@ -541,7 +545,7 @@ def main():
                 bf_retry, opts.bf_exact = True, 1
                 continue
             if sharded and e.code == 10 and args.m_local:
-                log("m_local=%d was too short; repeating with m_local = m" % args.m_local)
+                log("m_local=%d: a list was too short or a compact block overflowed; repeating with worst-case blocks" % args.m_local)
                 args.m_local = 0
                 continue
             raise
@@ -740,6 +744,8 @@ def main():
                        "k": k, "batch": Q, "global_batch": Q * (nproc if replica else 1),
                        "pre_reorder_k": m if args.workload != "bf_dot" else None,
                        "pre_reorder_k_per_rank": (args.m_local or m) if sharded else None,
+                       "exchange_bytes_per_link_per_step": (hip.comm_layout(Q, nproc, args.m_local, k)["block_bytes"]
+                                                            if args.m_local else Q // nproc * m * 16) if sharded else None,
                        "distribution": args.dist if args.workload != "txh" else "clustered (1000 Gaussians)",
                        "leaves": (args.leaves * (nproc if sharded else 1)) if args.workload == "txh" else None,
                        "partitions_to_search": args.partitions_to_search if args.workload == "txh" else None,

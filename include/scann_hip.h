@@ -299,8 +299,10 @@ int scann_hip_assign_leaves(const uint32_t *leaf_sizes, uint32_t num_partitions,
  *   merges) -> merge of this rank's queries (stable sort by key, truncate m, stable sort by exact,
  *   truncate k: tree_x_hybrid/mod.rs:283-293, 360-361) -> ncclAllGather of the k result rows.
  * All ranks pass the same queries, nq, k and options; every rank receives all nq result rows
- * ([nq][k] / [nq], device pointers).  m_local = 0 means m (exact by construction); a smaller
- * m_local is verified by the merge (scann_hip_comm_last_status -> Aborted: repeat with 0).
+ * ([nq][k] / [nq], device pointers).  m_local = 0 means m with destination blocks sized for the worst
+ * case (exact by construction); m_local > 0 sends compact blocks (scann_hip_comm_layout) and is verified
+ * by the merge -- a too-short list or an overflowing block gives scann_hip_comm_last_status -> Aborted on
+ * every rank: repeat the batch with 0.
  * The exchange runs on the communicator's own stream; `hip_stream` carries the local stage and,
  * at the end of the call, waits for the results.  Internal buffers are double-buffered and ordered
  * with events, so a caller that alternates between two streams (and two sets of output buffers)
@@ -317,14 +319,24 @@ int scann_hip_txh_search_sharded_device(scann_hip_index *index, scann_hip_comm *
                                         uint32_t m_local, uint32_t *d_out_idx, float *d_out_dist,
                                         uint32_t *d_out_count, void *hip_stream);
 /* Byte layout of one sharded step for nq queries (no GPU needed; for hosts that size their own
- * buffers and for the protocol tests): out[0..12) = { qr = queries merged per rank (the batch is
- * padded to qr * world), nq_pad, block_bytes (one destination block: [keys u64 | idx u32 | exact f32
- * | count u32] of qr queries x m_local), offset of idx, of exact, of count inside a block, bytes of
+ * buffers and for the protocol tests): out[0..16) = { qr = queries merged per rank (the batch is
+ * padded to qr * world), nq_pad, block_bytes (one destination block = the bytes a rank sends each peer
+ * over its xGMI link per step), offset of idx, of exact, of count inside a block, bytes of
  * the local-stage arrays [nq][m_local] and the offsets of idx, exact, count inside them, bytes of
- * the result rows ([nq_pad][k] idx | dist | [nq_pad] count) and the offset of dist }. */
-int scann_hip_comm_layout(uint32_t nq, uint32_t world, uint32_t m_local, uint32_t k, uint64_t *out12);
+ * the result rows ([nq_pad][k] idx | dist | [nq_pad] count | [world] status) and the offset of dist,
+ * offset of keys inside a block, cap = entries a block has room for, offset of the block's overflow flag,
+ * offset of the status words inside the result rows }.
+ * A destination block is COMPACT: [count u32[qr] | overflow flag u32 | pad to 16 | keys u64[cap] | idx u32[cap] |
+ * exact f32[cap]], the entries of the block's queries one behind the other.  cap = min(qr * m_local, max(m_local,
+ * ceil(fill * qr * m_local / world))) with fill = SCANN_HIP_COMM_FILL (default 2.5): the candidates of one query total
+ * about m over ALL ranks, so a peer's share averages m_local / world per query.  A block that overflows is flagged,
+ * scann_hip_comm_last_status then returns Aborted on EVERY rank (the status words are gathered with the rows), and
+ * the caller repeats the batch with m_local = 0, which sizes the blocks for the worst case (cap = qr * m).
+ * This function reports the layout of calls with m_local > 0. */
+int scann_hip_comm_layout(uint32_t nq, uint32_t world, uint32_t m_local, uint32_t k, uint64_t *out16);
 /* Status of the merges since the last call of this function (0 = ok, Aborted = an m_local < m list
- * was too short); synchronises the communicator's stream and clears the word. */
+ * was too short or a compact block overflowed -- the same answer on every rank); synchronises the
+ * communicator's stream and clears the word. */
 int scann_hip_comm_last_status(scann_hip_comm *comm);
 
 /* ---- index files ---------------------------------------------------------

@@ -84,8 +84,15 @@ struct TxhWorkspace {
     }
     int commit() {
         if (!dirty) return SCANN_HIP_OK;
-        size_t total = 0;
-        for_each([&](WsBuf &b) { total += (b.need + 255) & ~(size_t)255; });
+        // Every buffer starts at its own skew inside a 128 KB window.  Back to back, the six per-candidate arrays of a
+        // batch ([nq][m] words each) lie exactly nq * m * 4 bytes apart -- 32 MB at nq = 1024, m = 8192 -- so that
+        // element (q, i) of ALL of them maps to the same HBM channel and bank: rerank_short_kernel, which walks
+        // several of them in step, ran 3x slower on such a layout (0.41 vs 0.14 ms; same instructions, same bytes:
+        // round 2's "workspace growth" slowdown was this aliasing, present or absent by the accident of which other
+        // buffers the handle had allocated in between).
+        auto skew = [](size_t i) { return (((i + 1) * 37) % 509) * 256; };
+        size_t total = 0, idx = 0;
+        for_each([&](WsBuf &b) { total += ((b.need + 255) & ~(size_t)255) + skew(idx++); });
         if (arena) (void)hipFree(arena);   // (waits for the device: kernels of earlier calls may still read it)
         arena = nullptr;
         arena_bytes = 0;
@@ -93,7 +100,9 @@ struct TxhWorkspace {
         SCANN_HIP_CHECK(hipMalloc(&arena, total ? total : 256));
         arena_bytes = total;
         size_t off = 0;
+        idx = 0;
         for_each([&](WsBuf &b) {
+            off += skew(idx++);
             if (!b.need) return;
             b.p = static_cast<char *>(arena) + off;
             b.bytes = (b.need + 255) & ~(size_t)255;

@@ -194,7 +194,8 @@ int txh_launch_partition_only(const TxhIndexDev &ix, const TxhWork &w, hipStream
 int txh_launch_merge(uint32_t world, uint32_t nq, uint32_t m_local, uint32_t m, uint32_t k,
                      size_t rank_stride_bytes, const uint64_t *d_keys, const uint32_t *d_idx, const float *d_exact,
                      const uint32_t *d_count, uint32_t *d_out_idx, float *d_out_dist,
-                     uint32_t *d_out_count, uint32_t *d_status, hipStream_t stream);
+                     uint32_t *d_out_count, uint32_t *d_status, hipStream_t stream,
+                     const uint32_t *d_qoff = nullptr /* compact lists: [world][nq] element offsets */);
 
 int txh_launch_pack_blocks(uint32_t world, uint32_t nq, uint32_t m_local, const uint64_t *d_keys,
                            const uint32_t *d_idx, const float *d_exact, const uint32_t *d_count,

@@ -1498,8 +1498,14 @@ __global__ __launch_bounds__(kMfmaWaves * 64, (S_ <= 32 ? SCANN_MFMA_MINW : 2)) 
 // (lut8_build_kernel, fold): a point passes iff its sum is negative -- one v_alignbit per result.
 // Items, survivor staging, flush and lists as in adc_mfma_kernel; candidate lists identical (the refine is exact).
 // =====================================================================================
-constexpr uint32_t kSpStage = 512;   // adc_smfmac_kernel: list entries staged per flush round (per wave)
-constexpr uint32_t kSpU = 8;         // ... and code rows in flight per lane in the copy phase
+#ifndef SCANN_SP_STAGE
+#define SCANN_SP_STAGE 512
+#endif
+constexpr uint32_t kSpStage = SCANN_SP_STAGE;   // adc_smfmac_kernel: list entries staged per flush round (per wave)
+#ifndef SCANN_SP_U
+#define SCANN_SP_U 8
+#endif
+constexpr uint32_t kSpU = SCANN_SP_U;         // ... and code rows in flight per lane in the copy phase
 
 template <int S_>
 struct SpLayout {
@@ -4283,9 +4289,10 @@ __global__ __launch_bounds__(kSelectThreads) void merge_kernel(
     size_t rank_stride, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx,
     const float *__restrict__ exact, const uint32_t *__restrict__ count,
     uint32_t *__restrict__ out_idx, float *__restrict__ out_dist,
-    uint32_t *__restrict__ out_count, uint32_t *__restrict__ status) {
+    uint32_t *__restrict__ out_count, uint32_t *__restrict__ status, const uint32_t *__restrict__ qoff) {
     // rank g's arrays start rank_stride BYTES after rank g-1's (a packed all_gather buffer);
-    // rank_stride == 0 means dense [world][nq][m_local] arrays.
+    // rank_stride == 0 means dense [world][nq][m_local] arrays.  qoff != nullptr: COMPACT lists (comm.hip): the
+    // entries of (rank g, query q) start at element qoff[g * nq + q] of rank g's arrays instead of q * m_local.
     extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];   // [m2max] (sort path)
     uint32_t *s_src = reinterpret_cast<uint32_t *>(skeys + m2max);     // [m2max] packed (g, slot)
     uint64_t *s_mth = reinterpret_cast<uint64_t *>(s_src + m2max);     // [1] key at rank nsel-1
@@ -4295,14 +4302,15 @@ __global__ __launch_bounds__(kSelectThreads) void merge_kernel(
         return reinterpret_cast<const char *>(base) +
                (rank_stride ? (size_t)g * rank_stride : (size_t)g * dense_elems * esz);
     };
+    auto first = [&](uint32_t g) { return qoff ? (size_t)qoff[(size_t)g * nq + q] : (size_t)q * m_local; };
     auto keys_of = [&](uint32_t g) {
-        return reinterpret_cast<const uint64_t *>(at(keys, g, (size_t)nq * m_local, 8)) + (size_t)q * m_local;
+        return reinterpret_cast<const uint64_t *>(at(keys, g, (size_t)nq * m_local, 8)) + first(g);
     };
     auto idx_of = [&](uint32_t g) {
-        return reinterpret_cast<const uint32_t *>(at(idx, g, (size_t)nq * m_local, 4)) + (size_t)q * m_local;
+        return reinterpret_cast<const uint32_t *>(at(idx, g, (size_t)nq * m_local, 4)) + first(g);
     };
     auto exact_of = [&](uint32_t g) {
-        return reinterpret_cast<const float *>(at(exact, g, (size_t)nq * m_local, 4)) + (size_t)q * m_local;
+        return reinterpret_cast<const float *>(at(exact, g, (size_t)nq * m_local, 4)) + first(g);
     };
     auto count_of = [&](uint32_t g) {
         return reinterpret_cast<const uint32_t *>(at(count, g, (size_t)nq, 4))[q];
@@ -5191,7 +5199,8 @@ int txh_launch_pack_blocks(uint32_t world, uint32_t nq, uint32_t m_local, const 
 int txh_launch_merge(uint32_t world, uint32_t nq, uint32_t m_local, uint32_t m, uint32_t k,
                      size_t rank_stride_bytes, const uint64_t *d_keys, const uint32_t *d_idx,
                      const float *d_exact, const uint32_t *d_count, uint32_t *d_out_idx,
-                     float *d_out_dist, uint32_t *d_out_count, uint32_t *d_status, hipStream_t st) {
+                     float *d_out_dist, uint32_t *d_out_count, uint32_t *d_status, hipStream_t st,
+                     const uint32_t *d_qoff) {
     if (nq == 0) return SCANN_HIP_OK;
     if (world == 0 || world > 64) return fail(SCANN_HIP_INVALID_ARGUMENT, "world must be 1..64");
     if (m_local == 0 || m_local > m) return fail(SCANN_HIP_INVALID_ARGUMENT, "need 0 < m_local <= m");
@@ -5202,7 +5211,7 @@ int txh_launch_merge(uint32_t world, uint32_t nq, uint32_t m_local, uint32_t m, 
     SCANN_TRY(set_dyn_lds(merge_kernel, lds));
     hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kSelectThreads), lds, st, world, nq, m_local, m, k, m2,
                        rank_stride_bytes, d_keys, d_idx, d_exact, d_count, d_out_idx, d_out_dist,
-                       d_out_count, d_status);
+                       d_out_count, d_status, d_qoff);
     LAUNCH_CHECK();
     return SCANN_HIP_OK;
 }

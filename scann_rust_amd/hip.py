@@ -480,12 +480,12 @@ def abi_layout():
 
 
 _LAYOUT_KEYS = ["qr", "nq_pad", "block_bytes", "blk_idx", "blk_exact", "blk_count", "soa_bytes", "soa_idx",
-                "soa_exact", "soa_count", "res_bytes", "res_dist"]
+                "soa_exact", "soa_count", "res_bytes", "res_dist", "blk_keys", "cap", "blk_flag", "res_status"]
 
 
 def comm_layout(nq, world, m_local, k):
     """scann_hip_comm_layout as a dict (no GPU needed)."""
-    out = np.zeros(12, np.uint64)
+    out = np.zeros(16, np.uint64)
     check(load().scann_hip_comm_layout(nq, world, m_local, k, ptr(out, u64p)))
     return {n: int(v) for n, v in zip(_LAYOUT_KEYS, out)}
 

@@ -104,42 +104,82 @@ def unpack_blocks(buf, nq, m_local, world):
 
 
 # ---- the library's own exchange (csrc/comm.hip, scann_hip_txh_search_sharded_device) --------------
-def comm_layout(nq, world, m_local, k):
+def comm_fill():
+    import os
+    f = float(os.environ.get("SCANN_HIP_COMM_FILL", "2.5"))
+    return max(f, 0.0)
+
+
+def comm_layout(nq, world, m_local, k, worst_case=False):
     """Python statement of comm.hip::comm_layout (checked against scann_hip_comm_layout by the tests):
-    the batch is padded to qr * world queries; queries past nq travel with count 0."""
+    the batch is padded to qr * world queries; queries past nq travel with count 0.  Destination blocks are
+    compact: [count u32[qr] | overflow flag | pad | keys u64[cap] | idx u32[cap] | exact f32[cap]]."""
+    import math
     qr = (nq + world - 1) // world
-    per = qr * m_local
-    return dict(qr=qr, nq_pad=qr * world, block_bytes=(per * 16 + qr * 4 + 15) // 16 * 16,
-                blk_idx=per * 8, blk_exact=per * 12, blk_count=per * 16,
+    full = qr * m_local
+    cap = full
+    f = comm_fill()
+    if not worst_case and f > 0.0:
+        cap = min(full, max(m_local, int(math.ceil(f * full / world))))
+    blk_flag = qr * 4
+    blk_keys = (blk_flag + 4 + 15) // 16 * 16
+    blk_idx = blk_keys + cap * 8
+    blk_exact = blk_idx + cap * 4
+    res_dist = qr * world * k * 4
+    res_status = 2 * res_dist + qr * world * 4
+    return dict(qr=qr, nq_pad=qr * world, block_bytes=(blk_exact + cap * 4 + 15) // 16 * 16,
+                blk_idx=blk_idx, blk_exact=blk_exact, blk_count=0,
                 soa_bytes=nq * m_local * 16 + nq * 4, soa_idx=nq * m_local * 8, soa_exact=nq * m_local * 12,
-                soa_count=nq * m_local * 16, res_bytes=qr * world * (2 * k + 1) * 4, res_dist=qr * world * k * 4)
+                soa_count=nq * m_local * 16, res_bytes=res_status + world * 4, res_dist=res_dist,
+                blk_keys=blk_keys, cap=cap, blk_flag=blk_flag, res_status=res_status)
 
 
 def comm_pack_reference(keys, idx, exact, counts, world, lay):
-    """Numpy statement of comm.hip::comm_pack_kernel: uint8 [world][block_bytes]."""
+    """Numpy statement of comm.hip::comm_offsets_kernel + comm_pack_kernel: uint8 [world][block_bytes]."""
     nq, m = keys.shape
-    qr = lay["qr"]
+    qr, cap = lay["qr"], lay["cap"]
     out = np.zeros((world, lay["block_bytes"]), np.uint8)
     for d in range(world):
-        q0, q1 = min(nq, d * qr), min(nq, (d + 1) * qr)
-        n = q1 - q0
-        kb = np.zeros((qr, m), np.uint64); ib = np.zeros((qr, m), np.uint32); eb = np.zeros((qr, m), np.float32)
-        cb = np.zeros(qr, np.uint32)
-        kb[:n], ib[:n], eb[:n], cb[:n] = keys[q0:q1], idx[q0:q1], exact[q0:q1], counts[q0:q1]
-        out[d, :lay["blk_idx"]] = kb.view(np.uint8).reshape(-1)
-        out[d, lay["blk_idx"]:lay["blk_exact"]] = ib.view(np.uint8).reshape(-1)
-        out[d, lay["blk_exact"]:lay["blk_count"]] = eb.view(np.uint8).reshape(-1)
-        out[d, lay["blk_count"]:lay["blk_count"] + qr * 4] = cb.view(np.uint8).reshape(-1)
+        hdr = np.zeros(qr, np.uint32)
+        kb = np.zeros(cap, np.uint64); ib = np.zeros(cap, np.uint32); eb = np.zeros(cap, np.float32)
+        base, overflow = 0, 0
+        for ql in range(qr):
+            q = d * qr + ql
+            c = min(int(counts[q]), m) if q < nq else 0
+            sent = c
+            if base + c > cap:
+                sent = max(0, cap - base)
+                overflow = 1
+            hdr[ql] = sent
+            if sent:
+                kb[base:base + sent], ib[base:base + sent], eb[base:base + sent] = keys[q, :sent], idx[q, :sent], exact[q, :sent]
+            base += c
+        out[d, :qr * 4] = hdr.view(np.uint8)
+        out[d, lay["blk_flag"]:lay["blk_flag"] + 4] = np.array([overflow], np.uint32).view(np.uint8)
+        out[d, lay["blk_keys"]:lay["blk_idx"]] = kb.view(np.uint8)
+        out[d, lay["blk_idx"]:lay["blk_exact"]] = ib.view(np.uint8)
+        out[d, lay["blk_exact"]:lay["blk_exact"] + cap * 4] = eb.view(np.uint8)
     return out
 
 
 def comm_unpack(buf, world, m_local, lay):
-    """(keys, idx, exact, counts) [world][qr][...] of a received [world][block_bytes] buffer."""
-    qr = lay["qr"]
+    """(keys, idx, exact, counts, overflow) of a received [world][block_bytes] buffer, the lists expanded to
+    [world][qr][m_local] (what comm_recv_offsets_kernel + merge_kernel read through the per-query offsets)."""
+    qr, cap = lay["qr"], lay["cap"]
     buf = np.ascontiguousarray(buf).reshape(world, lay["block_bytes"])
-    keys = np.stack([buf[g, :lay["blk_idx"]].view(np.uint64).reshape(qr, m_local) for g in range(world)])
-    idx = np.stack([buf[g, lay["blk_idx"]:lay["blk_exact"]].view(np.uint32).reshape(qr, m_local) for g in range(world)])
-    exact = np.stack([buf[g, lay["blk_exact"]:lay["blk_count"]].view(np.float32).reshape(qr, m_local)
-                      for g in range(world)])
-    cnt = np.stack([buf[g, lay["blk_count"]:lay["blk_count"] + qr * 4].view(np.uint32) for g in range(world)])
-    return keys, idx, exact, cnt
+    keys = np.zeros((world, qr, m_local), np.uint64); idx = np.zeros((world, qr, m_local), np.uint32)
+    exact = np.zeros((world, qr, m_local), np.float32); cnt = np.zeros((world, qr), np.uint32)
+    overflow = False
+    for g in range(world):
+        hdr = buf[g, :qr * 4].view(np.uint32)
+        overflow = overflow or bool(buf[g, lay["blk_flag"]:lay["blk_flag"] + 4].view(np.uint32)[0])
+        kb = buf[g, lay["blk_keys"]:lay["blk_idx"]].view(np.uint64)
+        ib = buf[g, lay["blk_idx"]:lay["blk_exact"]].view(np.uint32)
+        eb = buf[g, lay["blk_exact"]:lay["blk_exact"] + cap * 4].view(np.float32)
+        base = 0
+        for ql in range(qr):
+            c = int(hdr[ql])
+            keys[g, ql, :c], idx[g, ql, :c], exact[g, ql, :c] = kb[base:base + c], ib[base:base + c], eb[base:base + c]
+            cnt[g, ql] = c
+            base += c
+    return keys, idx, exact, cnt, overflow

@@ -174,7 +174,12 @@ def test_comm_layout_python_mirror_matches_library_constants():
     build.build()
     lay = sharding.comm_layout(nq=10, world=4, m_local=7, k=3)
     assert lay["qr"] == 3 and lay["nq_pad"] == 12
-    assert lay["block_bytes"] % 16 == 0 and lay["block_bytes"] >= 3 * 7 * 16 + 3 * 4
-    assert lay["blk_idx"] == 3 * 7 * 8 and lay["blk_exact"] == 3 * 7 * 12 and lay["blk_count"] == 3 * 7 * 16
-    for nq, world, m, k in ((10, 4, 7, 3), (1024, 8, 8192, 10), (1, 1, 1, 1), (12, 3, 40, 10), (5, 8, 30, 10)):
+    # compact blocks: room for fill / world of the worst case (default fill 2.5), never less than one full list
+    assert lay["cap"] == 14 and lay["blk_count"] == 0 and lay["blk_flag"] == 12 and lay["blk_keys"] == 16
+    assert lay["blk_idx"] == 16 + 14 * 8 and lay["blk_exact"] == lay["blk_idx"] + 14 * 4
+    assert lay["block_bytes"] % 16 == 0 and lay["block_bytes"] >= lay["blk_exact"] + 14 * 4
+    big = sharding.comm_layout(1024, 8, 8192, 10)
+    assert big["cap"] == 128 * 8192 * 5 // 16 and big["block_bytes"] < 0.32 * 128 * 8192 * 16   # bytes per link per step
+    assert sharding.comm_layout(1024, 8, 8192, 10, worst_case=True)["cap"] == 128 * 8192
+    for nq, world, m, k in ((10, 4, 7, 3), (1024, 8, 8192, 10), (1, 1, 1, 1), (12, 3, 40, 10), (5, 8, 30, 10), (1024, 2, 100, 10)):
         assert sharding.comm_layout(nq, world, m, k) == hip.comm_layout(nq, world, m, k)

@@ -206,19 +206,29 @@ def _worker_comm(rank, world, port, ret, nq):
         keys, idx, exact, cnt = (a[:nq] for a in _local_stage(kw, ix, queries, tokens))
         lay = hip.comm_layout(nq, world, M, K)                  # the library's constants
         assert lay == sharding.comm_layout(nq, world, M, K)
-        send = sharding.comm_pack_reference(keys.view(np.uint64), idx.view(np.uint32), exact,
-                                            cnt.view(np.uint32), world, lay)
-        recv = torch.empty(send.size, dtype=torch.uint8)
-        dist.all_to_all_single(recv, torch.from_numpy(send.reshape(-1)))
-        gk, gi, ge, gc = sharding.comm_unpack(recv.numpy(), world, M, lay)
-        oi, od, oc = sharding.merge_reference(gk, gi, ge, gc, M, K)      # my qr queries (padding: count 0)
-        qr = lay["qr"]
-        outs = []
-        for arr in (oi.view(np.int32), od, oc.view(np.int32)):           # three all-gathers, rank g at g * qr
-            t = torch.from_numpy(np.ascontiguousarray(arr).reshape(-1))  # (gloo has no unsigned 32-bit type)
-            parts = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(parts, t)
-            outs.append(np.concatenate([p.numpy() for p in parts]))
+        retried = False
+        while True:
+            send = sharding.comm_pack_reference(keys.view(np.uint64), idx.view(np.uint32), exact,
+                                                cnt.view(np.uint32), world, lay)
+            recv = torch.empty(send.size, dtype=torch.uint8)
+            dist.all_to_all_single(recv, torch.from_numpy(send.reshape(-1)))
+            gk, gi, ge, gc, overflow = sharding.comm_unpack(recv.numpy(), world, M, lay)
+            oi, od, oc = sharding.merge_reference(gk, gi, ge, gc, M, K)      # my qr queries (padding: count 0)
+            qr = lay["qr"]
+            outs = []
+            status = np.full(1, 10 if overflow else 0, np.int32)             # this rank's step status, gathered with the rows
+            for arr in (oi.view(np.int32), od, oc.view(np.int32), status):   # all-gathers, rank g at g * qr
+                t = torch.from_numpy(np.ascontiguousarray(arr).reshape(-1))  # (gloo has no unsigned 32-bit type)
+                parts = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(parts, t)
+                outs.append(np.concatenate([p.numpy() for p in parts]))
+            if outs[3].max() == 0:
+                break
+            # a compact block overflowed somewhere: EVERY rank sees Aborted and repeats with worst-case blocks (m_local = 0)
+            assert not retried
+            retried = True
+            lay = sharding.comm_layout(nq, world, M, K, worst_case=True)
+        ret["retried_%d" % rank] = retried
         outs[0], outs[2] = outs[0].view(np.uint32), outs[2].view(np.uint32)
         all_i, all_d, all_c = outs[0].reshape(-1, K)[:nq], outs[1].reshape(-1, K)[:nq], outs[2][:nq]
         oix = orc.TxhIndex(data, stride, DIM, ix["centers"], ix["leaf_off"], ix["leaf_ids"],
@@ -244,3 +254,6 @@ def test_library_exchange_protocol_with_padding_matches_single_process(world, nq
     [p.join(300) for p in procs]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert all(ret.get(r) for r in range(world)), dict(ret)
+    # world 2: blocks have room for everything; world 4 with 3 queries per rank: a block overflows, all ranks repeat
+    assert len({ret["retried_%d" % r] for r in range(world)}) == 1
+    assert ret["retried_0"] == (world == 4)

@@ -1048,7 +1048,7 @@ def test_bf_shortlist_aggressive_filter_bound_stays_exact(monkeypatch, force_sho
 
 
 # ---- multi-GPU exchange inside the library (csrc/comm.hip) ---------------------------------------------
-def test_sharded_search_through_rccl_world1():
+def test_sharded_search_through_rccl_world1(monkeypatch):
     """scann_hip_txh_search_sharded_device with a 1-rank communicator: the whole path (local stage, block
     packing with batch padding, grouped ncclSend/ncclRecv to self, merge, in-place ncclAllGather, copy-out)
     runs through RCCL on the communicator's stream and must equal the plain search bit for bit; two
@@ -1099,6 +1099,36 @@ def test_sharded_search_through_rccl_world1():
                                              pre_reorder_multiplier=4.0), qs[0][i], k)
         H.assert_topk_equal_up_to_ties(outs[0][1][i].cpu().numpy().view(np.uint32)[:wi.size],
                                        outs[0][2][i].cpu().numpy()[:wi.size], wi, wd, what="sharded q%d" % i)
+    # m_local = m: compact destination blocks (a count per query, the entries one behind the other), same rows
+    def call(m_local):
+        hip.check(L.scann_hip_txh_search_sharded_device(index.h, comm.h, ctypes.c_void_p(outs[0][0].data_ptr()), nq, 64, k,
+                                                        ctypes.byref(o), m_local, ctypes.c_void_p(outs[0][1].data_ptr()),
+                                                        ctypes.c_void_p(outs[0][2].data_ptr()),
+                                                        ctypes.c_void_p(outs[0][3].data_ptr()),
+                                                        ctypes.c_void_p(streams[0].cuda_stream)))
+        torch.cuda.synchronize()
+    want0 = [t.cpu().numpy().copy() for t in outs[0][1:]]
+    for t in outs[0][1:]:
+        t.zero_()
+    call(40)
+    comm.last_status()
+    for t, w in zip(outs[0][1:], want0):
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), w.view(np.uint32))
+    # blocks with room for a twentieth of the worst case: the overflow is flagged and reported as Aborted ...
+    monkeypatch.setenv("SCANN_HIP_COMM_FILL", "0.05")
+    assert hip.comm_layout(nq, 1, 40, k)["cap"] < nq * 40 // 10
+    call(40)
+    with pytest.raises(hip.ScannError) as e:
+        comm.last_status()
+    assert e.value.code == 10
+    # ... and m_local = 0 (worst-case blocks whatever the fill factor) repairs it
+    for t in outs[0][1:]:
+        t.zero_()
+    call(0)
+    comm.last_status()
+    for t, w in zip(outs[0][1:], want0):
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), w.view(np.uint32))
+    monkeypatch.delenv("SCANN_HIP_COMM_FILL")
     # m_local < m that is too short must be reported, not silently wrong
     hip.check(L.scann_hip_txh_search_sharded_device(index.h, comm.h, ctypes.c_void_p(outs[0][0].data_ptr()), nq, 64, k,
                                                     ctypes.byref(o), 12, ctypes.c_void_p(outs[0][1].data_ptr()),
