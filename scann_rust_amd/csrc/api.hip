@@ -604,6 +604,8 @@ int scann::txh_create_checked(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, s
     // SCANN_HIP_RERANK_STORE = int8 (default: per-row scaled integers, the tighter filter) or fp8 (the
     // reference's E4M3 codec with a per-row calibrate_scale, quantization/fp8.rs).
     t.rows8_fmt = 0;
+    t.rows8_uniform = 0;
+    t.rows8_scale = t.rows8_emax = 0.0f;
     {
         int mode = 1;
         if (const char *e = std::getenv("SCANN_HIP_RERANK_I8")) mode = std::atoi(e);
@@ -633,6 +635,43 @@ int scann::txh_create_checked(scann_hip_ctx *ctx, const scann_hip_txh_desc *d, s
                                               ix->d_rows8_meta.p, ix->stream)) != SCANN_HIP_OK)
                     return bail(s);
                 if (hipStreamSynchronize(ix->stream) != hipSuccess) return bail(fail(SCANN_HIP_INTERNAL, "int8 row build failed"));
+                // Rows of EQUAL magnitude (largest per-row scale within 2 % of the mean scale, every row finite): ONE
+                // scale and ONE error bound (the largest ||x - x~||) for all rows, so that the filter pass gathers a
+                // candidate's 128-byte row and nothing else -- the per-row {scale, error} pair is a second random
+                // cache line per candidate, half of the pass's memory requests (C3, uniform data: 163 -> 128 us).  The
+                // bound is strict because a coarser common scale widens every bracket: on the clustered 10M x 128 set
+                // (per-row maxima 25 % apart, candidates nearly equidistant) the shortlists outgrew the fast path and
+                // the step went from 1.43 to 1.86 ms.  SCANN_HIP_RERANK_UNIFORM=0: always per-row, 2: always one scale.
+                const char *ue = std::getenv("SCANN_HIP_RERANK_UNIFORM");
+                const double spread = (ue && std::atoi(ue) == 2) ? 1e30 : 1.02;
+                if (!(ue && std::atoi(ue) == 0)) {
+                    std::vector<float> meta((size_t)d->n_rows * 2);
+                    if (hipMemcpy(meta.data(), ix->d_rows8_meta.p, meta.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+                        return bail(fail(SCANN_HIP_INTERNAL, "int8 row meta copy failed"));
+                    double sum = 0.0;
+                    float smax = 0.0f;
+                    bool finite = true;
+                    for (uint64_t r = 0; r < d->n_rows; ++r) {
+                        const float sc = meta[2 * r], E = meta[2 * r + 1];
+                        finite = finite && E < INFINITY && sc < INFINITY;
+                        smax = std::max(smax, sc);
+                        sum += sc;
+                    }
+                    if (finite && d->n_rows > 0 && (double)smax <= spread * (sum / (double)d->n_rows)) {
+                        if ((s = launch_rows_i8_build(ix->d_rows.as<float>(), d->n_rows, d->dim, d->stride, ix->d_rows8.as<int8_t>(),
+                                                      ix->d_rows8_meta.p, ix->stream, smax)) != SCANN_HIP_OK)
+                            return bail(s);
+                        if (hipMemcpy(meta.data(), ix->d_rows8_meta.p, meta.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+                            return bail(fail(SCANN_HIP_INTERNAL, "int8 row meta copy failed"));
+                        float emax = 0.0f;
+                        for (uint64_t r = 0; r < d->n_rows; ++r) emax = std::max(emax, meta[2 * r + 1]);
+                        if (emax < INFINITY) {
+                            t.rows8_uniform = 1;
+                            t.rows8_scale = smax;
+                            t.rows8_emax = emax;
+                        }
+                    }
+                }
             }
             t.rows8 = ix->d_rows8.as<int8_t>();
             t.rows8_meta = ix->d_rows8_meta.p;

@@ -99,6 +99,8 @@ struct TxhIndexDev {
     const int8_t *rows8;          // the same rows as int8 (per-row scale) for the re-rank filter, or nullptr
     int rows8_fmt;                // 0 = int8, 1 = the reference's FP8 E4M3 codes (quantization/fp8.rs)
     const void *rows8_meta;       // [n_rows] float2 {scale, ||x - s q||}
+    int rows8_uniform;            // int8 store with ONE scale and ONE error bound for all rows (rows8_scale, rows8_emax)
+    float rows8_scale, rows8_emax;
     int rows_csr;
     const float *codebook;        // [S][K][dsub]
     int use_residuals;
@@ -223,7 +225,7 @@ int launch_fp8_dequantize(const uint8_t *d_bits, uint64_t n, float scale, int fo
 int launch_fp8_one_to_many(const float *d_query, uint32_t dim, const uint8_t *d_db, uint64_t stride, uint64_t n,
                            int dot, float *d_out, hipStream_t st);
 int launch_rows_i8_build(const float *d_rows, uint64_t n, uint32_t dim, uint32_t stride, int8_t *d_rows8,
-                         void *d_meta, hipStream_t stream);
+                         void *d_meta, hipStream_t stream, float uni_scale = 0.0f);
 
 int launch_lut16_quantize(const float *d_tables, uint32_t S, uint8_t *d_lut8, float *d_bias_mult,
                           hipStream_t stream);

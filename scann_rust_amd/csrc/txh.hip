@@ -2591,12 +2591,13 @@ __global__ __launch_bounds__(kThrTailThreads) void threshold_tail_kernel(
         m0 = x < m0 ? x : m0;
         m1 = hi < m1 ? hi : m1;
     };
-    for (uint32_t i0 = 0; i0 < n4; i0 += 4 * nt) {
-        uint4 v[4];
+    constexpr int LU = 8;   // 16-byte loads in flight per thread
+    for (uint32_t i0 = 0; i0 < n4; i0 += LU * nt) {
+        uint4 v[LU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = load4(i0 + u * nt + tid);
+        for (int u = 0; u < LU; ++u) v[u] = load4(i0 + u * nt + tid);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < LU; ++u) {
             keep(v[u].x); keep(v[u].y); keep(v[u].z); keep(v[u].w);
         }
     }
@@ -2610,12 +2611,12 @@ __global__ __launch_bounds__(kThrTailThreads) void threshold_tail_kernel(
     // (absent samples -- rejected by the allow-bitmap -- sort last: with fewer than J kept values present the pivot is
     // "every present value")
     if (pivot == 0xFFFFFFFFu) pivot = 0xFFFFFFFEu;
-    for (uint32_t i0 = 0; i0 < n4; i0 += 4 * nt) {
-        uint4 v[4];
+    for (uint32_t i0 = 0; i0 < n4; i0 += LU * nt) {
+        uint4 v[LU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = load4(i0 + u * nt + tid);
+        for (int u = 0; u < LU; ++u) v[u] = load4(i0 + u * nt + tid);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < LU; ++u) {
             const uint32_t i = 4 * (i0 + u * nt + tid);
             const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
@@ -3402,9 +3403,10 @@ __global__ __launch_bounds__(NT) void final_topk_kernel(
 //   rerank_short_kernel  block per query: tau, shortlist, exact distances (rerank_kernel's
 //                        arithmetic), the k best by (exact, merge key), output rows
 // =====================================================================================
+// uni_scale > 0: every row with that one scale (the store of rerank_i8_kernel's UNIFORM form, see the launcher)
 __global__ __launch_bounds__(256) void rows_i8_build_kernel(const float *__restrict__ rows, uint64_t n, uint32_t dim,
                                                             uint32_t stride, int8_t *__restrict__ rows8,
-                                                            float2 *__restrict__ meta) {
+                                                            float2 *__restrict__ meta, float uni_scale) {
     // 8 lanes per row
     const uint64_t r = (uint64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
     const uint32_t l8 = threadIdx.x & 7u;
@@ -3416,7 +3418,7 @@ __global__ __launch_bounds__(256) void rows_i8_build_kernel(const float *__restr
     mx = fmaxf(mx, __shfl_xor(mx, 2, 8));
     mx = fmaxf(mx, __shfl_xor(mx, 4, 8));
     const bool finite = mx < __builtin_inff();      // (NaN rows: mx stays finite-or-NaN; the error below turns NaN)
-    const float sc = (mx > 0.0f && finite) ? mx / 127.0f : 1.0f;
+    const float sc = uni_scale > 0.0f ? uni_scale : (mx > 0.0f && finite) ? mx / 127.0f : 1.0f;
     float err = 0.0f;
     for (uint32_t j = l8; j < dim; j += 8) {
         const float x = row[j];
@@ -3549,6 +3551,7 @@ __global__ __launch_bounds__(256) void rows_fp8_build_kernel(const float *__rest
 struct I8RerankArgs {
     const int8_t *rows8;      // [n_rows][dim] int8, or the reference's E4M3 codes (FMT = 1)
     const float2 *meta;       // [n_rows] {dequantisation factor, error norm}
+    float uni_scale, uni_E;   // UNI form: one dequantisation factor and one error bound for every row (no meta gather)
     const float *queries;
     uint32_t q_stride, m;
     const uint32_t *cand_row, *cand_count;
@@ -3557,7 +3560,7 @@ struct I8RerankArgs {
 
 constexpr uint32_t kI8PerBlock = 256;   // candidates per block (8 lanes each, 8 rounds): amortises the query staging
 
-template <int FMT>   // 0 = int8 rows, 1 = FP8 (E4M3) rows
+template <int FMT, bool UNI = false>   // 0 = int8 rows, 1 = FP8 (E4M3) rows
 __global__ __launch_bounds__(256) void rerank_i8_kernel(uint32_t dim, I8RerankArgs a) {
     typedef float v2f __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float s_q[];   // [dim]
@@ -3579,7 +3582,7 @@ __global__ __launch_bounds__(256) void rerank_i8_kernel(uint32_t dim, I8RerankAr
     for (int it = 0; it < R; ++it) {
         const uint32_t c = c0 + (uint32_t)it * 32u + (tid >> 3);
         const bool act = c < nsel;
-        const float2 me = a.meta[row[it]];
+        const float2 me = UNI ? make_float2(a.uni_scale, a.uni_E) : a.meta[row[it]];
         const int8_t *r8 = a.rows8 + (size_t)row[it] * dim;
         float acc = 0.0f;
         for (uint32_t j0 = l8 * 16u; j0 < dim; j0 += 128u) {   // 16 dims per lane per pass (dim % 16 == 0)
@@ -3689,38 +3692,53 @@ __global__ __launch_bounds__(256) void rerank_short_kernel(TxhIndexDev ix, Short
     // unfused tail: simd/x86.rs:139-165, 31-44)
     const uint32_t chunks = ix.dim >> 3, lane8 = tid & 7u;
     const uint32_t total = fast ? ns : nsel;
-    for (uint32_t b0 = 0; b0 < total; b0 += nt / 8) {
-        const uint32_t jx = b0 + (tid >> 3);
-        const bool act = jx < total;
-        uint32_t i = 0;
-        bool listed = false;
-        if (act) {
-            i = fast ? s_pos[jx] : jx;
-            listed = fast || a.lb[(size_t)q * m + i] <= tau;
-        }
-        float r = __builtin_inff();
-        if (listed) {   // (divergence is by groups of 8 lanes)
-            const float *row = ix.rows + (size_t)a.cand_row[(size_t)q * m + i] * ix.stride;
-            float accv = 0.0f;
-            for (uint32_t c = 0; c < chunks; ++c) {
-                const float diff = s_q[8 * c + lane8] - row[8 * c + lane8];
-                accv = fmaf(diff, diff, accv);
+    // (kShortR rows per 8-lane group and pass, their row gathers in flight together: one row per pass left every pass
+    // waiting for a 512-byte gather from HBM -- 284 us at 10M x 128, m = 8192, where shortlists hold hundreds of rows)
+    constexpr int kShortR = 4;
+    for (uint32_t b0 = 0; b0 < total; b0 += (nt / 8) * kShortR) {
+        uint32_t jx[kShortR], ci[kShortR];
+        bool act[kShortR], listed[kShortR];
+        const float *rowp[kShortR];
+#pragma unroll
+        for (int u = 0; u < kShortR; ++u) {
+            jx[u] = b0 + (uint32_t)u * (nt / 8) + (tid >> 3);
+            act[u] = jx[u] < total;
+            ci[u] = 0;
+            listed[u] = false;
+            if (act[u]) {
+                ci[u] = fast ? s_pos[jx[u]] : jx[u];
+                listed[u] = fast || a.lb[(size_t)q * m + ci[u]] <= tau;
             }
-            const float s1 = accv + __shfl_down(accv, 4, 8);
+            rowp[u] = ix.rows + (size_t)(listed[u] ? a.cand_row[(size_t)q * m + ci[u]] : 0u) * ix.stride;
+        }
+        float accv[kShortR];
+#pragma unroll
+        for (int u = 0; u < kShortR; ++u) accv[u] = 0.0f;
+        for (uint32_t c = 0; c < chunks; ++c) {
+#pragma unroll
+            for (int u = 0; u < kShortR; ++u) {
+                const float diff = s_q[8 * c + lane8] - rowp[u][8 * c + lane8];
+                accv[u] = fmaf(diff, diff, accv[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kShortR; ++u) {
+            const float s1 = accv[u] + __shfl_down(accv[u], 4, 8);
             const float t1 = s1 + __shfl_down(s1, 1, 8);
-            r = t1 + __shfl_down(t1, 2, 8);
+            float r = t1 + __shfl_down(t1, 2, 8);
             if (lane8 == 0)
                 for (uint32_t j = chunks * 8; j < ix.dim; ++j) {
-                    const float diff = s_q[j] - row[j];
+                    const float diff = s_q[j] - rowp[u][j];
                     r = r + diff * diff;
                 }
-        }
-        if (act && lane8 == 0) {
-            if (fast) {
-                s_eb[jx] = f32_to_ordered(r);
-                s_kk[jx] = a.cand_key[(size_t)q * m + i];
-            } else {
-                a.cand_exact[(size_t)q * m + i] = r;   // +inf outside the shortlist: final_topk orders the rest
+            if (!listed[u]) r = __builtin_inff();
+            if (act[u] && lane8 == 0) {
+                if (fast) {
+                    s_eb[jx[u]] = f32_to_ordered(r);
+                    s_kk[jx[u]] = a.cand_key[(size_t)q * m + ci[u]];
+                } else {
+                    a.cand_exact[(size_t)q * m + ci[u]] = r;   // +inf outside the shortlist: final_topk orders the rest
+                }
             }
         }
     }
@@ -5112,9 +5130,13 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
         ia.rows8 = ix.rows8; ia.meta = reinterpret_cast<const float2 *>(ix.rows8_meta); ia.queries = w.queries;
         ia.q_stride = w.q_stride; ia.m = w.m; ia.cand_row = w.cand_row; ia.cand_count = w.cand_count;
         ia.lb = w.rr_lb; ia.ub = w.rr_ub;
+        ia.uni_scale = ix.rows8_scale; ia.uni_E = ix.rows8_emax;
         if (ix.rows8_fmt == 1) {
             SCANN_TRY(set_dyn_lds(rerank_i8_kernel<1>, lds_rr));
             hipLaunchKernelGGL(rerank_i8_kernel<1>, dim3(ceil_div_u32(w.m, kI8PerBlock), w.nq), dim3(256), lds_rr, st, ix.dim, ia);
+        } else if (ix.rows8_uniform) {
+            SCANN_TRY(set_dyn_lds((rerank_i8_kernel<0, true>), lds_rr));
+            hipLaunchKernelGGL((rerank_i8_kernel<0, true>), dim3(ceil_div_u32(w.m, kI8PerBlock), w.nq), dim3(256), lds_rr, st, ix.dim, ia);
         } else {
             SCANN_TRY(set_dyn_lds(rerank_i8_kernel<0>, lds_rr));
             hipLaunchKernelGGL(rerank_i8_kernel<0>, dim3(ceil_div_u32(w.m, kI8PerBlock), w.nq), dim3(256), lds_rr, st, ix.dim, ia);
@@ -5305,10 +5327,10 @@ int launch_fp8_one_to_many(const float *d_query, uint32_t dim, const uint8_t *d_
 }
 
 int launch_rows_i8_build(const float *d_rows, uint64_t n, uint32_t dim, uint32_t stride, int8_t *d_rows8,
-                         void *d_meta, hipStream_t st) {
+                         void *d_meta, hipStream_t st, float uni_scale) {
     if (n == 0) return SCANN_HIP_OK;
     hipLaunchKernelGGL(rows_i8_build_kernel, dim3((uint32_t)ceil_div_u64(n, 32)), dim3(256), 0, st, d_rows, n, dim,
-                       stride, d_rows8, reinterpret_cast<float2 *>(d_meta));
+                       stride, d_rows8, reinterpret_cast<float2 *>(d_meta), uni_scale);
     LAUNCH_CHECK();
     return SCANN_HIP_OK;
 }

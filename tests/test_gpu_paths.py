@@ -6,6 +6,8 @@ ORACLE (not with one another): the driver's own `pytest -m gpu` run sees the who
     SCANN_HIP_RESIDENT     (with MFMA = 0) 2 = resident-table scan kernel
     SCANN_HIP_RERANK_I8    0 = exact re-rank of every candidate, 2 = 8-bit row filter in front of it (any size)
     SCANN_HIP_RERANK_STORE int8 | fp8 row store of that filter (read at index creation)
+    SCANN_HIP_RERANK_UNIFORM (int8 store, read at index creation) 0 = a {scale, error} pair per row; default: one
+                           scale and one error bound for all rows when their magnitudes allow it
 
 The cases mirror test_txh_search_stages / test_ah_search_with_reordering of test_gpu_parity.py at sizes where a
 filter bound is in force (the prefilter needs one), plus the 1M x 128 headline index."""
@@ -21,6 +23,8 @@ pytestmark = pytest.mark.gpu
 # (MFMA, SMFMAC, RESIDENT, RERANK_I8, STORE)
 MATRIX = [
     ("0", None, "0", "0", "int8"),
+    ("0", None, "0", "2", "int8-perrow"),
+    ("2", "1", None, "2", "int8-perrow"),
     ("0", None, "2", "2", "fp8"),
     ("2", "1", None, "0", "int8"),
     ("2", "1", None, "2", "int8"),
@@ -43,7 +47,9 @@ def _force(monkeypatch, mfma, smfmac, resident, i8, store):
             monkeypatch.setenv(name, val)
     monkeypatch.setenv("SCANN_HIP_RERANK_I8", i8)
     monkeypatch.setenv("SCANN_HIP_RERANK_I8_MIN", "1")
-    monkeypatch.setenv("SCANN_HIP_RERANK_STORE", store)
+    monkeypatch.setenv("SCANN_HIP_RERANK_STORE", store.split("-")[0])
+    # the int8 store with a {scale, error} pair per row, or with one pair for all rows whatever their magnitudes
+    monkeypatch.setenv("SCANN_HIP_RERANK_UNIFORM", "0" if store.endswith("-perrow") else "2")
 
 
 def _expected_kernel(mfma, smfmac, resident):
@@ -110,8 +116,8 @@ def ah_1m():
 
 
 @pytest.mark.parametrize("mfma,smfmac,resident,i8,store",
-                         [MATRIX[0], MATRIX[3], MATRIX[5], MATRIX[6], MATRIX[8]],
-                         ids=[IDS[0], IDS[3], IDS[5], IDS[6], IDS[8]])
+                         [MATRIX[0], MATRIX[2], MATRIX[5], MATRIX[7], MATRIX[8], MATRIX[10]],
+                         ids=[IDS[0], IDS[2], IDS[5], IDS[7], IDS[8], IDS[10]])
 def test_ah_1m_headline_every_path(ah_1m, mfma, smfmac, resident, i8, store, monkeypatch):
     """BASELINE configs[2] (1M x 128, S = 32, pre_reorder_k = 5000, batch 1024) under each forced path: three rows
     against the oracle, every row against exact re-computation and against the default path."""
@@ -123,7 +129,7 @@ def test_ah_1m_headline_every_path(ah_1m, mfma, smfmac, resident, i8, store, mon
               codebook=b["codebook"], codes=b["codes"], codes_packed4=False, use_residuals=False, partitions_to_search=1,
               pre_reorder_multiplier=1.0)
     for name in ("SCANN_HIP_MFMA", "SCANN_HIP_SMFMAC", "SCANN_HIP_RESIDENT", "SCANN_HIP_RERANK_I8", "SCANN_HIP_RERANK_I8_MIN",
-                 "SCANN_HIP_RERANK_STORE"):
+                 "SCANN_HIP_RERANK_STORE", "SCANN_HIP_RERANK_UNIFORM"):
         monkeypatch.delenv(name, raising=False)
     ref = hip.txh_create(**kw).search_batched(b["q"], k, o)      # the default heuristics
     _force(monkeypatch, mfma, smfmac, resident, i8, store)
