@@ -320,7 +320,30 @@ def scan_roofline(hip, workload, kernel_name, kernel_ms, scanned_points, S, K, Q
     code_bytes = S // 2 if K <= 16 else S
     algo_bytes = scanned_points * code_bytes + pairs_per_query * S * (16 if K <= 16 else 256) * 4 + k * 8
     t = kernel_ms * 1e-3
-    if kernel_name in ("adc_mfma_kernel", "adc_mfma16_kernel"):
+    if kernel_name == "adc_smfmac_kernel":
+        # The prefilter on the 2:4-sparse MFMA: a 32 x 32 tile issues 2 dense v_mfma_i32_32x32x32_i8 (subspaces 0..3)
+        # and (S - 4) / 4 v_smfmac_i32_32x32x64_i8 (four subspaces each), every one of them one 32-cycle slot of the
+        # matrix pipe.  achieved = ISSUED slots x the dense slot's 2 x 32^3 integer op -- the share of the dense-i8
+        # pipe rate the kernel keeps busy (the sparse instruction's doubled K is not counted: it is the same slot);
+        # the one-hot product those slots evaluate is reported beside it.
+        slots = scanned_points / 32.0 * Q / 32.0 * (2.0 + (S - 4) / 4.0)
+        ops = slots * 2.0 * 32768.0
+        ach = ops / t / 1e12 if t else 0.0
+        dense_equiv = 2.0 * scanned_points * S * 16.0 * Q
+        roof = {"bound": "mfma", "achieved": ach, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
+                "frac": ach / I8_MFMA_PEAK_TOPS, "frac_of_measured_peak": ach / I8_MFMA_MEASURED_TOPS,
+                "peak_measured": I8_MFMA_MEASURED_TOPS, "traffic": None, "kernel": kernel_name,
+                "kernel_ms": kernel_ms,
+                "useful_lookups_per_s": scanned_points * S * Q / t if t else 0.0,
+                "one_hot_product_TOPs": dense_equiv / t / 1e12 if t else 0.0,
+                "algorithmic": "matrix-pipe slots: scanned points (%.0f) / 32 x %d queries / 32 x (2 dense + %d sparse MFMAs "
+                               "per tile) = %.4g slots x 2 x 32^3 integer op = %.4g op per launch; peak = dense i8 MFMA "
+                               "(2 x the 2.5 PFLOP/s bf16 rate); peak_measured = sustained rate of either instruction on "
+                               "random operands (tools/micro/mfma_rate.hip, smfmac_probe.hip); the one-hot product "
+                               "evaluated is 2 x points x S*16 x queries = %.4g op (one_hot_product_TOPs), of which "
+                               "points x S x queries table lookups are useful (useful_lookups_per_s)"
+                               % (scanned_points, Q, (S - 4) // 4, slots, ops, dense_equiv)}
+    elif kernel_name in ("adc_mfma_kernel", "adc_mfma16_kernel"):
         # integer-MFMA prefilter: one-hot(codes) [points x S*16] x u8 tables [S*16 x queries]; every
         # (point, query) costs S*16 multiply-adds on the matrix cores (16x the useful table adds: the price
         # of turning a gather into a product).  Bound: the i8 MFMA rate.

@@ -228,6 +228,17 @@ int scann_hip_search_batched(scann_hip_index *index, const float *queries, uint3
                              const scann_hip_search_opts *opts, uint32_t *out_idx,
                              float *out_dist, uint32_t *out_count);
 
+/* Searcher::search_batched_with_params (searcher.rs:148-186; tree_x_hybrid/mod.rs:383-409, hashes/hasher.rs,
+ * brute_force/searcher.rs: one SearchParameters per query, of which the searchers on this path read
+ * num_neighbors): query i is searched with k_per_query[i] -- and therefore with ITS OWN pre-reorder candidate
+ * count k_i * pre_reorder_multiplier when opts->pre_reorder_k is 0 -- exactly as a single search(query, k_i)
+ * would.  Queries that share a k travel as one batch.  Row i of out_idx / out_dist starts at i * out_pitch
+ * (out_pitch >= the largest k); slots past out_count[i] hold idx 0xFFFFFFFF, dist +inf. */
+int scann_hip_search_batched_params(scann_hip_index *index, const float *queries, uint32_t nq,
+                                    uint32_t q_stride, uint32_t q_dim, const uint32_t *k_per_query,
+                                    const scann_hip_search_opts *opts, uint32_t out_pitch,
+                                    uint32_t *out_idx, float *out_dist, uint32_t *out_count);
+
 /* Same, all pointers device-resident, enqueued on `hip_stream`, no sync.  The caller
  * must first reserve workspace for the largest batch it will submit. */
 int scann_hip_index_reserve(scann_hip_index *index, uint32_t max_nq, uint32_t max_k,

@@ -1373,6 +1373,53 @@ int scann_hip_search_batched(scann_hip_index *ix, const float *queries, uint32_t
     return txh_search_host(ix, queries, nq, q_stride, k, opts, out_idx, out_dist, out_count);
 }
 
+int scann_hip_search_batched_params(scann_hip_index *ix, const float *queries, uint32_t nq, uint32_t q_stride,
+                                    uint32_t q_dim, const uint32_t *k_per_query, const scann_hip_search_opts *opts,
+                                    uint32_t out_pitch, uint32_t *out_idx, float *out_dist, uint32_t *out_count) {
+    if (!ix) return fail(SCANN_HIP_INVALID_ARGUMENT, "index is null");
+    if (nq == 0) return SCANN_HIP_OK;
+    if (!queries || !k_per_query || !out_count) return fail(SCANN_HIP_INVALID_ARGUMENT, "null query/k/output pointer");
+    if (q_stride < q_dim) return fail(SCANN_HIP_INVALID_ARGUMENT, "q_stride < q_dim");
+    uint32_t kmax = 0;
+    for (uint32_t i = 0; i < nq; ++i) kmax = std::max(kmax, k_per_query[i]);
+    if (kmax > out_pitch) return fail(SCANN_HIP_INVALID_ARGUMENT, "out_pitch is smaller than the largest k");
+    if (kmax > 0 && (!out_idx || !out_dist)) return fail(SCANN_HIP_INVALID_ARGUMENT, "null output pointer");
+    for (size_t i = 0; i < (size_t)nq * out_pitch; ++i) {
+        out_idx[i] = 0xFFFFFFFFu;
+        out_dist[i] = INFINITY;
+    }
+    // one batch per distinct k, in order of first appearance
+    std::vector<uint32_t> order(nq);
+    for (uint32_t i = 0; i < nq; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return k_per_query[a] < k_per_query[b]; });
+    std::vector<float> qbuf;
+    std::vector<uint32_t> gi, gc;
+    std::vector<float> gd;
+    for (uint32_t a0 = 0; a0 < nq;) {
+        const uint32_t k = k_per_query[order[a0]];
+        uint32_t a1 = a0;
+        while (a1 < nq && k_per_query[order[a1]] == k) ++a1;
+        const uint32_t g = a1 - a0;
+        qbuf.resize((size_t)g * q_stride);
+        for (uint32_t j = 0; j < g; ++j)
+            std::memcpy(&qbuf[(size_t)j * q_stride], queries + (size_t)order[a0 + j] * q_stride, (size_t)q_stride * 4);
+        gi.assign((size_t)g * std::max(1u, k), 0xFFFFFFFFu);
+        gd.assign((size_t)g * std::max(1u, k), INFINITY);
+        gc.assign(g, 0u);
+        SCANN_TRY(scann_hip_search_batched(ix, qbuf.data(), g, q_stride, q_dim, k, opts, gi.data(), gd.data(), gc.data()));
+        for (uint32_t j = 0; j < g; ++j) {
+            const uint32_t q = order[a0 + j];
+            out_count[q] = gc[j];
+            for (uint32_t r = 0; r < gc[j]; ++r) {
+                out_idx[(size_t)q * out_pitch + r] = gi[(size_t)j * k + r];
+                out_dist[(size_t)q * out_pitch + r] = gd[(size_t)j * k + r];
+            }
+        }
+        a0 = a1;
+    }
+    return SCANN_HIP_OK;
+}
+
 int scann_hip_index_reserve(scann_hip_index *ix, uint32_t max_nq, uint32_t max_k,
                             const scann_hip_search_opts *opts) {
     if (!ix) return fail(SCANN_HIP_INVALID_ARGUMENT, "index is null");

@@ -163,9 +163,19 @@ __device__ __forceinline__ T shfl_xor_t(T v, int d) {
     }
 }
 
-template <typename T>
-__device__ static T block_select(const T *vals, uint32_t n, uint32_t rank, SelCfg cfg, uint32_t *hist,
+// AGENT: vals was written by OTHER workgroups of the same launch with agent-scope (write-through, sc1) stores: every
+// read of it must then be an agent-scope load (a plain load may be served from this CU's L1 / a stale line).
+template <typename T, bool AGENT = false>
+__device__ static T block_select(const T *vals_in, uint32_t n, uint32_t rank, SelCfg cfg, uint32_t *hist,
                                  T *list, uint64_t *red) {
+    struct Vals {
+        const T *p;
+        __device__ __forceinline__ T operator[](uint32_t i) const {
+            if constexpr (AGENT) return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else return p[i];
+        }
+    };
+    const Vals vals{vals_in};
     const uint32_t kSelBins = cfg.bins, kSelList = cfg.list;
     const uint32_t tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u, wave = tid >> 6, nwaves = nt >> 6;
     constexpr T kAbsent = ~(T)0;

@@ -26,7 +26,7 @@ _CODE_NAMES = {
 EXPORTS = [
     "scann_hip_init", "scann_hip_shutdown", "scann_hip_last_error", "scann_hip_version",
     "scann_hip_compute_stride", "scann_hip_bf_create", "scann_hip_txh_create",
-    "scann_hip_search_opts_default", "scann_hip_search_batched", "scann_hip_index_reserve",
+    "scann_hip_search_opts_default", "scann_hip_search_batched", "scann_hip_search_batched_params", "scann_hip_index_reserve",
     "scann_hip_search_batched_device", "scann_hip_index_last_device_status",
     "scann_hip_txh_search_local_device", "scann_hip_txh_merge_device",
     "scann_hip_assign_leaves", "scann_hip_txh_partition", "scann_hip_lut_from_query",
@@ -128,6 +128,8 @@ def load():
     L.scann_hip_search_opts_default.restype = None
     L.scann_hip_search_batched.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                            C.c_uint32, C.POINTER(SearchOpts), u32p, f32p, u32p]
+    L.scann_hip_search_batched_params.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p,
+                                                  C.POINTER(SearchOpts), C.c_uint32, u32p, f32p, u32p]
     L.scann_hip_index_reserve.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(SearchOpts)]
     L.scann_hip_search_batched_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32,
                                                   C.POINTER(SearchOpts), vp, vp, vp, vp]
@@ -281,6 +283,19 @@ class Index:
         if stages:
             return out_idx[:, :k], out_dist[:, :k], out_cnt, extra
         return out_idx[:, :k], out_dist[:, :k], out_cnt
+
+    def search_batched_with_params(self, queries, ks, opts=None):
+        """Searcher::search_batched_with_params: one num_neighbors per query; rows at pitch max(ks)."""
+        q = f32(queries)
+        nq, qs = q.shape
+        ks = np.ascontiguousarray(ks, np.uint32)
+        pitch = max(int(ks.max()), 1)
+        out_idx = np.zeros((nq, pitch), np.uint32); out_dist = np.zeros((nq, pitch), np.float32)
+        out_cnt = np.zeros(nq, np.uint32)
+        check(load().scann_hip_search_batched_params(self.h, ptr(q, f32p), nq, qs, qs, ptr(ks, u32p),
+                                                     C.byref(opts) if opts is not None else None, pitch,
+                                                     ptr(out_idx, u32p), ptr(out_dist, f32p), ptr(out_cnt, u32p)))
+        return out_idx, out_dist, out_cnt
 
     def enable_timing(self, on=True):
         load().scann_hip_index_enable_timing(self.h, 1 if on else 0)

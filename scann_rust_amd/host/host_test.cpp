@@ -95,6 +95,9 @@ static void tree_x_hybrid_tests() {
     sorted(r);
     auto b = s.search_batched({q, q}, 10);
     EXPECT(b.size() == 2 && b[0] == r && b[1] == r);
+    // Searcher::search_batched_with_params (mod.rs:399-409): one num_neighbors per query == single searches
+    auto bp = s.search_batched_with_params({q, q, q}, {10, 3, 1});
+    EXPECT(bp.size() == 3 && bp[0] == r && bp[1] == s.search(q, 3) && bp[2] == s.search(q, 1));
     bool threw = false;
     try { s.search({1, 2, 3}, 5); } catch (const ScannError &e) { threw = e.code == ErrorCode::InvalidArgument; }
     EXPECT(threw);

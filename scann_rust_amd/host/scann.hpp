@@ -235,6 +235,21 @@ inline std::vector<NNResultsVector> run_search(scann_hip_index *h, const float *
     return out;
 }
 
+// Searcher::search_batched_with_params (searcher.rs:148-186): one num_neighbors per query
+inline std::vector<NNResultsVector> run_search_params(scann_hip_index *h, const float *q, uint32_t nq,
+                                                      uint32_t q_stride, uint32_t q_dim, const std::vector<uint32_t> &ks,
+                                                      const scann_hip_search_opts *opts) {
+    uint32_t pitch = 1;
+    for (uint32_t k : ks) pitch = std::max(pitch, k);
+    std::vector<uint32_t> idx((size_t)nq * pitch), cnt(nq);
+    std::vector<float> dist((size_t)nq * pitch);
+    check(scann_hip_search_batched_params(h, q, nq, q_stride, q_dim, ks.data(), opts, pitch, idx.data(), dist.data(), cnt.data()));
+    std::vector<NNResultsVector> out(nq);
+    for (uint32_t i = 0; i < nq; ++i)
+        for (uint32_t j = 0; j < cnt[i]; ++j) out[i].emplace_back(idx[(size_t)i * pitch + j], dist[(size_t)i * pitch + j]);
+    return out;
+}
+
 inline std::vector<float> flatten(const std::vector<std::vector<float>> &qs, uint32_t *dim_out) {
     uint32_t d = qs.empty() ? 0 : (uint32_t)qs[0].size();
     for (auto &q : qs)
@@ -528,6 +543,16 @@ public:
         uint32_t d;
         auto flat = detail::flatten(queries, &d);
         return detail::run_search(ix_.h, flat.data(), (uint32_t)queries.size(), d, d, (uint32_t)k, nullptr);
+    }
+    // Searcher::search_batched_with_params (tree_x_hybrid/mod.rs:399-409): params[i].num_neighbors per query
+    std::vector<NNResultsVector> search_batched_with_params(const std::vector<std::vector<float>> &queries,
+                                                            const std::vector<uint32_t> &num_neighbors) const {
+        if (!ix_.h) throw ScannError::failed_precondition("Partitioner not built");
+        if (queries.size() != num_neighbors.size()) throw ScannError::invalid_argument("one SearchParameters per query");
+        if (queries.empty()) return {};
+        uint32_t d;
+        auto flat = detail::flatten(queries, &d);
+        return detail::run_search_params(ix_.h, flat.data(), (uint32_t)queries.size(), d, d, num_neighbors, nullptr);
     }
     size_t num_partitions() const { return L_ ? L_ : (leaf_off_.empty() ? 0 : leaf_off_.size() - 1); }
     size_t num_datapoints() const { return n_; }

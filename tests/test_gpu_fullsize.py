@@ -287,6 +287,25 @@ def test_txh_10m_gpu_build_and_oracle():
     with pytest.raises(hip.ScannError) as e:
         b["index"].search_batched(b["q"][:2], k, o)
     assert e.value.code == hip.UNIMPLEMENTED
+    # A batch of 4096 queries gives every leaf ~40 (query, leaf) pairs: the DEFAULT heuristic now takes the integer-MFMA
+    # prefilter (32-pair tiles, sparse instruction) on this TREE index; stage by stage against the oracle.
+    rng = np.random.default_rng(5)
+    pick = rng.integers(0, 10_000_000, 4096)
+    q4 = b["data"][pick] + np.float32(0.02) * rng.standard_normal((4096, 128)).astype(np.float32)
+    o = hip.default_opts()
+    o.partitions_to_search, o.pre_reorder_k = 10, 500
+    b["index"].enable_timing(True)
+    idx, dist, cnt, (tok, tokd, ci, cd, cc) = b["index"].search_batched(q4, k, o, stages=True)
+    assert b["index"].last_kernel_ms()[1] == "adc_smfmac_kernel"
+    b["index"].enable_timing(False)
+    oix = orc.TxhIndex(b["data"], b["stride"], b["dim"], b["centers"], b["leaf_off"], b["ids"], b["cb"], b["codes"],
+                       use_residuals=True, partitions_to_search=10, pre_reorder_multiplier=50.0)
+    for i in (0, 777, 2048, 4095):
+        H.check_txh_query(oix, q4[i], k, idx[i, :cnt[i]], dist[i, :cnt[i]], tok[i], tokd[i], ci[i, :cc[i]], cd[i, :cc[i]],
+                          what="4096-query batch q%d" % i)
+    for i in range(0, 4096, 97):
+        want = orc.one_to_many(q4[i], b["data"][idx[i]].ravel(), 128, k, hip.SQUARED_L2)
+        assert np.array_equal(want.view(np.uint32), dist[i].view(np.uint32))
 
 
 def test_txh_c5_shard_shape():

@@ -1666,3 +1666,39 @@ def test_device_calls_on_two_streams_match_oracle(kind):
             wi, wd = oracle(qs[s][i])[:2]
             H.assert_topk_equal_up_to_ties(outs[s][0][i].cpu().numpy().view(np.uint32)[:wi.size],
                                            outs[s][1][i].cpu().numpy()[:wi.size], wi, wd, what="%s s%d q%d" % (kind, s, i))
+
+
+# ---- Searcher::search_batched_with_params: one num_neighbors per query ------------------------------------------
+@pytest.mark.parametrize("kind", ["txh", "ah", "bf"])
+def test_search_batched_with_params_per_query_k(kind):
+    """searcher.rs:148-186 / tree_x_hybrid/mod.rs:383-409: every query of a batch carries its own SearchParameters, of
+    which the searchers on this path read num_neighbors.  Query i must get exactly the rows of search(query_i, k_i) --
+    with the pre-reorder candidate count k_i * multiplier that goes with ITS k -- whatever the other queries ask for."""
+    if kind == "txh":
+        rows, data, stride, ix, oix, kw = H.make_txh_case(5000, 64, 12, 16, seed=81, P=4, mult=3.0, kmeans_iters=3, pq_iters=3)
+        index = hip.txh_create(**kw)
+        single = lambda qv, k: orc.txh_search(oix, qv, k)
+    elif kind == "ah":
+        rows, data, stride, ix, kw = H.make_ah_case(4000, 64, 16, seed=82, pq_iters=3)
+        kw["pre_reorder_multiplier"] = 4.0
+        index = hip.txh_create(**kw)
+        single = lambda qv, k: orc.ah_search_with_reordering(ix["codebook"], ix["codes"], data, stride, qv, k, orc.pre_reorder_k(k, 4.0))
+    else:
+        rows = synth.uniform_f32(3000, 48, 83)
+        data, stride = orc.to_strided(rows)
+        index = hip.bf_create(data, 3000, 48, stride, hip.DOT_PRODUCT)
+        single = lambda qv, k: orc.bf_search(data, 3000, 48, stride, hip.DOT_PRODUCT, qv, k)
+    dim = index.dimensionality()
+    q = synth.uniform_f32(23, dim, 84)
+    ks = np.array([10, 1, 5, 10, 37, 0, 5, 64, 10, 2, 3, 10, 1, 100, 7, 10, 5, 5, 10, 20, 1, 10, 9], np.uint32)
+    idx, dist, cnt = index.search_batched_with_params(q, ks)
+    assert idx.shape[1] == 100
+    for i in range(q.shape[0]):
+        k = int(ks[i])
+        if k == 0:
+            assert cnt[i] == 0
+            continue
+        wi, wd = single(q[i], k)[:2]
+        assert cnt[i] == wi.size, (i, k, cnt[i], wi.size)
+        H.assert_topk_equal_up_to_ties(idx[i, :cnt[i]], dist[i, :cnt[i]], wi, wd, what="%s q%d k=%d" % (kind, i, k))
+        assert np.all(idx[i, cnt[i]:] == 0xFFFFFFFF) and np.all(np.isinf(dist[i, cnt[i]:]))
