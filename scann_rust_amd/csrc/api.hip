@@ -912,9 +912,17 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
             if (v == 2) w->mfma = mfma_ok ? 1u : 0u;
             if (v == 3) w->mfma = mfma_ok ? 2u : 0u;
         }
-        // the 32-pair form runs on the 2:4-sparse MFMA when the index holds the operand planes (SCANN_HIP_SMFMAC=0
-        // at this call keeps the dense instruction: tests compare the two)
-        if (w->mfma == 1 && t.codes_sp) {
+        // With the operand planes in the index the 32-pair form runs on the 2:4-sparse MFMA (SCANN_HIP_SMFMAC=0 at this
+        // call keeps the dense instruction: tests compare the two) -- and takes over from 8 pairs per leaf, whatever
+        // m / stream is: at 10M x 128, 1000 leaves, 1024 queries, P = 10 (10 pairs per leaf: tiles a third full)
+        // m = 1000 / 4000 / 8192 run 0.68 / 0.95 / 1.29 ms per step on it against 0.88 / 1.09 / 1.61 ms on the 16-pair
+        // dense form / the f32 gather scan the rules above pick.
+        if (mfma_ok && t.codes_sp && quads_per_leaf >= 2) {
+            const char *e = std::getenv("SCANN_HIP_SMFMAC");
+            const char *f = std::getenv("SCANN_HIP_MFMA");
+            if (!(e && std::atoi(e) == 0) && !(f && (std::atoi(f) == 0 || std::atoi(f) == 3))) w->mfma = 3u;
+        }
+        if (w->mfma == 1 && t.codes_sp) {   // (forced 32-pair form, fewer pairs per leaf)
             const char *e = std::getenv("SCANN_HIP_SMFMAC");
             if (!(e && std::atoi(e) == 0)) w->mfma = 3u;
         }

@@ -1544,27 +1544,28 @@ __global__ __launch_bounds__(256) void codes_sp_build_kernel(const uint32_t *__r
         }
 }
 
-// The flush of adc_smfmac_kernel: the item's survivor bitmap -> the queries' lists.  Lane (col, h) owns the words
-// [tt][h][col]; the two lanes of a pair share ONE returning atomic for the pair's segment of the query's list.
-//   1. every lane reads its words into registers and counts its survivors; a wave scan orders the pairs' segments;
-//      the atomics are issued and travel while
-//   2. every lane walks its words and stages (position in the pair's segment, pair, point) of its survivors in LDS,
-//      pair-major, at most kSpStage entries per round;
-//   3. the 64 lanes copy the staged entries to the lists side by side, each with up to kSpU code-row loads in flight.
-//      What travels with a position is the point's PLANE row (codes_sp: the lines the tile loop has just read, still in
-//      L2 -- the packed codes themselves were last touched at index creation: copying those cost 0.1 ms per launch
-//      at C3); adc_refine_kernel decodes it (a.planes).
-// A lane copying only its own survivors pays one dependent load round trip per survivor -- 24 of them in the fullest
-// lane of an item, as long as the item's MFMAs themselves.  Its own function, so that its registers are allocated
-// apart from the tile loop's (inlined, the loop spilled its table fragments).
-#ifndef SCANN_SP_VGPRS
-#define SCANN_SP_VGPRS 144   // registers of a wave of adc_smfmac_kernel (S <= 32): see the kernel
-#endif
+// inclusive prefix sum over the 64 lanes of a wave: DPP row shifts inside the 16-lane rows, then the row broadcasts
+// (six v_add with a DPP operand; no LDS round trips)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+    return v;
+}
+
 #ifndef SCANN_SP_FLUSH_INLINE
 #define SCANN_SP_FLUSH_INLINE __forceinline__
 #endif
+// The flush for FLAT hashers (one leaf, every pair sparse: ~0.4 survivors per bitmap word at C3): lane (col, h) keeps
+// its own 32 words in registers and walks their bits itself, in rounds of kSpStage staged entries; the copy-out is the
+// same as in sp_flush_item_words.  No per-pair round trip through LDS and the wave scan: 0.35 ms at C3 against
+// 0.44 ms for the word-parallel form -- which wins wherever pairs are dense (tree indexes: 10M x 128, P = 25, m = 1000:
+// scan 0.27 ms against 0.71 ms), because a lane walking its own survivors takes them one by one.
 template <int S>
-__device__ SCANN_SP_FLUSH_INLINE void sp_flush_item(const uint32_t *__restrict__ codes_sp, uint32_t *__restrict__ cand32_cnt,
+__device__ SCANN_SP_FLUSH_INLINE void sp_flush_item_lanes(const uint32_t *__restrict__ codes_sp, uint32_t *__restrict__ cand32_cnt,
                                                         uint32_t *__restrict__ cand32, uint32_t *__restrict__ cand32_codes,
                                                         uint32_t cap32, const uint32_t *bits, uint2 *stage, uint32_t *s_fq,
                                                         uint32_t *s_fvb, uint32_t *s_fgb, uint32_t ntile, uint32_t c0,
@@ -1623,20 +1624,18 @@ __device__ SCANN_SP_FLUSH_INLINE void sp_flush_item(const uint32_t *__restrict__
                 const uint32_t e = e0 + lane + 64u * (uint32_t)u;
                 ent[u] = e < n ? stage[e] : make_uint2(0xFFFFFFFFu, 0u);
             }
-#ifndef SCANN_SP_EXPERIMENT
-#define SCANN_SP_EXPERIMENT 0   // timing experiments only (1: no row loads, 2: no row stores, 3: neither) -- wrong results
-#endif
-            if (cand32_codes && !(SCANN_SP_EXPERIMENT & 1)) {   // (wave-uniform)
+            if (cand32_codes) {   // (wave-uniform)
 #pragma unroll
                 for (int u = 0; u < (int)kSpU; ++u)
 #pragma unroll
                     for (int x = 0; x < SPW / 4; ++x)
                         cw[u][x] = reinterpret_cast<const uint4 *>(codes_sp + (size_t)(lb + c0 + (ent[u].y & 0xFFFFu)) * SPW)[x];
-            } else {
+            } else {   // (defined on every path: a conditionally initialised array stays in scratch memory -- 16 scratch
+                       // round trips per copy-out, 0.41 instead of 0.35 ms at C3)
 #pragma unroll
                 for (int u = 0; u < (int)kSpU; ++u)
 #pragma unroll
-                    for (int x = 0; x < SPW / 4; ++x) cw[u][x] = make_uint4(ent[u].x, ent[u].y, 0u, 0u);
+                    for (int x = 0; x < SPW / 4; ++x) cw[u][x] = make_uint4(0u, 0u, 0u, 0u);
             }
 #pragma unroll
             for (int u = 0; u < (int)kSpU; ++u) {
@@ -1646,7 +1645,7 @@ __device__ SCANN_SP_FLUSH_INLINE void sp_flush_item(const uint32_t *__restrict__
                     if (dst < cap32) {
                         const size_t o = (size_t)s_fq[c] * cap32 + dst;
                         cand32[o] = s_fvb[c] + c0 + (ent[u].y & 0xFFFFu);
-                        if (cand32_codes && !(SCANN_SP_EXPERIMENT & 2)) {
+                        if (cand32_codes) {
 #pragma unroll
                             for (int x = 0; x < SPW / 4; ++x) reinterpret_cast<uint4 *>(cand32_codes + o * SPW)[x] = cw[u][x];
                         }
@@ -1658,7 +1657,129 @@ __device__ SCANN_SP_FLUSH_INLINE void sp_flush_item(const uint32_t *__restrict__
     }
 }
 
-template <int S_>
+// The flush of adc_smfmac_kernel: the item's survivor bitmap -> the queries' lists.  The tile loop left word
+// [tt][h][col] = the masks of tiles 2 tt, 2 tt + 1 of lane (col, h).
+//   1. every lane counts the bits of its own words; the two lanes of a pair share ONE returning atomic for the pair's
+//      segment of the query's list (issued now, consumed in step 3);
+//   2. pair by pair, the 64 lanes take the pair's 64 words ONE WORD EACH: a DPP prefix sum gives every word its offset
+//      in the segment, and each lane stages (offset, pair, point) of its word's bits in LDS.  A pair whose every point
+//      passes (a query's nearest leaf in a tree index) costs 32 rounds here, not the 2048 a lane walking its own
+//      survivors one by one would need; a sparse pair (0.2 bits per word on a flat 1M index) costs two;
+//   3. whenever the stage is full (kSpStage entries) or the pairs are done, the 64 lanes copy the staged entries to the
+//      lists side by side, each with up to kSpU row loads in flight.  What travels with a position (flat hashers) is
+//      the point's PLANE row (codes_sp: the lines the tile loop has just read, still in L2 -- the packed codes were
+//      last touched at index creation); adc_refine_kernel decodes it (RefineArgs::planes).
+template <int S>
+__device__ SCANN_SP_FLUSH_INLINE void sp_flush_item_words(const uint32_t *__restrict__ codes_sp, uint32_t *__restrict__ cand32_cnt,
+                                                        uint32_t *__restrict__ cand32, uint32_t *__restrict__ cand32_codes,
+                                                        uint32_t cap32, const uint32_t *bits_w, uint2 *stage, uint32_t *s_fq,
+                                                        uint32_t *s_fvb, uint32_t *s_fgb, uint32_t ntile, uint32_t c0,
+                                                        uint32_t lb, uint32_t pq, uint32_t vb) {
+    constexpr int SPW = SpLayout<S>::SPW;
+    constexpr int TTM = (int)(kMfmaRange / 64);
+    static_assert(TTM == 32, "the flush maps the 64 words of a pair onto the 64 lanes");
+    const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
+    const uint32_t ntt = (ntile + 1u) >> 1;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int tt = 0; tt < TTM; ++tt) cnt += (uint32_t)tt < ntt ? (uint32_t)__popc(bits_w[tt * 64 + lane]) : 0u;
+    const uint32_t n_pair = cnt + (uint32_t)__shfl_xor((int)cnt, 32);   // (the same in both lanes of a pair)
+    if (!__any(n_pair != 0)) return;
+    uint32_t gbase = 0;
+    if (h == 0 && n_pair) gbase = atomicAdd(&cand32_cnt[pq], n_pair);   // (padding pairs have no bits)
+    if (lane < 32) {
+        s_fq[lane] = pq == kInvalid ? 0u : pq;
+        s_fvb[lane] = vb;
+    }
+    bool fgb_done = false;
+    // step 3: stage[0 .. n) -> the lists
+    auto copy_out = [&](uint32_t n) {
+        if (!fgb_done) {   // (wave-uniform; the atomics have travelled under the first pairs' staging)
+            if (lane < 32) s_fgb[lane] = gbase;
+            fgb_done = true;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t e0 = 0; e0 < n; e0 += 64u * kSpU) {
+            uint2 ent[kSpU];
+            uint4 cw[kSpU][SPW / 4];
+#pragma unroll
+            for (int u = 0; u < (int)kSpU; ++u) {
+                const uint32_t e = e0 + lane + 64u * (uint32_t)u;
+                ent[u] = e < n ? stage[e] : make_uint2(0xFFFFFFFFu, 0u);
+            }
+            if (cand32_codes) {   // (wave-uniform)
+#pragma unroll
+                for (int u = 0; u < (int)kSpU; ++u)
+#pragma unroll
+                    for (int x = 0; x < SPW / 4; ++x)
+                        cw[u][x] = reinterpret_cast<const uint4 *>(codes_sp + (size_t)(lb + c0 + (ent[u].y & 0xFFFFu)) * SPW)[x];
+            } else {   // (defined on every path: a conditionally initialised array stays in scratch memory -- 16 scratch
+                       // round trips per copy-out, 0.41 instead of 0.35 ms at C3)
+#pragma unroll
+                for (int u = 0; u < (int)kSpU; ++u)
+#pragma unroll
+                    for (int x = 0; x < SPW / 4; ++x) cw[u][x] = make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < (int)kSpU; ++u) {
+                if (ent[u].x != 0xFFFFFFFFu) {
+                    const uint32_t c = ent[u].y >> 16;
+                    const uint32_t dst = s_fgb[c] + ent[u].x;
+                    if (dst < cap32) {
+                        const size_t o = (size_t)s_fq[c] * cap32 + dst;
+                        cand32[o] = s_fvb[c] + c0 + (ent[u].y & 0xFFFFu);
+                        if (cand32_codes) {
+#pragma unroll
+                            for (int x = 0; x < SPW / 4; ++x) reinterpret_cast<uint4 *>(cand32_codes + o * SPW)[x] = cw[u][x];
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // step 2: lane = word (tt, hh) of the current pair
+    const uint32_t tt = lane & 31u, hh = lane >> 5;
+    const uint32_t woff = tt * 64u + hh * 32u;
+    const bool wok = tt < ntt;
+    auto jrel_of = [&](uint32_t bpos) {
+        const uint32_t r = 15u - (bpos & 15u);
+        return (2u * tt + (bpos >> 4)) * 32u + 4u * hh + (r & 3u) + ((r >> 2) << 3);
+    };
+    // (one copy_out site: the stage is filled with as many pairs -- or as much of a dense pair -- as fit, then copied)
+    uint32_t c = 0, r0 = 0;   // current pair; entries of it already copied out (a dense pair spans several rounds)
+    for (;;) {
+        uint32_t fill = 0;
+        while (c < 32u) {
+            const uint32_t n_c = (uint32_t)__builtin_amdgcn_readlane((int)n_pair, (int)c);
+            if (n_c == 0) {   // (wave-uniform)
+                ++c;
+                continue;
+            }
+            const uint32_t rem = n_c - r0;
+            if (fill && fill + min(rem, kSpStage) > kSpStage) break;   // no room: copy out first
+            const uint32_t take = min(rem, kSpStage - fill);           // entries [r0, r0 + take) of the pair's segment
+            const uint32_t w = wok ? bits_w[woff + c] : 0u;
+            const uint32_t p = (uint32_t)__popc(w);
+            uint32_t x = w, i = wave_incl_scan(p) - p;
+            while (x) {
+                const uint32_t bpos = (uint32_t)__ffs((int)x) - 1u;
+                x &= x - 1u;
+                if (i - r0 < take) stage[fill + i - r0] = make_uint2(i, (c << 16) | jrel_of(bpos));
+                ++i;
+            }
+            fill += take;
+            r0 += take;
+            if (r0 < n_c) break;   // a dense pair: the rest after this copy-out
+            ++c;
+            r0 = 0;
+        }
+        if (!fill) break;
+        copy_out(fill);
+    }
+}
+
+template <int S_, bool WORDS>   // WORDS: the word-parallel flush (tree indexes); else lanes walk their own words (flat)
 __device__ __forceinline__ void adc_smfmac_body(const TxhIndexDev &ix, const MfmaArgs &a) {
     typedef int v4i __attribute__((ext_vector_type(4)));
     typedef int v8i __attribute__((ext_vector_type(8)));
@@ -1867,24 +1988,30 @@ __device__ __forceinline__ void adc_smfmac_body(const TxhIndexDev &ix, const Mfm
 
         // ---- flush: the item's bitmap -> the queries' lists (sp_flush_item: its own function, so that its registers
         // are allocated apart from the tile loop's -- inlined, the loop spilled its table fragments)
-        sp_flush_item<S>(ix.codes_sp, a.cand32_cnt, a.cand32, a.cand32_codes, a.cap32, bits, s_stage[wave], s_fq[wave], s_fvb[wave],
-                         s_fgb[wave], ntile, c0, lb, pq, vb);
+        if constexpr (WORDS)
+            sp_flush_item_words<S>(ix.codes_sp, a.cand32_cnt, a.cand32, a.cand32_codes, a.cap32, &s_bits[wave][0][0], s_stage[wave],
+                                   s_fq[wave], s_fvb[wave], s_fgb[wave], ntile, c0, lb, pq, vb);
+        else
+            sp_flush_item_lanes<S>(ix.codes_sp, a.cand32_cnt, a.cand32, a.cand32_codes, a.cap32, bits, s_stage[wave], s_fq[wave],
+                                   s_fvb[wave], s_fgb[wave], ntile, c0, lb, pq, vb);
         tile = __builtin_amdgcn_readfirstlane(next_tile);
     }
 }
 
-// S <= 32: three waves per SIMD in SCANN_SP_VGPRS registers each.  Fewer than the 168 three waves could have: the
-// registers (and LDS) left over on every SIMD take a wave of ANOTHER kernel -- with two caller streams (scann_hip.h
-// "device entry points and streams") the HBM- and latency-bound kernels of one batch (sample, select, 8-bit row
-// filter, re-rank) run inside the matrix-core-bound scan of the next instead of behind it.
-template <int S_>
+// S <= 32: three waves per SIMD (the pair tile's table fragments alone are 64 registers); S = 48, 64: two.  (Capping the
+// registers at 144 to leave room for a wave of another stream's kernel was tried: amdgpu_num_vgpr is ignored by this
+// compiler, and two waves per SIMD -- SCANN_HIP_MFMA_WGS=2 -- cost the scan 10 % and gained the two-stream step nothing.)
+#ifndef SCANN_SP_VGPRS
+#define SCANN_SP_VGPRS 144
+#endif
+template <int S_, bool WORDS>
 __global__ __launch_bounds__(kMfmaWaves * 64, SCANN_MFMA_MINW) __attribute__((amdgpu_num_vgpr(SCANN_SP_VGPRS)))
 void adc_smfmac_kernel(TxhIndexDev ix, MfmaArgs a) {
-    adc_smfmac_body<S_>(ix, a);
+    adc_smfmac_body<S_, WORDS>(ix, a);
 }
-template <int S_>
+template <int S_, bool WORDS>
 __global__ __launch_bounds__(kMfmaWaves * 64, 2) void adc_smfmac_wide_kernel(TxhIndexDev ix, MfmaArgs a) {   // S = 48, 64
-    adc_smfmac_body<S_>(ix, a);
+    adc_smfmac_body<S_, WORDS>(ix, a);
 }
 
 // The prefilter with 16-pair tiles on v_mfma_i32_16x16x64_i8, for leaves scanned by 8-24 queries of the batch
@@ -4689,14 +4816,23 @@ static int launch_scan_stages(const TxhIndexDev &ix, const TxhWork &w, hipStream
             if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
             uint32_t mwgs = 4;   // workgroups per CU (4 waves each)
             if (const char *e = std::getenv("SCANN_HIP_MFMA_WGS")) mwgs = (uint32_t)std::max(1, std::atoi(e));
+            // the sparse kernel's flush: lanes walk their own words on flat hashers, word-parallel on tree indexes
+            // (SCANN_HIP_SP_WORDS = 0 / 1 forces a form)
+            bool words = !ix.ah_mode;
+            if (const char *e = std::getenv("SCANN_HIP_SP_WORDS")) words = std::atoi(e) != 0;
+            const dim3 mgrid((uint32_t)cus * mwgs), mblock(kMfmaWaves * 64);
             if (w.mfma == 2)
-                hipLaunchKernelGGL(adc_mfma16_kernel<C::S>, dim3((uint32_t)cus * mwgs), dim3(kMfmaWaves * 64), 0, st, ix, ma);
-            else if (w.mfma == 3 && C::S <= 32)
-                hipLaunchKernelGGL(adc_smfmac_kernel<C::S>, dim3((uint32_t)cus * mwgs), dim3(kMfmaWaves * 64), 0, st, ix, ma);
-            else if (w.mfma == 3)
-                hipLaunchKernelGGL(adc_smfmac_wide_kernel<C::S>, dim3((uint32_t)cus * mwgs), dim3(kMfmaWaves * 64), 0, st, ix, ma);
+                hipLaunchKernelGGL(adc_mfma16_kernel<C::S>, mgrid, mblock, 0, st, ix, ma);
+            else if (w.mfma != 3)
+                hipLaunchKernelGGL(adc_mfma_kernel<C::S>, mgrid, mblock, 0, st, ix, ma);
+            else if (C::S <= 32 && !words)
+                hipLaunchKernelGGL((adc_smfmac_kernel<C::S, false>), mgrid, mblock, 0, st, ix, ma);
+            else if (C::S <= 32)
+                hipLaunchKernelGGL((adc_smfmac_kernel<C::S, true>), mgrid, mblock, 0, st, ix, ma);
+            else if (!words)
+                hipLaunchKernelGGL((adc_smfmac_wide_kernel<C::S, false>), mgrid, mblock, 0, st, ix, ma);
             else
-                hipLaunchKernelGGL(adc_mfma_kernel<C::S>, dim3((uint32_t)cus * mwgs), dim3(kMfmaWaves * 64), 0, st, ix, ma);
+                hipLaunchKernelGGL((adc_smfmac_wide_kernel<C::S, true>), mgrid, mblock, 0, st, ix, ma);
             LAUNCH_CHECK();
             if (ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
             RefineArgs ra;
