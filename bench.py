@@ -582,9 +582,23 @@ def main():
         barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        kernel_ms, kernel_name = index.last_kernel_ms()
+        kernel_ms_timed, kernel_name = index.last_kernel_ms()
         index.enable_timing(False)
         device_status()
+        # The dominant kernel ALONE on the machine, for the roofline: with two caller streams the timed region runs
+        # kernels of consecutive batches side by side, so an event pair around one of them also measures its neighbours
+        # (C3: 0.52 ms inside the region, 0.35 ms alone; rocprofv3 --kernel-trace agrees with each in its own run).  A
+        # short single-stream pass after the timed region, same index, same batches, HIP events on the launch stream.
+        kernel_ms = kernel_ms_timed
+        if two_streams and not sharded:
+            index.enable_timing(True)
+            two_streams = False
+            for i in range(min(args.steps, 40)):
+                step(i)
+            torch.cuda.synchronize()
+            kernel_ms, _ = index.last_kernel_ms()
+            index.enable_timing(False)
+            two_streams = True
         break
     if nproc > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -757,6 +771,11 @@ def main():
                                        scanned, S, K, Q, k, pairs)
         if roof["frac"] > 1.0:
             roof["warning"] = "fraction above 1: the assumed bound is not the binding one"
+        if roof is not None:
+            roof["kernel_ms_in_timed_region"] = kernel_ms_timed
+            roof["timing"] = ("kernel_ms: HIP events around the kernel on its launch stream, mean over a single-stream pass "
+                              "run right after the timed region (the kernel alone on the machine); kernel_ms_in_timed_region: "
+                              "the same events inside the timed region, where two caller streams overlap consecutive batches")
         line = {
             "metric": METRIC, "value": qps, "unit": "queries/s", "n_gpus": nproc, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "timed_region_s": elapsed,

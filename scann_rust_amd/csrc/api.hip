@@ -916,8 +916,11 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
         // call keeps the dense instruction: tests compare the two) -- and takes over from 8 pairs per leaf, whatever
         // m / stream is: at 10M x 128, 1000 leaves, 1024 queries, P = 10 (10 pairs per leaf: tiles a third full)
         // m = 1000 / 4000 / 8192 run 0.68 / 0.95 / 1.29 ms per step on it against 0.88 / 1.09 / 1.61 ms on the 16-pair
-        // dense form / the f32 gather scan the rules above pick.
-        if (mfma_ok && t.codes_sp && quads_per_leaf >= 2) {
+        // dense form / the f32 gather scan the rules above pick (P = 25 / 50 / 100 at m = 1000: 0.94 / 1.11 / 1.44 ms
+        // against round 2's 1.12 / 1.41 / 1.91).
+        // (long leaves only -- an item is up to 2048 points of a leaf, and its fixed costs, the table fragments and the
+        // flush, want most of that: at 1M x 128 / 1000 leaves of 1000 points the gather scan's 0.08 ms beats 0.13 ms)
+        if (mfma_ok && t.codes_sp && quads_per_leaf >= 2 && t.n_local / std::max(1u, L) >= 4096) {
             const char *e = std::getenv("SCANN_HIP_SMFMAC");
             const char *f = std::getenv("SCANN_HIP_MFMA");
             if (!(e && std::atoi(e) == 0) && !(f && (std::atoi(f) == 0 || std::atoi(f) == 3))) w->mfma = 3u;
