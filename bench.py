@@ -692,7 +692,7 @@ def main():
         gi = last_out[0].cpu().numpy().view(np.uint32)
         gd = last_out[1].cpu().numpy()
         ok = True
-        for i in range(4):
+        for i in range(min(4, Q)):
             if args.workload == "bf_dot":
                 oi, od = orc.bf_search(data, n, dim, stride, orc.DOT_PRODUCT, last_q[i], k)
             elif args.workload == "txh":

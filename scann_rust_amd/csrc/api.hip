@@ -59,7 +59,8 @@ struct TxhWorkspace {
     WsBuf queries, cdist, tokens, token_dists, vbase, leaf_cnt, leaf_cursor, pair_off, tile_off,
         counters, pair_q, pair_leaf, pair_vbase, pair_thr, slot_of, lutq, thr, cand_cnt, cand, cand_key,
         cand_idx, cand_dist, cand_exact, cand_row, cand_count, out_idx, out_dist, out_count, allow,
-        sbase, pair_sbase, stile_off, samp, lut8, lut8_meta, cand32, cand32_codes, cand32_cnt, mfma_thr1, rr_lb, rr_ub, small_tickets;
+        sbase, pair_sbase, stile_off, samp, lut8, lut8_meta, cand32, cand32_codes, cand32_cnt, mfma_thr1, rr_lb, rr_ub, small_tickets,
+          wide_min, wide_ckey, wide_ceb, wide_cidx, wide_cnt;
     void *arena = nullptr;
     size_t arena_bytes = 0;
     bool dirty = false;
@@ -74,7 +75,8 @@ struct TxhWorkspace {
                         &counters, &pair_q, &pair_leaf, &pair_vbase, &pair_thr, &slot_of, &lutq, &thr, &cand_cnt, &cand,
                         &cand_key, &cand_idx, &cand_dist, &cand_exact, &cand_row, &cand_count, &out_idx, &out_dist,
                         &out_count, &allow, &sbase, &pair_sbase, &stile_off, &samp, &lut8, &lut8_meta, &cand32,
-                        &cand32_codes, &cand32_cnt, &mfma_thr1, &rr_lb, &rr_ub, &small_tickets};
+                        &cand32_codes, &cand32_cnt, &mfma_thr1, &rr_lb, &rr_ub, &small_tickets,
+                        &wide_min, &wide_ckey, &wide_ceb, &wide_cidx, &wide_cnt};
         for (WsBuf *b : all) f(*b);
     }
     void want(WsBuf &b, size_t bytes) {
@@ -706,7 +708,8 @@ struct TxhCallParams {
     uint32_t P, m, k, cap, st, scap;
     int exact_reorder;
     int no_threshold;
-    int small;   // small-batch pipeline (txh.hip "Small batches")
+    int small;   // small-batch pipeline (txh.hip "Small batches"); 2 = the wide one ("Few queries, long streams")
+    uint32_t wide_cap2;
 };
 
 static uint64_t max_stream(const scann_hip_index *ix, uint32_t P) {
@@ -716,7 +719,7 @@ static uint64_t max_stream(const scann_hip_index *ix, uint32_t P) {
 }
 
 static int resolve_params(const scann_hip_index *ix, uint32_t k, const scann_hip_search_opts *o,
-                          bool full_cap, TxhCallParams *out, uint32_t nq = 0xFFFFFFFFu) {
+                          bool full_cap, TxhCallParams *out, uint32_t nq = 0xFFFFFFFFu, bool allow_wide = true) {
     scann_hip_search_opts def;
     scann_hip_search_opts_default(&def);
     if (!o) o = &def;
@@ -754,6 +757,23 @@ static int resolve_params(const scann_hip_index *ix, uint32_t k, const scann_hip
     const bool small_on = small_batch_enabled();
     out->small = (small_on && nq <= kSmallBatch && !ix->sharded && m <= kSmallMaxCandidates &&
                   k <= 64 && ms <= kSmallMaxStream && ix->tx.L <= 4096) ? 1 : 0;
+    // Fewer queries still, over a long stream: the wide pipeline (three launches, every stage spread over the chip).
+    // Its scan rebuilds the tables per leaf inside a workgroup of 1024 stream positions: leaves of >= 512 points
+    // (or one leaf, or an exact scan).  Streams of >= 8 m points: below that most of the stream is candidates anyway.
+    // SCANN_HIP_WIDE: 0 = never, 2 = whenever the limits allow (tests), else from kWideMinStream points.
+    out->wide_cap2 = 0;
+    {
+        int mode = 1;
+        if (const char *e = std::getenv("SCANN_HIP_WIDE")) mode = std::atoi(e);
+        const bool limits = small_on && allow_wide && mode != 0 && nq <= kWideBatch && !ix->sharded && m >= 1 &&
+                            m <= kWideMaxCandidates && k <= 64 && ms <= kWideMaxStream && ix->tx.L <= 4096 && P <= 512;
+        const bool long_leaves = ix->tx.exact_scan || P == 1 || ix->tx.n_local / std::max(1u, ix->tx.L) >= 512;
+        const bool pays = ms >= kWideMinStream && ms >= 8ull * m && long_leaves;
+        if (limits && (mode == 2 || pays)) {
+            out->small = 2;
+            out->wide_cap2 = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(ms, 2ull * m + 1024), 16384);
+        }
+    }
     if (out->small) full_cap = true;
     uint64_t cap = ms;
     if (!full_cap) {
@@ -966,6 +986,13 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
         w->cap32 = (uint32_t)cap32;
     }
     if (p.small) s.want(s.small_tickets, 64 * 4);
+    if (p.small == 2) {
+        s.want(s.wide_min, (size_t)nq * p.cap * 4);
+        s.want(s.wide_ckey, (size_t)nq * p.wide_cap2 * 8);
+        s.want(s.wide_ceb, (size_t)nq * p.wide_cap2 * 4);
+        s.want(s.wide_cidx, (size_t)nq * p.wide_cap2 * 4);
+        s.want(s.wide_cnt, 64 * 4);
+    }
     SCANN_TRY(s.commit());
     w->queries = s.queries.as<float>();
     w->cdist = s.cdist.as<float>();
@@ -985,6 +1012,16 @@ static int ensure_txh_workspace(scann_hip_index *ix, TxhWorkspace &s, uint32_t n
         w->cand32_cnt = s.cand32_cnt.as<uint32_t>();
     }
     if (p.small) w->small_tickets = s.small_tickets.as<uint32_t>();
+    w->wide_cap2 = p.wide_cap2;
+    w->wide_min = w->wide_ceb = w->wide_cidx = w->wide_cnt = nullptr;
+    w->wide_ckey = nullptr;
+    if (p.small == 2) {
+        w->wide_min = s.wide_min.as<uint32_t>();
+        w->wide_ckey = s.wide_ckey.as<uint64_t>();
+        w->wide_ceb = s.wide_ceb.as<uint32_t>();
+        w->wide_cidx = s.wide_cidx.as<uint32_t>();
+        w->wide_cnt = s.wide_cnt.as<uint32_t>();
+    }
     w->sbase = s.sbase.as<uint32_t>();
     w->pair_sbase = s.pair_sbase.as<uint32_t>();
     w->stile_off = s.stile_off.as<uint32_t>();
@@ -1188,7 +1225,7 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
     SCANN_TRY(set_device(ix->ctx));
     for (int attempt = 0; attempt < 2; ++attempt) {
         TxhCallParams p;
-        SCANN_TRY(resolve_params(ix, k, opts, /*full_cap=*/attempt == 1, &p, nq));
+        SCANN_TRY(resolve_params(ix, k, opts, /*full_cap=*/attempt == 1, &p, nq, /*allow_wide=*/attempt == 0));
         if (p.m == 0) {  // nothing can be kept (reference panics on FastTopNeighbors::new(0))
             fill_empty(nq, k, out_idx, out_dist, out_count);
             if (opts && opts->cand_count) std::memset(opts->cand_count, 0, (size_t)nq * 4);
@@ -1225,13 +1262,18 @@ static int txh_search_host(scann_hip_index *ix, const float *queries, uint32_t n
                                         sl.primary ? ix->ev1 : nullptr));
             if (sl.primary) {
                 ix->timing_valid = ix->timing;
-                ix->timed_kernel = "small_scan_kernel";
+                ix->timed_kernel = w.small == 2 ? "wide_scan_kernel" : "small_scan_kernel";
             }
             SCANN_TRY(wait_small_done(stream, reinterpret_cast<const volatile uint32_t *>(hp + off_flag), nq, seq));
+            if (w.small == 2) {   // the wide pipeline's compact arrays can overflow: count row 0xFFFFFFFF -> the batched pipeline
+                bool overflow = false;
+                for (uint32_t i = 0; i < nq; ++i) overflow = overflow || reinterpret_cast<const uint32_t *>(hp + off_cnt)[i] == 0xFFFFFFFFu;
+                if (overflow) continue;
+            }
             std::memcpy(out_idx, hp + off_idx, ob);
             std::memcpy(out_dist, hp + off_dist, ob);
             std::memcpy(out_count, hp + off_cnt, (size_t)nq * 4);
-            return SCANN_HIP_OK;   // (dense candidate lists: this pipeline has no overflow / retry case)
+            return SCANN_HIP_OK;   // (dense candidate lists: the three-launch / one-launch forms have no overflow / retry case)
         }
         if (opts && opts->allow_bitmap) {   // search_with_filter(Some(allow-list))
             SCANN_HIP_CHECK(hipMemcpyAsync(ws.allow.p, opts->allow_bitmap, allow_words * 8,

@@ -39,6 +39,11 @@ constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 constexpr uint32_t kSmallBatch = 16;                      // queries per call the small-batch pipeline takes
 constexpr uint32_t kSmallMaxStream = 262144;              // ... longest candidate stream (points) it takes
 constexpr uint32_t kSmallMaxCandidates = 1024;            // ... largest pre_reorder_k
+// the wide few-query pipeline (txh.hip "Few queries, long streams"): three launches, every stage spread over the chip
+constexpr uint32_t kWideBatch = 4;                        // queries per call it takes
+constexpr uint32_t kWideMaxStream = 4u << 20;             // ... longest candidate stream (points)
+constexpr uint32_t kWideMaxCandidates = 8192;             // ... largest pre_reorder_k
+constexpr uint32_t kWideMinStream = 32768;                // ... and the stream from which it replaces the pipeline above
 
 // ---- threshold sampling plan (shared by host buffer sizing and the device kernels) ----
 // Every st-th point of each selected leaf is scored ahead of the scan (adc_sample_kernel,
@@ -155,6 +160,13 @@ struct TxhWork {
     uint32_t *small_done;      // small-batch host calls: [nq] pinned completion flags (or nullptr) ...
     uint32_t small_seq;        // ... and the value the finish kernel stores there after the result rows
     uint32_t *small_tickets;   // [kSmallBatch] ticket counters of the one-launch pipeline (zero between launches)
+    // small == 2: the wide few-query pipeline
+    uint32_t wide_cap2;        // entries per query of the compact candidate arrays
+    uint32_t *wide_min;        // [nq][cap] ordered approximate distance: minimum of each group of stream positions
+    uint64_t *wide_ckey;       // [nq][wide_cap2] merge keys of the candidates under the pivot ...
+    uint32_t *wide_ceb;        // ... their ordered exact distances (approximate ones without re-ordering) ...
+    uint32_t *wide_cidx;       // ... and datapoint indices
+    uint32_t *wide_cnt;        // [nq] entries appended
     uint32_t cap32;
     uint32_t *sbase;           // [nq][P+2] prefix of per-leaf sample counts; [P]=samples, [P+1]=local points
     uint32_t *pair_sbase;      // [max_slots]

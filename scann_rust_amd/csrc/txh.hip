@@ -4713,6 +4713,17 @@ static int set_dyn_lds(F kernel, size_t bytes) {
     return SCANN_HIP_OK;
 }
 
+// The same for a kernel that also holds `static_bytes` of static LDS arrays: the attribute bounds the DYNAMIC part, and
+// static + dynamic may not exceed the CU's 160 KB (again one constant per kernel).
+template <typename F>
+static int set_dyn_lds_with_static(F kernel, size_t bytes, size_t static_bytes) {
+    constexpr size_t kMaxLds = 160 * 1024;
+    if (bytes + static_bytes > kMaxLds) return fail(SCANN_HIP_RESOURCE_EXHAUSTED, "kernel needs more than 160 KB of LDS");
+    SCANN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(kMaxLds - static_bytes)));
+    return SCANN_HIP_OK;
+}
+
 static int launch_partition_stage(const TxhIndexDev &ix, const TxhWork &w, hipStream_t st) {
     if (ix.ah_mode) {
         hipLaunchKernelGGL(ah_tokens_kernel, dim3(ceil_div_u32(w.nq, 256)), dim3(256), 0, st, w.nq,
@@ -4933,6 +4944,16 @@ static int launch_exact_scan(const TxhIndexDev &ix, const TxhWork &w, hipStream_
 constexpr uint32_t kFusedChunk = kSelectThreads;   // stream positions per workgroup
 constexpr uint32_t kFusedMaxWgs = 512;              // nq x workgroups per query above which three launches are used
 
+// Wide pipeline: stream positions per group minimum for a stream of cnt keys and m wanted candidates -- the largest
+// power of two <= 64 that leaves >= 3 m groups (the pivot, the m-th smallest group minimum, then lets ~1.2 m keys
+// pass), 1 for streams under 6 m (the pivot is then the m-th smallest distance itself).  Chosen on the device from
+// the query's OWN stream: leaves differ in size by an order of magnitude and the host only knows the longest stream.
+__host__ __device__ static inline uint32_t wide_group(uint32_t cnt, uint32_t m) {
+    uint32_t g = 64;
+    while (g > 1 && (uint64_t)cnt / g < 3ull * m) g >>= 1;
+    return g;
+}
+
 struct FusedArgs {
     uint32_t L, n_pow2, p_pow2, st;
     float *cdist, *token_dists;
@@ -5080,9 +5101,657 @@ __global__ __launch_bounds__(kSelectThreads) void small_fused_kernel(TxhIndexDev
     small_finish_body<true>(ix, a, q, reinterpret_cast<float *>(s_dyn), s_vb, s_tok);
 }
 
+// =====================================================================================
+// Few queries, long streams: the wide pipeline (TxhWork::small == 2).
+//
+// The small-batch pipeline above finishes a query in ONE workgroup: two passes over the dense key list, then m
+// row gathers -- 0.1 ms for 100 k keys and m = 1000, and pre_reorder_k is capped by the workgroup's LDS.  One
+// query over the flat 1M hasher at m = 5000 (the reference's ann_benchmark operating point,
+// bin/ann_benchmark.rs:172-178) fell back to the batched pipeline's twelve launches.  Here every stage is
+// spread over the chip, in three launches:
+//   1. wide_scan_kernel: leaf selection + scan as in small_fused_kernel; every group of g stream positions
+//      (wide_group: from the query's own stream length) also leaves its minimum approximate distance.
+//   2. wide_filter_kernel: a few dozen workgroups per query.  Each derives the same pivot -- the m-th smallest
+//      group minimum, which is >= the m-th smallest key's distance (the m smallest minima belong to m distinct
+//      points) and, with >= 3 m groups, lets ~1.2 m keys pass -- filters its share of the key list, decodes
+//      the passing keys, scores their rows exactly (exact_pair_8lanes) and appends (key, exact, index) to the
+//      query's compact arrays (one global atomic per batch of candidates).
+//   3. wide_final_kernel: a workgroup per query: the m-th smallest key among the entries (the candidates of
+//      mod.rs:283-293: everything above it drops out), then the k best of those by (exact, merge key)
+//      (mod.rs:342-364) through block_select -- exact under any number of ties.
+// Same keys, same arithmetic, same tie order as the other pipelines: rows are identical.  If the compact arrays
+// overflow (thousands of points tied at the pivot's distance: a dataset of few distinct code rows) the status word
+// says RESOURCE_EXHAUSTED and a host call's count row 0xFFFFFFFF; the host entry repeats the call on the batched
+// pipeline.
+// =====================================================================================
+constexpr uint32_t kWideList = 2048;        // passing keys a workgroup of the filter collects per batch
+
+struct WideArgs {
+    uint32_t ng_stride, cap2, wgs;
+    const uint32_t *mins;
+    uint64_t *ckey;
+    uint32_t *ceb, *cidx, *ccnt;
+};
+
+// Bin of 1-based rank `rank` in a complete kSelBinsMax-bin histogram in LDS (counts synchronised by the caller; the
+// histogram holds >= rank entries).  Every thread of a kSelectThreads block calls; two barriers; s_w: LDS u32[>= 49].
+__device__ __forceinline__ uint32_t block_hist_rank_bin(const uint32_t *s_hist, uint32_t *s_w, uint32_t rank) {
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    constexpr uint32_t per = kSelBinsMax / kSelectThreads;   // bins per thread
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < per; ++j) mine += s_hist[tid * per + j];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+        if ((int)lane >= o) incl += up;
+    }
+    if (lane == 63) s_w[32 + wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t w2 = 0; w2 < wave; ++w2) wbase += s_w[32 + w2];
+    incl += wbase;
+    const uint32_t excl = incl - mine;
+    if (excl < rank && rank <= incl) {   // exactly one thread
+        uint32_t c = excl;
+#pragma unroll
+        for (uint32_t j = 0; j < per; ++j) {
+            c += s_hist[tid * per + j];
+            if (c >= rank) {
+                s_w[48] = tid * per + j;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    return s_w[48];
+}
+
+// Launch 1: leaf selection (every workgroup repeats it, as in small_fused_kernel) and the scan of
+// [v0, v0 + chunk) stream positions per workgroup -- for ADC scans up to kWideRep positions per thread, so that a
+// workgroup's table build (and its four dependent round trips) is shared by 4096 points and one wave of workgroups
+// covers a 1M stream -- plus the group minima.
+constexpr int kWideRep = 4;
+
+__global__ __launch_bounds__(kSelectThreads) void wide_scan_kernel(TxhIndexDev ix, SmallArgs a, FusedArgs f, WideArgs wa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // selection | scan tables | query
+    __shared__ uint32_t s_tok[kDecodeStage], s_vb[kDecodeStage + 1], s_lrow[kDecodeStage];
+    const uint32_t q = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, nt = kSelectThreads;
+    const uint32_t P = a.P, dim = ix.dim;
+    if (q == 0 && b == 0 && tid == 0) a.counters[CNT_STATUS] = 0;
+    if (b == 0 && tid == 0) wa.ccnt[q] = 0;
+    if (ix.ah_mode) {
+        if (tid == 0) {
+            s_tok[0] = 0;
+            s_vb[0] = 0;
+            s_vb[1] = ix.leaf_gsize[0];
+            if (b == 0) {   // (ah_tokens_kernel)
+                const uint32_t sz = ix.leaf_off[1] - ix.leaf_off[0];
+                f.tokens[q] = 0;
+                f.token_dists[q] = 0.0f;
+                f.vbase[2 * q] = 0;
+                f.vbase[2 * q + 1] = ix.leaf_gsize[0];
+                f.sbase[3 * q] = 0;
+                f.sbase[3 * q + 1] = (sz + f.st - 1) / f.st;
+                f.sbase[3 * q + 2] = sz;
+            }
+        }
+    } else {
+        select_leaves_body(reinterpret_cast<uint64_t *>(s_dyn), q, b == 0, s_tok, s_vb, f.cdist, f.L, f.n_pow2, P,
+                           f.p_pow2, ix.leaf_gsize, ix.leaf_off, f.st, f.tokens, f.token_dists, f.vbase, f.sbase,
+                           ix.centers_t, a.queries, a.q_stride, dim, ix.centers_pitch);
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < P; r += nt) s_lrow[r] = ix.leaf_off[s_tok[r]];
+    const uint32_t cnt = min(s_vb[P], a.cap);
+    const uint32_t chunk = a.chunk;   // stream positions per workgroup: <= nt for exact scans, nt * rep for ADC scans
+    const uint32_t v0 = b * chunk;
+    if (v0 >= cnt) return;            // an idle workgroup (block-uniform)
+    __syncthreads();
+    const uint32_t g = wide_group(cnt, a.m);
+    uint32_t *mins = const_cast<uint32_t *>(wa.mins) + (size_t)q * wa.ng_stride;
+    uint64_t *out = a.cand + (size_t)q * a.cap;
+    auto leaf_of = [&](uint32_t v) {
+        uint32_t lo = 0, hi = P;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_vb[mid] <= v) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    // minimum of every group of g positions (a group lies inside one wave) -> mins[v / g]
+    auto group_min = [&](uint32_t d32, uint32_t v, bool slot) {
+        for (uint32_t o = 1; o < g; o <<= 1) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)d32, (int)o);
+            d32 = other < d32 ? other : d32;
+        }
+        if (slot && (tid & (g - 1u)) == 0 && v < cnt) mins[v / g] = d32;
+    };
+    if (ix.exact_scan) {
+        float *s_qe = reinterpret_cast<float *>(s_dyn);
+        for (uint32_t d = tid; d < dim; d += nt) s_qe[d] = a.queries[(size_t)q * a.q_stride + d];
+        __syncthreads();
+        const uint32_t v = v0 + tid;
+        const bool have = tid < chunk && v < cnt;
+        uint64_t key = SCANN_KEY_MAX;
+        if (have) {
+            const uint32_t r = leaf_of(v), csr = s_lrow[r] + (v - s_vb[r]);
+            const float *row = ix.rows + (size_t)(ix.rows_csr ? csr : ix.leaf_ids[csr]) * ix.stride;
+            key = make_key(exact_pair_thread(ix.measure, dim, s_qe, row), v);
+            out[v] = key;
+        }
+        group_min((uint32_t)(key >> 32), v, tid < chunk);
+        return;
+    }
+    const uint32_t S = ix.S, K = ix.K, dsub = ix.dsub, kp = ix.kp;
+    float *s_lut = reinterpret_cast<float *>(s_dyn), *s_qr = s_lut + S * kp;
+    const uint32_t vz = min(v0 + chunk, cnt);                      // end of this workgroup's positions
+    const uint32_t r_first = leaf_of(v0), r_last = leaf_of(vz - 1u);
+    const uint32_t bits = ix.code_bits, per = 32u / bits, mask = (1u << bits) - 1u, nw = ix.nw;
+    const bool fast4 = bits == 4 && nw <= 4 && S == nw * 8u;       // whole words of eight 4-bit codes
+    uint32_t d32[kWideRep];
+#pragma unroll
+    for (int it = 0; it < kWideRep; ++it) d32[it] = 0xFFFFFFFFu;   // (no position / rejected by the restrict filter: absent)
+    for (uint32_t rr = r_first; rr <= r_last; ++rr) {
+        if (s_vb[rr + 1] == s_vb[rr]) continue;   // an empty leaf (uniform)
+        const uint32_t leaf = s_tok[rr];
+        for (uint32_t d = tid; d < dim; d += nt) {   // residual q - centroid (mod.rs:309-316)
+            float x = a.queries[(size_t)q * a.q_stride + d];
+            if (ix.use_residuals) x = x - ix.centers[(size_t)leaf * dim + d];
+            s_qr[d] = x;
+        }
+        // this leaf's share of the positions: their code words travel while the tables are built
+        const uint32_t la = max(v0, s_vb[rr]), lz = min(vz, s_vb[rr + 1]);
+        uint32_t cw[kWideRep][4];
+        bool in[kWideRep];
+#pragma unroll
+        for (int it = 0; it < kWideRep; ++it) {
+            const uint32_t v = v0 + (uint32_t)it * nt + tid;
+            in[it] = v >= la && v < lz;
+#pragma unroll
+            for (int wi = 0; wi < 4; ++wi) cw[it][wi] = 0;
+            if (fast4 && in[it]) {
+                const uint32_t *w = ix.codes + (size_t)(s_lrow[rr] + (v - s_vb[rr])) * nw;
+#pragma unroll
+                for (int wi = 0; wi < 4; ++wi)
+                    if ((uint32_t)wi < nw) cw[it][wi] = w[wi];
+            }
+        }
+        __syncthreads();
+        for (uint32_t e = tid; e < S * kp; e += nt) {   // LookupTable::from_query (lut.rs:47-70, codebook.rs:98-115)
+            const uint32_t sub = e / kp, c = e - sub * kp;
+            float acc = 0.0f;
+            if (c < K) {
+                const float *cb = ix.codebook + ((size_t)sub * K + c) * dsub;
+                for (uint32_t d = 0; d < dsub; ++d) {
+                    const float t = s_qr[sub * dsub + d] - cb[d];
+                    acc = acc + t * t;
+                }
+            }
+            s_lut[e] = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kWideRep; ++it) {
+            if (!in[it]) continue;
+            const uint32_t v = v0 + (uint32_t)it * nt + tid;
+            const uint32_t csr = s_lrow[rr] + (v - s_vb[rr]);
+            float acc = 0.0f;   // LookupTable::compute_distance (lut.rs:74-82): 0.0 + lut[0][c0] + lut[1][c1] ...
+            if (fast4) {
+#pragma unroll
+                for (int wi = 0; wi < 4; ++wi) {
+                    if ((uint32_t)wi >= nw) break;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float tv = s_lut[((uint32_t)wi * 8u + (uint32_t)j) * kp + ((cw[it][wi] >> (4 * j)) & 15u)];
+                        acc = (wi == 0 && j == 0) ? tv : acc + tv;
+                    }
+                }
+            } else {
+                const uint32_t *w = ix.codes + (size_t)csr * nw;
+                for (uint32_t sub = 0; sub < S; ++sub) {
+                    const uint32_t code = (w[sub / per] >> (bits * (sub % per))) & mask;
+                    const float tv = s_lut[sub * kp + code];
+                    acc = sub == 0 ? tv : acc + tv;
+                }
+            }
+            const uint64_t key = row_allowed(ix, a.allow, a.allow_bits, csr) ? make_key(acc, v) : SCANN_KEY_MAX;
+            out[v] = key;
+            d32[it] = (uint32_t)(key >> 32);
+        }
+        __syncthreads();   // (the tables are rebuilt for the next leaf)
+    }
+#pragma unroll
+    for (int it = 0; it < kWideRep; ++it) {
+        if ((uint32_t)it * nt >= chunk) break;   // (uniform)
+        group_min(d32[it], v0 + (uint32_t)it * nt + tid, true);
+    }
+}
+
+__global__ __launch_bounds__(kSelectThreads) void wide_filter_kernel(TxhIndexDev ix, SmallArgs a, WideArgs wa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_wdyn[];   // [dim] query
+    __shared__ uint64_t s_pass[kWideList], s_slist[kSelListMax], s_red[48];
+    __shared__ uint32_t s_hist[kSelBinsMax], s_eb[kWideList], s_ix[kWideList], s_dvb[kDecodeStage + 1], s_drow[kDecodeStage];
+    __shared__ uint32_t s_n, s_base;
+    const uint32_t q = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, nt = kSelectThreads;
+    const uint32_t P = a.P, m = a.m;
+    const uint32_t *vbq = a.vbase + (size_t)q * (P + 1), *tokq = a.tokens + (size_t)q * P;
+    const uint32_t cnt = min(vbq[P], a.cap);
+    if ((uint64_t)b * nt >= cnt) return;   // no key block for this workgroup (block-uniform)
+    float *s_q = reinterpret_cast<float *>(s_wdyn);
+    for (uint32_t j = tid; j < ix.dim; j += nt) s_q[j] = a.queries[(size_t)q * a.q_stride + j];
+    for (uint32_t r = tid; r <= P; r += nt) {
+        s_dvb[r] = vbq[r];
+        if (r < P) s_drow[r] = ix.leaf_off[tokq[r]];
+    }
+    if (tid == 0) s_n = 0;
+    // (the first key blocks of this workgroup travel while the pivot is computed)
+    const uint64_t *list = a.cand + (size_t)q * a.cap;
+    constexpr int KP = 4;
+    uint64_t kpre[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        const uint64_t i = ((uint64_t)b + (uint64_t)j * wa.wgs) * nt + tid;
+        kpre[j] = i < cnt ? list[i] : SCANN_KEY_MAX;
+    }
+    // ---- the pivot (every workgroup of the query computes the same one): an upper bound of the m-th smallest group
+    // minimum -- the upper edge of its bin in a 4096-bin histogram over [min, max] of the minima.  One read of the
+    // minima (16 per thread, in registers), four barriers; the exact m-th minimum (block_select: a dozen barriers
+    // of 1024 threads, 9 us) would let a few dozen keys fewer pass.
+    uint32_t pivot = 0xFFFFFFFEu;
+    const uint32_t g = wide_group(cnt, m), ng = (cnt + g - 1u) / g;
+    if (cnt > m && ng >= m) {
+        const uint32_t *mins = wa.mins + (size_t)q * wa.ng_stride;
+        constexpr int RV = 16;
+        if (ng <= (uint32_t)RV * nt) {
+            uint32_t *s_w = reinterpret_cast<uint32_t *>(s_red);   // [0..15] min, [16..31] max, [32..47] present / scan, [48] bin
+            uint32_t mv[RV];
+            uint32_t vmin = 0xFFFFFFFFu, vmax = 0, present = 0;
+#pragma unroll
+            for (int e = 0; e < RV; ++e) {
+                const uint32_t i = (uint32_t)e * nt + tid;
+                mv[e] = ((uint32_t)e * nt < ng && i < ng) ? mins[i] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int e = 0; e < RV; ++e)
+                if (mv[e] != 0xFFFFFFFFu) {
+                    vmin = min(vmin, mv[e]);
+                    vmax = max(vmax, mv[e]);
+                    ++present;
+                }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                vmin = min(vmin, (uint32_t)__shfl_xor((int)vmin, o));
+                vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, o));
+                present += (uint32_t)__shfl_xor((int)present, o);
+            }
+            const uint32_t wave = tid >> 6, lane = tid & 63u;
+            if (lane == 0) {
+                s_w[wave] = vmin;
+                s_w[16 + wave] = vmax;
+                s_w[32 + wave] = present;
+            }
+            for (uint32_t i = tid; i < kSelBinsMax; i += nt) s_hist[i] = 0;
+            __syncthreads();
+            present = 0;
+            for (uint32_t w2 = 0; w2 < (nt >> 6); ++w2) {
+                vmin = min(vmin, s_w[w2]);
+                vmax = max(vmax, s_w[16 + w2]);
+                present += s_w[32 + w2];
+            }
+            __syncthreads();   // (s_w[32..] is reused by the scan)
+            if (present >= m) {   // block-uniform (else: fewer than m groups hold an allowed point, everything passes)
+                const uint32_t range = vmax - vmin;
+                uint32_t sh = 0;
+                while ((range >> sh) >= kSelBinsMax) ++sh;
+#pragma unroll
+                for (int e = 0; e < RV; ++e)
+                    if (mv[e] != 0xFFFFFFFFu) atomicAdd(&s_hist[(mv[e] - vmin) >> sh], 1u);
+                __syncthreads();
+                const uint32_t bin = block_hist_rank_bin(s_hist, s_w, m);
+                const uint64_t hi = (uint64_t)vmin + (((uint64_t)bin + 1u) << sh) - 1u;
+                pivot = hi > vmax ? vmax : (uint32_t)hi;
+                if (pivot == 0xFFFFFFFFu) pivot = 0xFFFFFFFEu;
+            }
+        } else {   // very long streams: the exact select, from L2
+            __syncthreads();
+            const uint32_t pv = block_select<uint32_t>(mins, ng, m, sel_cfg(ng), s_hist, reinterpret_cast<uint32_t *>(s_slist), s_red);
+            if (pv != 0xFFFFFFFFu) pivot = pv;   // (fewer than m groups hold an allowed point: everything passes)
+        }
+    }
+    __syncthreads();
+    // a batch of collected keys: decode, exact distance (8 lanes per candidate), append to the compact arrays
+    auto flush = [&]() {
+        const uint32_t n = min(s_n, kWideList);
+        for (uint32_t c0 = 0; c0 < n; c0 += nt / 8) {
+            const uint32_t c = c0 + (tid >> 3), lane8 = tid & 7u;
+            const bool act = c < n;
+            uint32_t idx = 0, rowi = 0;
+            uint64_t key = 0;
+            if (act) {
+                key = s_pass[c];
+                const uint32_t vpos = (uint32_t)key;
+                uint32_t lo = 0, hi = P;
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_dvb[mid] <= vpos) lo = mid; else hi = mid;
+                }
+                const uint32_t csr = s_drow[lo] + (vpos - s_dvb[lo]);
+                idx = ix.leaf_ids ? ix.leaf_ids[csr] : csr;
+                rowi = ix.rows_csr ? csr : idx;
+            }
+            float r = 0.0f;
+            if (a.exact_reorder) r = exact_pair_8lanes<16>(ix, s_q, ix.rows + (size_t)rowi * ix.stride, act, lane8);
+            if (act && lane8 == 0) {
+                s_ix[c] = idx;
+                s_eb[c] = a.exact_reorder ? f32_to_ordered(r) : (uint32_t)(key >> 32);
+            }
+        }
+        if (tid == 0) s_base = atomicAdd(&wa.ccnt[q], n);
+        __syncthreads();
+        const uint32_t base = s_base;
+        if (tid == 0 && base + n > wa.cap2) atomicExch(&a.counters[CNT_STATUS], (uint32_t)SCANN_HIP_RESOURCE_EXHAUSTED);
+        for (uint32_t i = tid; i < n; i += nt)
+            if (base + i < wa.cap2) {
+                const size_t e = (size_t)q * wa.cap2 + base + i;
+                wa.ckey[e] = s_pass[i];
+                wa.ceb[e] = s_eb[i];
+                wa.cidx[e] = s_ix[i];
+            }
+        __syncthreads();
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+    };
+    // ---- key blocks b, b + wgs, ...: interleaved, so that the near leaves' dense runs of passing keys are shared
+    uint32_t jb = 0;
+    for (uint64_t i0 = (uint64_t)b * nt; i0 < cnt; i0 += (uint64_t)wa.wgs * nt, ++jb) {
+        const uint32_t i = (uint32_t)i0 + tid;
+        uint64_t key = SCANN_KEY_MAX;
+        if (jb < (uint32_t)KP) {
+#pragma unroll
+            for (int j = 0; j < KP; ++j)
+                if (jb == (uint32_t)j) key = kpre[j];
+        } else if (i < cnt) {
+            key = list[i];
+        }
+        const bool keep = key != SCANN_KEY_MAX && (uint32_t)(key >> 32) <= pivot;
+        uint32_t wtot;
+        const uint32_t wpre = wave_prefix_count(keep, &wtot);
+        uint32_t base = 0;
+        if ((tid & 63u) == 0 && wtot) base = atomicAdd(&s_n, wtot);
+        base = (uint32_t)__shfl((int)base, 0);
+        if (keep) s_pass[base + wpre] = key;   // (s_n <= kWideList - nt before the block: never past the end)
+        __syncthreads();
+        const uint32_t collected = s_n;
+        __syncthreads();                       // (everyone has read it before the next block adds to it)
+        if (collected > kWideList - nt) flush();
+    }
+    __syncthreads();
+    if (s_n) flush();
+}
+
+__global__ __launch_bounds__(kSelectThreads) void wide_final_kernel(SmallArgs a, WideArgs wa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_fdyn[];   // u64[cap2]
+    __shared__ uint64_t s_slist[kSelListMax], s_red[48];
+    __shared__ uint32_t s_hist[kSelBinsMax], s_ce[64], s_cs[64], s_cn;
+    __shared__ uint64_t s_ck[64];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, nt = kSelectThreads, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t m = a.m, k = a.k;
+    uint64_t *s_v = reinterpret_cast<uint64_t *>(s_fdyn);
+    const bool polled = a.done != nullptr;
+    auto out_store = [&](auto *p, auto v) {
+        if (polled) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else *p = v;
+    };
+#ifdef SCANN_WIDE_TIMING
+    uint64_t tq[8];
+    int tqi = 0;
+#define WIDE_T() do { __syncthreads(); tq[tqi++] = wall_clock64(); } while (0)
+#else
+#define WIDE_T() do { } while (0)
+#endif
+    WIDE_T();
+    const uint32_t appended = wa.ccnt[q];
+    const bool overflow = appended > wa.cap2;
+    const uint32_t c2 = min(appended, wa.cap2);
+    const uint64_t *ckey = wa.ckey + (size_t)q * wa.cap2;
+    const uint32_t *ceb = wa.ceb + (size_t)q * wa.cap2, *cidx = wa.cidx + (size_t)q * wa.cap2;
+    const uint32_t nsel = min(c2, m), nout = overflow ? 0u : min(k, nsel);
+    if (nout) {
+        // entry e * nt + tid of the compact arrays lives in this lane's registers (cap2 <= 16 * nt)
+        constexpr int E0 = 16;
+        uint64_t kk[E0];
+        uint32_t eb[E0];
+#pragma unroll
+        for (int e = 0; e < E0; ++e) {
+            const uint32_t i = (uint32_t)e * nt + tid;
+            kk[e] = SCANN_KEY_MAX;
+            eb[e] = 0xFFFFFFFFu;
+            if ((uint32_t)e * nt < c2 && i < c2) {
+                kk[e] = ckey[i];
+                eb[e] = ceb[i];
+            }
+        }
+        WIDE_T();
+        // the candidates: the m smallest keys (mod.rs:283-293); everything above T drops out
+        uint64_t T = SCANN_KEY_MAX - 1;
+        if (c2 > m) {
+#pragma unroll
+            for (int e = 0; e < E0; ++e)
+                if ((uint32_t)e * nt < c2 && (uint32_t)e * nt + tid < c2) s_v[(uint32_t)e * nt + tid] = kk[e];
+            __syncthreads();
+            T = block_select<uint64_t>(s_v, c2, m, sel_cfg(c2), s_hist, s_slist, s_red);
+            __syncthreads();
+        }
+        WIDE_T();
+#pragma unroll
+        for (int e = 0; e < E0; ++e)
+            if (kk[e] > T) {
+                kk[e] = SCANN_KEY_MAX;
+                eb[e] = 0xFFFFFFFFu;
+            }
+        // the nout best by (exact, merge key) (mod.rs:342-364).  The entries are in registers: a 4096-bin histogram of
+        // the candidates' exact distances over [min, max] gives the bin of rank nout; the entries up to that bin's
+        // upper edge (nout and a few more: the low tail is sparse) go to a short list, which one wave ranks by
+        // counting.  More than 64 of them (heavy ties): the two-level tournament of small_finish_body instead.
+        uint32_t *s_w = reinterpret_cast<uint32_t *>(s_red);
+        uint32_t emin = 0xFFFFFFFFu, emax = 0;
+#pragma unroll
+        for (int e = 0; e < E0; ++e)
+            if ((uint32_t)e * nt < c2 && kk[e] != SCANN_KEY_MAX) {
+                emin = min(emin, eb[e]);
+                emax = max(emax, eb[e]);
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            emin = min(emin, (uint32_t)__shfl_xor((int)emin, o));
+            emax = max(emax, (uint32_t)__shfl_xor((int)emax, o));
+        }
+        if (lane == 0) {
+            s_w[wave] = emin;
+            s_w[16 + wave] = emax;
+        }
+        for (uint32_t i = tid; i < kSelBinsMax; i += nt) s_hist[i] = 0;
+        if (tid == 0) s_cn = 0;
+        __syncthreads();
+        for (uint32_t w2 = 0; w2 < (nt >> 6); ++w2) {
+            emin = min(emin, s_w[w2]);
+            emax = max(emax, s_w[16 + w2]);
+        }
+        uint32_t esh = 0;
+        while (((emax - emin) >> esh) >= kSelBinsMax) ++esh;
+#pragma unroll
+        for (int e = 0; e < E0; ++e)
+            if ((uint32_t)e * nt < c2 && kk[e] != SCANN_KEY_MAX) atomicAdd(&s_hist[(eb[e] - emin) >> esh], 1u);
+        __syncthreads();
+        const uint32_t ebin = block_hist_rank_bin(s_hist, s_w, nout);
+        const uint64_t ehi64 = (uint64_t)emin + (((uint64_t)ebin + 1u) << esh) - 1u;
+        const uint32_t ehi = ehi64 > emax ? emax : (uint32_t)ehi64;
+#pragma unroll
+        for (int e = 0; e < E0; ++e)
+            if ((uint32_t)e * nt < c2 && kk[e] != SCANN_KEY_MAX && eb[e] <= ehi) {
+                const uint32_t pos = atomicAdd(&s_cn, 1u);
+                if (pos < 64u) {
+                    s_ce[pos] = eb[e];
+                    s_ck[pos] = kk[e];
+                    s_cs[pos] = (uint32_t)e * nt + tid;
+                }
+            }
+        __syncthreads();
+        const uint32_t cn = s_cn;   // >= nout
+        WIDE_T();
+        if (cn <= 64u) {
+            if (tid < 64) {
+                const bool have = tid < cn;
+                const uint32_t ce = have ? s_ce[tid] : 0xFFFFFFFFu;
+                const uint64_t ck = have ? s_ck[tid] : SCANN_KEY_MAX;
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < cn; ++j) {
+                    const uint32_t oe = (uint32_t)__shfl((int)ce, (int)j);
+                    const uint64_t ok = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(ck >> 32), (int)j) << 32) |
+                                        (uint32_t)__shfl((int)(uint32_t)ck, (int)j);
+                    rank += (oe < ce || (oe == ce && ok < ck)) ? 1u : 0u;
+                }
+                if (have && rank < nout) {
+                    out_store(&a.out_idx[(size_t)q * k + rank], cidx[s_cs[tid]]);
+                    out_store(&a.out_dist[(size_t)q * k + rank], ordered_to_f32(ce));
+                }
+            }
+        } else {
+        __syncthreads();   // (the histogram and the select's list are reused below)
+        uint32_t *f_eb = s_hist, *f_sl = s_hist + kSelectThreads;
+        uint64_t *f_kk = s_slist;
+        for (uint32_t r0 = 0; r0 < nout; ++r0) {
+            uint32_t b_eb = 0xFFFFFFFFu, b_sl = 0xFFFFFFFFu;
+            uint64_t b_kk = SCANN_KEY_MAX;
+#pragma unroll
+            for (int e = 0; e < E0; ++e)
+                if ((uint32_t)e * nt < c2 && kk[e] != SCANN_KEY_MAX && (eb[e] < b_eb || (eb[e] == b_eb && kk[e] < b_kk))) {
+                    b_eb = eb[e];
+                    b_kk = kk[e];
+                    b_sl = (uint32_t)e * nt + tid;
+                }
+            wave_argmin96(b_eb, b_kk, b_sl);
+            if (b_kk == SCANN_KEY_MAX) b_sl = 0xFFFFFFFFu;   // (the wave's pool is empty)
+#pragma unroll
+            for (int e = 0; e < E0; ++e)
+                if ((uint32_t)e * nt < c2 && (uint32_t)e * nt + tid == b_sl) {
+                    kk[e] = SCANN_KEY_MAX;
+                    eb[e] = 0xFFFFFFFFu;
+                }
+            if (lane == 0) {
+                f_eb[wave * nout + r0] = b_eb;
+                f_kk[wave * nout + r0] = b_kk;
+                f_sl[wave * nout + r0] = b_sl;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            constexpr int E = kSelectThreads / 64;
+            const uint32_t nfin = (nt >> 6) * nout;           // <= 16 * 64
+            uint32_t feb[E], fsl[E];
+            uint64_t fkk[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t j = (uint32_t)e * 64u + tid;
+                const bool ok = j < nfin && f_sl[j] != 0xFFFFFFFFu;
+                feb[e] = ok ? f_eb[j] : 0xFFFFFFFFu;
+                fkk[e] = ok ? f_kk[j] : SCANN_KEY_MAX;
+                fsl[e] = ok ? f_sl[j] : 0xFFFFFFFFu;
+            }
+            uint32_t my_eb = 0xFFFFFFFFu, my_sl = 0xFFFFFFFFu;   // lane r0 keeps round r0's winner
+            for (uint32_t r0 = 0; r0 < nout; ++r0) {
+                uint32_t b_eb = 0xFFFFFFFFu, b_sl = 0xFFFFFFFFu;
+                uint64_t b_kk = SCANN_KEY_MAX;
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if ((uint32_t)e * 64u < nfin && fsl[e] != 0xFFFFFFFFu &&
+                        (feb[e] < b_eb || (feb[e] == b_eb && fkk[e] < b_kk))) {
+                        b_eb = feb[e];
+                        b_kk = fkk[e];
+                        b_sl = fsl[e];
+                    }
+                wave_argmin96(b_eb, b_kk, b_sl);
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if ((uint32_t)e * 64u < nfin && fsl[e] == b_sl) {   // (entry slots are unique: exactly one lane, one entry)
+                        feb[e] = 0xFFFFFFFFu;
+                        fkk[e] = SCANN_KEY_MAX;
+                        fsl[e] = 0xFFFFFFFFu;
+                    }
+                if (tid == r0) {
+                    my_eb = b_eb;
+                    my_sl = b_sl;
+                }
+            }
+            if (tid < nout) {   // the winners' datapoint indices: one parallel round trip
+                out_store(&a.out_idx[(size_t)q * k + tid], cidx[my_sl]);
+                out_store(&a.out_dist[(size_t)q * k + tid], ordered_to_f32(my_eb));
+            }
+        }
+        }
+    }
+    WIDE_T();
+#ifdef SCANN_WIDE_TIMING
+    if (tid == 0 && nout) printf("final: c2 %u load %.2f select %.2f shortlist %.2f rank %.2f us\n", c2, (tq[1] - tq[0]) * 0.01, (tq[2] - tq[1]) * 0.01, (tq[3] - tq[2]) * 0.01, (tq[4] - tq[3]) * 0.01);
+#endif
+    for (uint32_t i = nout + tid; i < k; i += nt) {
+        out_store(&a.out_idx[(size_t)q * k + i], kInvalid);
+        out_store(&a.out_dist[(size_t)q * k + i], __builtin_inff());
+    }
+    if (tid == 0) out_store(&a.out_count[q], overflow ? (polled ? 0xFFFFFFFFu : 0u) : nout);   // (host calls: repeat on the batched pipeline)
+    if (a.done) {   // (see small_finish_body)
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&a.done[q], a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // the three-launch pipeline for small batches (see "Small batches" above)
 static int launch_search_small(const TxhIndexDev &ix, const TxhWork &w, hipStream_t st, hipEvent_t ev0,
                                hipEvent_t ev1) {
+    if (w.small == 2) {   // the wide few-query pipeline ("Few queries, long streams")
+        // exact scans: a row per thread, 128-1024 positions per workgroup (see below); ADC scans: 1024 x rep positions,
+        // rep <= kWideRep chosen so that one wave of workgroups (256 CUs) covers the stream
+        uint32_t chunk = kFusedChunk * std::min<uint32_t>(kWideRep, std::max(1u, ceil_div_u32(w.cap, 256u * kFusedChunk)));
+        if (ix.exact_scan) chunk = std::min(kFusedChunk, std::max(128u, (ceil_div_u32(w.cap, 256u) + 127u) & ~127u));
+        const uint32_t G = std::max(1u, ceil_div_u32(w.cap, chunk));
+        SmallArgs a;
+        a.nq = w.nq; a.P = w.P; a.m = w.m; a.k = w.k; a.cap = w.cap; a.q_stride = w.q_stride;
+        a.exact_reorder = w.exact_reorder; a.queries = w.queries; a.tokens = w.tokens; a.vbase = w.vbase;
+        a.cand = w.cand; a.counters = w.counters; a.allow = w.allow; a.allow_bits = w.allow_bits;
+        a.out_idx = w.out_idx; a.out_dist = w.out_dist; a.out_count = w.out_count;
+        a.done = w.small_done; a.seq = w.small_seq; a.chunk = chunk;
+        FusedArgs f;
+        f.L = ix.L; f.n_pow2 = next_pow2_u32(ix.L);
+        f.p_pow2 = (w.P * 4u <= f.n_pow2) ? next_pow2_u32(std::max(1u, w.P)) : 0u;
+        f.st = w.st; f.cdist = w.cdist; f.token_dists = w.token_dists; f.tokens = w.tokens; f.vbase = w.vbase;
+        f.sbase = w.sbase; f.tickets = nullptr;
+        WideArgs wa;
+        wa.ng_stride = w.cap; wa.cap2 = w.wide_cap2;
+        wa.wgs = std::min(256u, std::max(8u, ceil_div_u32(w.cap, 4096u)));
+        wa.mins = w.wide_min; wa.ckey = w.wide_ckey; wa.ceb = w.wide_ceb; wa.cidx = w.wide_cidx; wa.ccnt = w.wide_cnt;
+        const SelCfg lcfg = sel_cfg(ix.L);
+        const size_t lds_sel = ix.ah_mode ? 0 : (size_t)(f.n_pow2 + f.p_pow2) * sizeof(uint64_t) + (size_t)lcfg.bins * 4 +
+                                                (size_t)lcfg.list * 8 + 48 * 8 + 64 * 4 + (size_t)ix.L * 8 +
+                                                (size_t)((ix.dim + 3u) & ~3u) * 4 + 16;
+        const size_t lds_scan = ((size_t)(ix.exact_scan ? 0u : ix.S * ix.kp) + ix.dim) * sizeof(float);
+        SCANN_TRY(set_dyn_lds(wide_scan_kernel, std::max(lds_sel, lds_scan)));
+        if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
+        hipLaunchKernelGGL(wide_scan_kernel, dim3(G, w.nq), dim3(kSelectThreads), std::max(lds_sel, lds_scan), st, ix, a, f, wa);
+        LAUNCH_CHECK();
+        if (ev1) SCANN_HIP_CHECK(hipEventRecord(ev1, st));
+        const size_t lds_f = (size_t)((ix.dim + 3u) & ~3u) * 4;
+        SCANN_TRY(set_dyn_lds_with_static(wide_filter_kernel, lds_f, 62 * 1024));   // (61840 B of static arrays)
+        hipLaunchKernelGGL(wide_filter_kernel, dim3(wa.wgs, w.nq), dim3(kSelectThreads), lds_f, st, ix, a, wa);
+        LAUNCH_CHECK();
+        const size_t lds_l = (size_t)w.wide_cap2 * 8;
+        SCANN_TRY(set_dyn_lds_with_static(wide_final_kernel, lds_l, 27 * 1024));   // (26 KB of static arrays)
+        hipLaunchKernelGGL(wide_final_kernel, dim3(w.nq), dim3(kSelectThreads), lds_l, st, a, wa);
+        LAUNCH_CHECK();
+        return SCANN_HIP_OK;
+    }
     {   // one launch when the grid stays small (SCANN_HIP_FUSED=0: always three)
         // Exact scans read a whole row per thread, 64 cache lines per wave instruction: they are bound by the
         // L1's line-request rate of ONE compute unit, so their workgroups take only 128 positions each (more

@@ -1330,14 +1330,8 @@ def test_small_batch_flags_survive_changing_layouts(kind, monkeypatch):
         assert np.array_equal(bits(got[1]), bits(w[1])), (it, nq, k)
 
 
-@pytest.mark.parametrize("kind,measure", list(_small_cases()))
-def test_small_batch_pipeline_matches_staged_pipeline(kind, measure, monkeypatch):
-    """Calls of <= 16 queries run select_leaves (inline centroid scoring) -> small_scan -> small_finish -- as ONE
-    launch (small_fused_kernel) when the grid is small, as three otherwise (SCANN_HIP_FUSED=0 forces three) -- with
-    pinned zero-copy staging; SCANN_HIP_SMALL=0 sends the same call down the staged pipeline the batched
-    parity tests pin to the oracle. Rows, distance bits and counts must be identical for every searcher
-    kind and measure, for 1, 7 and 16 queries, for k above the scanned stream (short results), and with an
-    allow-bitmap; a few queries are also checked against the oracle directly."""
+def _small_case(kind, measure):
+    """(index, opts, rows, n, oracle) of one searcher kind of the small-batch tests."""
     o = hip.default_opts()
     oracle = None
     if kind == "txh_residual":
@@ -1375,6 +1369,129 @@ def test_small_batch_pipeline_matches_staged_pipeline(kind, measure, monkeypatch
         index = hip.bf_create(data, n, dim, stride, measure)
         oracle = lambda qv, k: orc.bf_search(data, n, dim, stride, measure, qv, k)
         o = None
+    return index, o, rows, n, oracle
+
+
+def _wide_cases():
+    yield "txh_residual", None
+    yield "txh_byte_codes", None
+    yield "ah_flat", None
+    for m_ in (hip.SQUARED_L2, hip.DOT_PRODUCT, hip.COSINE):
+        yield "partitioned", m_
+
+
+@pytest.mark.parametrize("kind,measure", list(_wide_cases()))
+def test_wide_pipeline_matches_staged_pipeline(kind, measure, monkeypatch):
+    """Calls of <= 4 queries over long streams run the wide pipeline (wide_scan_kernel ->
+    wide_filter_kernel -> wide_final_kernel): SCANN_HIP_WIDE=2 forces it onto the small test indexes, so that streams
+    shorter than pre_reorder_k, k above the stream, one-point groups and every searcher kind pass through it.  Rows,
+    distance bits and counts must equal the staged pipeline's (SCANN_HIP_SMALL=0), which the batched parity tests pin
+    to the oracle; a few queries are checked against the oracle directly."""
+    index, o, rows, n, oracle = _small_case(kind, measure)
+    index.enable_timing(True)
+    dim = index.dimensionality()
+    q = synth.uniform_f32(8, dim, 67)
+    q[2] = rows[321]
+    variants = [None]
+    if kind in ("txh_residual", "ah_flat"):
+        variants = [None, (40, 1), (5000, 1), (0, 0)]   # (pre_reorder_k, exact_reorder): short lists, m above the stream, no re-ordering
+    for var in variants:
+        if var is not None:
+            o.pre_reorder_k, o.exact_reorder = var
+        for nq in (1, 3, 4):
+            for k in (10, 1, 64):
+                monkeypatch.delenv("SCANN_HIP_SMALL", raising=False)
+                monkeypatch.setenv("SCANN_HIP_WIDE", "2")
+                a = index.search_batched(q[:nq], k, o)
+                assert index.last_kernel_ms()[1] == "wide_scan_kernel", (kind, var, nq, k)
+                monkeypatch.setenv("SCANN_HIP_SMALL", "0")
+                b = index.search_batched(q[:nq], k, o)
+                assert np.array_equal(a[2], b[2]), (kind, var, nq, k)
+                assert np.array_equal(bits(a[1]), bits(b[1])), (kind, var, nq, k)
+                assert np.array_equal(a[0], b[0]), (kind, var, nq, k)
+        if oracle is not None and var is None:
+            monkeypatch.delenv("SCANN_HIP_SMALL", raising=False)
+            gi, gd, gc = index.search_batched(q[:3], 10, o)
+            for i in range(3):
+                oi, od = oracle(q[i], 10)
+                assert gc[i] == oi.size
+                H.assert_topk_equal_up_to_ties(gi[i, :oi.size], gd[i, :oi.size], oi, od, what="%s wide q%d" % (kind, i))
+    # five queries are above the wide pipeline's batch: the small-batch pipeline takes them
+    monkeypatch.delenv("SCANN_HIP_SMALL", raising=False)
+    index.search_batched(q[:5], 10, o)
+    assert index.last_kernel_ms()[1] == "small_scan_kernel"
+
+
+def _random_tree_index(sizes, dim, S, seed, rows=None):
+    """A tree index with the given leaf sizes: random centres, random 4-bit codes and codebook (the pipelines are
+    compared with each other: nothing here needs a trained quantiser)."""
+    rng = np.random.default_rng(seed)
+    n = int(sum(sizes))
+    if rows is None:
+        rows = synth.uniform_f32(n, dim, seed)
+    data, stride = orc.to_strided(rows)
+    L = len(sizes)
+    centers = np.ascontiguousarray(rows[rng.choice(n, L, replace=False)])
+    leaf_off = np.zeros(L + 1, np.uint32)
+    leaf_off[1:] = np.cumsum(np.asarray(sizes, np.uint32))
+    leaf_ids = rng.permutation(n).astype(np.uint32)
+    codebook = rng.random((S, 16, dim // S), dtype=np.float32)
+    codes = rng.integers(0, 16, (n, S), dtype=np.uint8)
+    kw = dict(data=data, n_rows=n, dim=dim, stride=stride, centers=centers, leaf_offsets=leaf_off, leaf_ids=leaf_ids,
+              codebook=codebook, codes=codes, codes_packed4=False, use_residuals=True, partitions_to_search=1,
+              pre_reorder_multiplier=1.0)
+    return rows, centers, kw
+
+
+def test_wide_pipeline_uneven_leaves_and_overflow(monkeypatch):
+    """The wide pipeline sizes its groups of stream positions from each query's OWN stream (a leaf of 40000 points next
+    to leaves of 3000).  Its compact candidate arrays overflow only when thousands of points tie at the pivot's
+    distance -- a dataset of few distinct code rows: count row 0xFFFFFFFF in the pinned buffer, and the host entry
+    repeats the call on the batched pipeline -- same rows either way."""
+    rows, centers, kw = _random_tree_index([40000, 3000, 3000, 3000, 3000, 3000], 32, 8, seed=71)
+    index = hip.txh_create(**kw)
+    index.enable_timing(True)
+    o = hip.default_opts()
+    o.partitions_to_search, o.pre_reorder_k = 1, 300
+    q = np.ascontiguousarray(centers + np.float32(0.001))
+    monkeypatch.delenv("SCANN_HIP_SMALL", raising=False)
+    monkeypatch.delenv("SCANN_HIP_WIDE", raising=False)   # (40000 points, leaves of 9000 on average: the default rule)
+
+    def both(ix_, qq, k):
+        a = ix_.search_batched(qq, k, o)
+        name = ix_.last_kernel_ms()[1]
+        monkeypatch.setenv("SCANN_HIP_SMALL", "0")
+        b = ix_.search_batched(qq, k, o)
+        monkeypatch.delenv("SCANN_HIP_SMALL", raising=False)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2])
+        return name
+
+    for i in range(6):
+        assert both(index, q[i:i + 1], 10) == "wide_scan_kernel", i
+    assert both(index, q[:4], 10) == "wide_scan_kernel"       # long and short streams in one call
+    # few distinct rows and code rows: ties everywhere (approximate and exact distances); the order is (exact, merge key)
+    base = synth.uniform_f32(37, 32, 72)
+    for ncodes, m, wide in ((53, 200, True), (53, 2000, True), (5, 200, False)):
+        rows2 = np.ascontiguousarray(base[np.arange(36000) % 37])
+        rows2, centers2, kw2 = _random_tree_index([36000], 32, 8, seed=73, rows=rows2)
+        kw2["codes"] = np.ascontiguousarray(kw2["codes"][np.arange(36000) % ncodes])
+        index2 = hip.txh_create(**kw2)
+        index2.enable_timing(True)
+        o.pre_reorder_k = m
+        name = both(index2, q[:2], 25)
+        # 5 code rows: 7200 points tie at the pivot, the compact arrays (2 m + 1024) overflow, the call is repeated
+        assert (name == "wide_scan_kernel") == wide, (ncodes, m, name)
+
+
+@pytest.mark.parametrize("kind,measure", list(_small_cases()))
+def test_small_batch_pipeline_matches_staged_pipeline(kind, measure, monkeypatch):
+    """Calls of <= 16 queries run select_leaves (inline centroid scoring) -> small_scan -> small_finish -- as ONE
+    launch (small_fused_kernel) when the grid is small, as three otherwise (SCANN_HIP_FUSED=0 forces three) -- with
+    pinned zero-copy staging; SCANN_HIP_SMALL=0 sends the same call down the staged pipeline the batched
+    parity tests pin to the oracle. Rows, distance bits and counts must be identical for every searcher
+    kind and measure, for 1, 7 and 16 queries, for k above the scanned stream (short results), and with an
+    allow-bitmap; a few queries are also checked against the oracle directly."""
+    index, o, rows, n, oracle = _small_case(kind, measure)
     dim = index.dimensionality()
     q = synth.uniform_f32(16, dim, 66) - np.float32(0.2 if kind == "bf" else 0.0)
     q[4] = rows[123]

@@ -145,3 +145,31 @@ def test_ah_1m_headline_every_path(ah_1m, mfma, smfmac, resident, i8, store, mon
     for i in (0, 511, 1023):
         oi, od = orc.ah_search_with_reordering(b["codebook"], b["codes"], b["data"], b["stride"], b["q"][i], k, pre_k)
         H.assert_topk_equal_up_to_ties(idx[i], dist[i], oi, od, what="oracle q%d" % i)
+
+
+def test_ah_1m_single_queries_take_the_wide_pipeline(ah_1m, monkeypatch):
+    """One to four queries over the flat 1M hasher at pre_reorder_k = 5000 (the ann_benchmark operating point,
+    bin/ann_benchmark.rs:172-178): the wide few-query pipeline (three launches), rows identical to the same queries'
+    rows inside a batch of 1024 and to the oracle's."""
+    b = ah_1m
+    k, pre_k = 10, 5000
+    o = hip.default_opts()
+    o.pre_reorder_k = pre_k
+    for name in ("SCANN_HIP_MFMA", "SCANN_HIP_SMFMAC", "SCANN_HIP_RESIDENT", "SCANN_HIP_RERANK_I8", "SCANN_HIP_RERANK_I8_MIN",
+                 "SCANN_HIP_RERANK_STORE", "SCANN_HIP_RERANK_UNIFORM", "SCANN_HIP_SMALL", "SCANN_HIP_WIDE"):
+        monkeypatch.delenv(name, raising=False)
+    index = hip.txh_create(data=b["data"], n_rows=1_000_000, dim=128, stride=b["stride"], centers=None, leaf_offsets=None,
+                           leaf_ids=None, codebook=b["codebook"], codes=b["codes"], codes_packed4=False, use_residuals=False,
+                           partitions_to_search=1, pre_reorder_multiplier=1.0)
+    index.enable_timing(True)
+    ref = index.search_batched(b["q"], k, o)
+    for lo, nq in ((0, 1), (1, 1), (100, 4), (511, 2), (1023, 1)):
+        idx, dist, cnt = index.search_batched(b["q"][lo:lo + nq], k, o)
+        assert index.last_kernel_ms()[1] == "wide_scan_kernel"
+        assert np.array_equal(cnt, ref[2][lo:lo + nq])
+        assert np.array_equal(dist.view(np.uint32), ref[1][lo:lo + nq].view(np.uint32))
+        assert np.array_equal(idx, ref[0][lo:lo + nq])
+    for i in (0, 1023):
+        idx, dist, cnt = index.search_batched(b["q"][i:i + 1], k, o)
+        oi, od = orc.ah_search_with_reordering(b["codebook"], b["codes"], b["data"], b["stride"], b["q"][i], k, pre_k)
+        H.assert_topk_equal_up_to_ties(idx[0], dist[0], oi, od, what="oracle q%d" % i)
