@@ -771,7 +771,7 @@ static int resolve_params(const scann_hip_index *ix, uint32_t k, const scann_hip
         const bool pays = ms >= kWideMinStream && ms >= 8ull * m && long_leaves;
         if (limits && (mode == 2 || pays)) {
             out->small = 2;
-            out->wide_cap2 = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(ms, 2ull * m + 1024), 16384);
+            out->wide_cap2 = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(ms, 3ull * m + 1024), 16384);
         }
     }
     if (out->small) full_cap = true;

@@ -43,7 +43,7 @@ constexpr uint32_t kSmallMaxCandidates = 1024;            // ... largest pre_reo
 constexpr uint32_t kWideBatch = 4;                        // queries per call it takes
 constexpr uint32_t kWideMaxStream = 4u << 20;             // ... longest candidate stream (points)
 constexpr uint32_t kWideMaxCandidates = 8192;             // ... largest pre_reorder_k
-constexpr uint32_t kWideMinStream = 32768;                // ... and the stream from which it replaces the pipeline above
+constexpr uint32_t kWideMinStream = 16384;                // ... and the stream from which it replaces the pipeline above
 
 // ---- threshold sampling plan (shared by host buffer sizing and the device kernels) ----
 // Every st-th point of each selected leaf is scored ahead of the scan (adc_sample_kernel,

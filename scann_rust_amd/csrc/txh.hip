@@ -78,6 +78,43 @@ __global__ __launch_bounds__(64) void centroid_scores_kernel(
 // centers_inline != nullptr (small batches): the block scores the centroids itself first, with
 // centroid_scores_kernel's arithmetic (sequential scalar sum of (q_j - c_j)^2, no FMA), instead of reading
 // a matrix another launch produced.
+// Bin of 1-based rank `rank` in a complete histogram of `bins` bins (1024 or 4096) in LDS (counts synchronised by the caller; the
+// histogram holds >= rank entries); s_w[49] = the rank inside that bin.  Every thread of a kSelectThreads block calls; two
+// barriers; s_w: LDS u32[>= 50].
+__device__ __forceinline__ uint32_t block_hist_rank_bin(const uint32_t *s_hist, uint32_t *s_w, uint32_t rank,
+                                                        uint32_t bins = kSelBinsMax) {
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t per = bins / kSelectThreads;   // bins per thread (1 or 4)
+    uint32_t mine = 0;
+    for (uint32_t j = 0; j < per; ++j) mine += s_hist[tid * per + j];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+        if ((int)lane >= o) incl += up;
+    }
+    if (lane == 63) s_w[32 + wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t w2 = 0; w2 < wave; ++w2) wbase += s_w[32 + w2];
+    incl += wbase;
+    const uint32_t excl = incl - mine;
+    if (excl < rank && rank <= incl) {   // exactly one thread
+        uint32_t c = excl;
+        for (uint32_t j = 0; j < per; ++j) {
+            const uint32_t h = s_hist[tid * per + j];
+            if (c + h >= rank) {
+                s_w[48] = tid * per + j;
+                s_w[49] = rank - c;   // 1-based rank inside the bin
+                break;
+            }
+            c += h;
+        }
+    }
+    __syncthreads();
+    return s_w[48];
+}
+
 // The kernel's body: also the first stage of small_fused_kernel, where EVERY workgroup of a query runs it
 // (write_out: only one of them stores the global outputs; s_tok_out / s_vb_out: LDS copies of the tokens
 // and the P + 1 key bases for the stages that follow in the same workgroup).
@@ -100,6 +137,10 @@ __device__ __forceinline__ void select_leaves_body(
     const uint32_t nfill = select_path ? L : n_pow2;
     // inline mode (small batches): the leaf size tables of this index live in LDS behind the scan words,
     // so nothing after the scoring waits on global memory
+#ifdef SCANN_WIDE_TIMING
+    uint64_t tl[6];
+    tl[0] = wall_clock64();
+#endif
     uint32_t *s_lsz = s_scan + 64, *s_lgs = s_lsz + (centers_inline ? L : 0u);
     float *s_qv = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(s_lgs + (centers_inline ? L : 0u)) + 15u) & ~(uintptr_t)15u);
     if (centers_inline) {
@@ -143,8 +184,14 @@ __device__ __forceinline__ void select_leaves_body(
             skeys[i] = key;
         }
     }
+#ifdef SCANN_WIDE_TIMING
+    tl[1] = wall_clock64();
+#endif
     __syncthreads();
     const uint64_t *sorted = skeys;
+#ifdef SCANN_WIDE_TIMING
+    tl[2] = tl[3] = wall_clock64();
+#endif
     if (select_path) {
         // P << L: the P-th smallest key by histogram select, then sort only the P survivors
         // (keys are unique: exactly P of them are <= the P-th smallest)
@@ -157,11 +204,17 @@ __device__ __forceinline__ void select_leaves_body(
             if (key <= T) s_top[atomicAdd(&s_scan[48], 1u)] = key;
         }
         __syncthreads();
+#ifdef SCANN_WIDE_TIMING
+        tl[3] = wall_clock64();
+#endif
         bitonic_sort_lds(s_top, p_pow2);
         sorted = s_top;
     } else {
         bitonic_sort_lds(skeys, n_pow2);
     }
+#ifdef SCANN_WIDE_TIMING
+    tl[4] = wall_clock64();
+#endif
     for (uint32_t r = tid; r < P; r += nt) {
         uint64_t key = sorted[r];
         uint32_t id = (uint32_t)key;
@@ -233,6 +286,10 @@ __device__ __forceinline__ void select_leaves_body(
             sbase[(size_t)q * (P + 2) + P + 1] = t_t;
         }
     }
+#ifdef SCANN_WIDE_TIMING
+    tl[5] = wall_clock64();
+    if (tid == 0 && write_out && q == 0) printf("leaves: score %.2f sync %.2f select %.2f sort %.2f prefix %.2f us\n", (tl[1] - tl[0]) * 0.01, (tl[2] - tl[1]) * 0.01, (tl[3] - tl[2]) * 0.01, (tl[4] - tl[3]) * 0.01, (tl[5] - tl[4]) * 0.01);
+#endif
 }
 
 __global__ __launch_bounds__(kSelectThreads) void select_leaves_kernel(
@@ -4944,13 +5001,17 @@ static int launch_exact_scan(const TxhIndexDev &ix, const TxhWork &w, hipStream_
 constexpr uint32_t kFusedChunk = kSelectThreads;   // stream positions per workgroup
 constexpr uint32_t kFusedMaxWgs = 512;              // nq x workgroups per query above which three launches are used
 
-// Wide pipeline: stream positions per group minimum for a stream of cnt keys and m wanted candidates -- the largest
-// power of two <= 64 that leaves >= 3 m groups (the pivot, the m-th smallest group minimum, then lets ~1.2 m keys
-// pass), 1 for streams under 6 m (the pivot is then the m-th smallest distance itself).  Chosen on the device from
-// the query's OWN stream: leaves differ in size by an order of magnitude and the host only knows the longest stream.
+// Wide pipeline: stream positions per group minimum for a stream of cnt keys and m wanted candidates: the smallest
+// power of two that leaves at most kWideGroups groups (wide_filter_kernel holds them in registers, 16 per thread) --
+// the pivot, the m-th smallest group minimum, lets about -G ln(1 - m / G) keys pass when the candidates are spread
+// evenly over G groups (1.2 m at G = 3 m), more when they sit in a few leaves -- but never fewer than 1.5 m groups.
+// Chosen on the device from the query's OWN stream: leaves differ in size by an order of magnitude and the host only
+// knows the longest stream.
+constexpr uint32_t kWideGroups = 16384;
 __host__ __device__ static inline uint32_t wide_group(uint32_t cnt, uint32_t m) {
-    uint32_t g = 64;
-    while (g > 1 && (uint64_t)cnt / g < 3ull * m) g >>= 1;
+    uint32_t g = 1;
+    while (g < 64 && (cnt + g - 1) / g > kWideGroups) g <<= 1;
+    while (g > 1 && (uint64_t)cnt / g < ((uint64_t)m * 3) / 2) g >>= 1;
     return g;
 }
 
@@ -5133,41 +5194,6 @@ struct WideArgs {
     uint32_t *ceb, *cidx, *ccnt;
 };
 
-// Bin of 1-based rank `rank` in a complete kSelBinsMax-bin histogram in LDS (counts synchronised by the caller; the
-// histogram holds >= rank entries).  Every thread of a kSelectThreads block calls; two barriers; s_w: LDS u32[>= 49].
-__device__ __forceinline__ uint32_t block_hist_rank_bin(const uint32_t *s_hist, uint32_t *s_w, uint32_t rank) {
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    constexpr uint32_t per = kSelBinsMax / kSelectThreads;   // bins per thread
-    uint32_t mine = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < per; ++j) mine += s_hist[tid * per + j];
-    uint32_t incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
-        if ((int)lane >= o) incl += up;
-    }
-    if (lane == 63) s_w[32 + wave] = incl;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (uint32_t w2 = 0; w2 < wave; ++w2) wbase += s_w[32 + w2];
-    incl += wbase;
-    const uint32_t excl = incl - mine;
-    if (excl < rank && rank <= incl) {   // exactly one thread
-        uint32_t c = excl;
-#pragma unroll
-        for (uint32_t j = 0; j < per; ++j) {
-            c += s_hist[tid * per + j];
-            if (c >= rank) {
-                s_w[48] = tid * per + j;
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    return s_w[48];
-}
-
 // Launch 1: leaf selection (every workgroup repeats it, as in small_fused_kernel) and the scan of
 // [v0, v0 + chunk) stream positions per workgroup -- for ADC scans up to kWideRep positions per thread, so that a
 // workgroup's table build (and its four dependent round trips) is shared by 4096 points and one wave of workgroups
@@ -5179,6 +5205,10 @@ __global__ __launch_bounds__(kSelectThreads) void wide_scan_kernel(TxhIndexDev i
     __shared__ uint32_t s_tok[kDecodeStage], s_vb[kDecodeStage + 1], s_lrow[kDecodeStage];
     const uint32_t q = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, nt = kSelectThreads;
     const uint32_t P = a.P, dim = ix.dim;
+#ifdef SCANN_WIDE_TIMING
+    uint64_t ts[6];
+    ts[0] = wall_clock64();
+#endif
     if (q == 0 && b == 0 && tid == 0) a.counters[CNT_STATUS] = 0;
     if (b == 0 && tid == 0) wa.ccnt[q] = 0;
     if (ix.ah_mode) {
@@ -5209,6 +5239,9 @@ __global__ __launch_bounds__(kSelectThreads) void wide_scan_kernel(TxhIndexDev i
     const uint32_t v0 = b * chunk;
     if (v0 >= cnt) return;            // an idle workgroup (block-uniform)
     __syncthreads();
+#ifdef SCANN_WIDE_TIMING
+    ts[1] = wall_clock64();
+#endif
     const uint32_t g = wide_group(cnt, a.m);
     uint32_t *mins = const_cast<uint32_t *>(wa.mins) + (size_t)q * wa.ng_stride;
     uint64_t *out = a.cand + (size_t)q * a.cap;
@@ -5292,6 +5325,9 @@ __global__ __launch_bounds__(kSelectThreads) void wide_scan_kernel(TxhIndexDev i
             s_lut[e] = acc;
         }
         __syncthreads();
+#ifdef SCANN_WIDE_TIMING
+        ts[2] = wall_clock64();
+#endif
 #pragma unroll
         for (int it = 0; it < kWideRep; ++it) {
             if (!in[it]) continue;
@@ -5322,11 +5358,18 @@ __global__ __launch_bounds__(kSelectThreads) void wide_scan_kernel(TxhIndexDev i
         }
         __syncthreads();   // (the tables are rebuilt for the next leaf)
     }
+#ifdef SCANN_WIDE_TIMING
+    ts[3] = wall_clock64();
+#endif
 #pragma unroll
     for (int it = 0; it < kWideRep; ++it) {
         if ((uint32_t)it * nt >= chunk) break;   // (uniform)
         group_min(d32[it], v0 + (uint32_t)it * nt + tid, true);
     }
+#ifdef SCANN_WIDE_TIMING
+    ts[4] = wall_clock64();
+    if (tid == 0 && b == 0) printf("scan: leaves %.2f tables %.2f points %.2f minima %.2f us\n", (ts[1] - ts[0]) * 0.01, (ts[2] - ts[1]) * 0.01, (ts[3] - ts[2]) * 0.01, (ts[4] - ts[3]) * 0.01);
+#endif
 }
 
 __global__ __launch_bounds__(kSelectThreads) void wide_filter_kernel(TxhIndexDev ix, SmallArgs a, WideArgs wa) {
@@ -5337,8 +5380,12 @@ __global__ __launch_bounds__(kSelectThreads) void wide_filter_kernel(TxhIndexDev
     const uint32_t q = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, nt = kSelectThreads;
     const uint32_t P = a.P, m = a.m;
     const uint32_t *vbq = a.vbase + (size_t)q * (P + 1), *tokq = a.tokens + (size_t)q * P;
+#ifdef SCANN_WIDE_TIMING
+    uint64_t tf[6];
+    tf[0] = wall_clock64();
+#endif
     const uint32_t cnt = min(vbq[P], a.cap);
-    if ((uint64_t)b * nt >= cnt) return;   // no key block for this workgroup (block-uniform)
+    if ((uint64_t)b * 64u >= cnt) return;   // no key chunk for this workgroup (block-uniform)
     float *s_q = reinterpret_cast<float *>(s_wdyn);
     for (uint32_t j = tid; j < ix.dim; j += nt) s_q[j] = a.queries[(size_t)q * a.q_stride + j];
     for (uint32_t r = tid; r <= P; r += nt) {
@@ -5346,15 +5393,22 @@ __global__ __launch_bounds__(kSelectThreads) void wide_filter_kernel(TxhIndexDev
         if (r < P) s_drow[r] = ix.leaf_off[tokq[r]];
     }
     if (tid == 0) s_n = 0;
-    // (the first key blocks of this workgroup travel while the pivot is computed)
+    // Key positions of this workgroup: 64-key chunks c = (j * 16 + wave) * wgs + b, j = 0, 1, ... -- interleaved at
+    // wave granularity, so that the near leaves' dense runs of passing keys (most of a tree query's candidates lie in
+    // its first one or two leaves) are shared by all workgroups.  The first KP rounds travel while the pivot is computed.
     const uint64_t *list = a.cand + (size_t)q * a.cap;
+    const uint32_t kwave = tid >> 6, klane = tid & 63u;
+    auto key_pos = [&](uint32_t j) { return ((uint64_t)(j * (nt >> 6) + kwave) * wa.wgs + b) * 64u + klane; };
     constexpr int KP = 4;
     uint64_t kpre[KP];
 #pragma unroll
     for (int j = 0; j < KP; ++j) {
-        const uint64_t i = ((uint64_t)b + (uint64_t)j * wa.wgs) * nt + tid;
+        const uint64_t i = key_pos((uint32_t)j);
         kpre[j] = i < cnt ? list[i] : SCANN_KEY_MAX;
     }
+#ifdef SCANN_WIDE_TIMING
+    tf[1] = wall_clock64();
+#endif
     // ---- the pivot (every workgroup of the query computes the same one): an upper bound of the m-th smallest group
     // minimum -- the upper edge of its bin in a 4096-bin histogram over [min, max] of the minima.  One read of the
     // minima (16 per thread, in registers), four barriers; the exact m-th minimum (block_select: a dozen barriers
@@ -5421,6 +5475,9 @@ __global__ __launch_bounds__(kSelectThreads) void wide_filter_kernel(TxhIndexDev
         }
     }
     __syncthreads();
+#ifdef SCANN_WIDE_TIMING
+    tf[2] = wall_clock64();
+#endif
     // a batch of collected keys: decode, exact distance (8 lanes per candidate), append to the compact arrays
     auto flush = [&]() {
         const uint32_t n = min(s_n, kWideList);
@@ -5463,10 +5520,9 @@ __global__ __launch_bounds__(kSelectThreads) void wide_filter_kernel(TxhIndexDev
         if (tid == 0) s_n = 0;
         __syncthreads();
     };
-    // ---- key blocks b, b + wgs, ...: interleaved, so that the near leaves' dense runs of passing keys are shared
-    uint32_t jb = 0;
-    for (uint64_t i0 = (uint64_t)b * nt; i0 < cnt; i0 += (uint64_t)wa.wgs * nt, ++jb) {
-        const uint32_t i = (uint32_t)i0 + tid;
+    // ---- rounds of 16 chunks (one per wave)
+    for (uint32_t jb = 0; (uint64_t)jb * (nt >> 6) * wa.wgs * 64u < cnt; ++jb) {
+        const uint64_t i = key_pos(jb);
         uint64_t key = SCANN_KEY_MAX;
         if (jb < (uint32_t)KP) {
 #pragma unroll
@@ -5488,7 +5544,15 @@ __global__ __launch_bounds__(kSelectThreads) void wide_filter_kernel(TxhIndexDev
         if (collected > kWideList - nt) flush();
     }
     __syncthreads();
+#ifdef SCANN_WIDE_TIMING
+    tf[3] = wall_clock64();
+    const uint32_t npass = s_n;
+#endif
     if (s_n) flush();
+#ifdef SCANN_WIDE_TIMING
+    tf[4] = wall_clock64();
+    if (tid == 0 && b == 0) printf("filter: cnt %u pass %u setup %.2f pivot %.2f filter %.2f flush %.2f us\n", cnt, npass, (tf[1] - tf[0]) * 0.01, (tf[2] - tf[1]) * 0.01, (tf[3] - tf[2]) * 0.01, (tf[4] - tf[3]) * 0.01);
+#endif
 }
 
 __global__ __launch_bounds__(kSelectThreads) void wide_final_kernel(SmallArgs a, WideArgs wa) {
@@ -5537,11 +5601,66 @@ __global__ __launch_bounds__(kSelectThreads) void wide_final_kernel(SmallArgs a,
         // the candidates: the m smallest keys (mod.rs:283-293); everything above T drops out
         uint64_t T = SCANN_KEY_MAX - 1;
         if (c2 > m) {
+            // block_select's scheme on the register copy (six barriers instead of a dozen): histogram of the keys over
+            // [min, max], the bin of rank m, its members ranked exactly by counting
+            uint32_t *s_w = reinterpret_cast<uint32_t *>(s_red);
+            uint64_t kmin = SCANN_KEY_MAX, kmax = 0;
 #pragma unroll
             for (int e = 0; e < E0; ++e)
-                if ((uint32_t)e * nt < c2 && (uint32_t)e * nt + tid < c2) s_v[(uint32_t)e * nt + tid] = kk[e];
+                if ((uint32_t)e * nt < c2 && kk[e] != SCANN_KEY_MAX) {
+                    kmin = kk[e] < kmin ? kk[e] : kmin;
+                    kmax = kk[e] > kmax ? kk[e] : kmax;
+                }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint64_t x = shfl_xor_t<uint64_t>(kmin, o), y = shfl_xor_t<uint64_t>(kmax, o);
+                kmin = x < kmin ? x : kmin;
+                kmax = y > kmax ? y : kmax;
+            }
+            if (lane == 0) {
+                s_red[wave] = kmin;
+                s_red[16 + wave] = kmax;
+            }
+            for (uint32_t i = tid; i < kSelBinsMax; i += nt) s_hist[i] = 0;
+            if (tid == 0) s_cn = 0;
             __syncthreads();
-            T = block_select<uint64_t>(s_v, c2, m, sel_cfg(c2), s_hist, s_slist, s_red);
+            for (uint32_t w2 = 0; w2 < (nt >> 6); ++w2) {
+                kmin = s_red[w2] < kmin ? s_red[w2] : kmin;
+                kmax = s_red[16 + w2] > kmax ? s_red[16 + w2] : kmax;
+            }
+            uint32_t ksh = 0;
+            while (((kmax - kmin) >> ksh) >= (uint64_t)kSelBinsMax) ++ksh;
+#pragma unroll
+            for (int e = 0; e < E0; ++e)
+                if ((uint32_t)e * nt < c2 && kk[e] != SCANN_KEY_MAX) atomicAdd(&s_hist[(uint32_t)((kk[e] - kmin) >> ksh)], 1u);
+            __syncthreads();   // (everyone has read the wave minima / maxima: the scan reuses their words)
+            const uint32_t kbin = block_hist_rank_bin(s_hist, s_w, m);
+            const uint32_t krk = s_w[49], kpop = s_hist[kbin];
+            const uint64_t klo = kmin + ((uint64_t)kbin << ksh);
+            uint64_t khi = klo + (((uint64_t)1 << ksh) - 1);
+            if (khi > kmax || khi < klo) khi = kmax;
+            if (ksh == 0) {
+                T = klo;
+            } else if (kpop <= kSelListMax) {
+#pragma unroll
+                for (int e = 0; e < E0; ++e)
+                    if ((uint32_t)e * nt < c2 && kk[e] >= klo && kk[e] <= khi) s_slist[atomicAdd(&s_cn, 1u)] = kk[e];
+                __syncthreads();
+                for (uint32_t i = tid; i < kpop; i += nt) {
+                    const uint64_t v = s_slist[i];
+                    uint32_t r = 0;
+                    for (uint32_t j2 = 0; j2 < kpop; ++j2) r += s_slist[j2] < v ? 1u : 0u;   // (keys are unique)
+                    if (r + 1 == krk) s_red[40] = v;
+                }
+                __syncthreads();
+                T = s_red[40];
+            } else {   // a crowded bin: the general select on an LDS copy
+#pragma unroll
+                for (int e = 0; e < E0; ++e)
+                    if ((uint32_t)e * nt < c2 && (uint32_t)e * nt + tid < c2) s_v[(uint32_t)e * nt + tid] = kk[e];
+                __syncthreads();
+                T = block_select<uint64_t>(s_v, c2, m, sel_cfg(c2), s_hist, s_slist, s_red);
+            }
             __syncthreads();
         }
         WIDE_T();
@@ -5730,7 +5849,7 @@ static int launch_search_small(const TxhIndexDev &ix, const TxhWork &w, hipStrea
         f.sbase = w.sbase; f.tickets = nullptr;
         WideArgs wa;
         wa.ng_stride = w.cap; wa.cap2 = w.wide_cap2;
-        wa.wgs = std::min(256u, std::max(8u, ceil_div_u32(w.cap, 4096u)));
+        wa.wgs = std::min(256u, std::max(8u, ceil_div_u32(w.cap, 1024u)));
         wa.mins = w.wide_min; wa.ckey = w.wide_ckey; wa.ceb = w.wide_ceb; wa.cidx = w.wide_cidx; wa.ccnt = w.wide_cnt;
         const SelCfg lcfg = sel_cfg(ix.L);
         const size_t lds_sel = ix.ah_mode ? 0 : (size_t)(f.n_pow2 + f.p_pow2) * sizeof(uint64_t) + (size_t)lcfg.bins * 4 +

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export SCANN_BENCH_STREAMS=1
 for wl in "ah" "txh --dist clustered --partitions-to-search 10 --pre-reorder-k 1000"; do
   for b in ${BATCHES:-1 4}; do
-    for wide in 1 0; do
+    for wide in ${WIDES:-1 0}; do
       r=$(SCANN_HIP_WIDE=$wide timeout -k 10 200 python3 bench.py --workload $wl --batch $b --steps 300 --warmup 20 --no-cpu-baseline --no-recall --no-batch-sweep 2>>gpurun_out/kstat_wide.err | grep -o '"ms_per_step": [0-9.]*') || exit 1
       echo "$wl batch $b wide=$wide $r"
     done
@@ -13,7 +13,7 @@ for wl in "ah" "txh --dist clustered --partitions-to-search 10 --pre-reorder-k 1
 done
 for wl in "ah" "txh --dist clustered --partitions-to-search 10 --pre-reorder-k 1000"; do
 O=gpurun_out/ksw; rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 bench.py --workload $wl --batch 1 --steps 200 --no-cpu-baseline --no-recall --no-batch-sweep > $O/ks.log 2>&1 || exit 1
+SCANN_HIP_WIDE=${PROFWIDE:-1} rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 bench.py --workload $wl --batch 1 --steps 200 --no-cpu-baseline --no-recall --no-batch-sweep > $O/ks.log 2>&1 || exit 1
 python3 - <<PY
 import csv,glob
 f=glob.glob("$O/ks/**/*kernel_stats.csv", recursive=True)[0]
