@@ -517,23 +517,25 @@ def main():
     # ---------------- device buffers (inputs resident in HBM before the timed region) ----------------
     nbatches = 4
     qdev = [torch.from_numpy(np.ascontiguousarray(queries_all[i * Q:(i + 1) * Q])).to(device) for i in range(nbatches)]
-    streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)]
+    n_streams = max(1, int(os.environ.get("SCANN_BENCH_STREAMS", "2")))   # caller streams that alternate (default two)
+    n_bufs = max(2, n_streams)
+    streams = [torch.cuda.Stream(device) for _ in range(n_bufs)]
     outs = [(torch.empty((Q, k), dtype=torch.int32, device=device), torch.empty((Q, k), dtype=torch.float32, device=device),
-             torch.empty((Q,), dtype=torch.int32, device=device)) for _ in range(2)]
+             torch.empty((Q,), dtype=torch.int32, device=device)) for _ in range(n_bufs)]
     hip.check(L.scann_hip_index_reserve(index.h, Q, k, ctypes.byref(opts)))
 
-    two_streams = os.environ.get("SCANN_BENCH_STREAMS", "2") != "1"
+    two_streams = n_streams != 1
     if sharded and args.m_local < 0:
         args.m_local = m   # every rank's full list, compact destination blocks
 
     def step(i, qd=None, nq=Q):
         qd = qdev[i % nbatches] if qd is None else qd
-        b = i & 1
+        b = i % n_bufs
         oi, od, oc = outs[b]
         # Two caller streams alternate (SCANN_BENCH_STREAMS=1: one): the library binds a workspace to each caller stream
         # (scann_hip.h "device entry points and streams"), so step i+1's matrix-core-bound scan runs under step i's
         # HBM-/latency-bound select + re-rank kernels; sharded: step i's exchange overlaps step i+1's local stage.
-        sp = ctypes.c_void_p(streams[b if two_streams else 0].cuda_stream)
+        sp = ctypes.c_void_p(streams[i % n_streams if two_streams else 0].cuda_stream)
         if sharded:
             # two caller streams alternate: step i's exchange (on the library's stream) overlaps
             # step i+1's local stage (the library orders its own buffers with events)
@@ -547,7 +549,7 @@ def main():
     def device_status():
         if sharded:
             comm.last_status()
-        for st_ in streams[:2 if two_streams else 1]:
+        for st_ in streams[:n_streams if two_streams else 1]:
             hip.check(L.scann_hip_index_last_device_status(index.h, ctypes.c_void_p(st_.cuda_stream)))
 
     def barrier():
@@ -607,7 +609,7 @@ def main():
     if elapsed < 0.2:
         log("WARNING: the timed region is only %.3f s (%d steps); raise --steps for a stable number" % (elapsed, args.steps))
     qps = Q * args.steps * (nproc if replica else 1) / elapsed
-    last_out = tuple(t.clone() for t in outs[(args.steps - 1) & 1])   # the sweep below reuses the buffers
+    last_out = tuple(t.clone() for t in outs[(args.steps - 1) % n_bufs])   # the sweep below reuses the buffers
     last_q = queries_all[((args.steps - 1) % nbatches) * Q:][:Q]
 
     # ---------------- batch-size sweep (batches {1, 100, 1024}, >= 10 reps, median) -----------
@@ -783,7 +785,7 @@ def main():
             "scaling": "weak" if (replica or nproc == 1) else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name, "n": n * (nproc if sharded else 1), "n_per_gpu": n, "dim": dim,
-                       "k": k, "batch": Q, "global_batch": Q * (nproc if replica else 1),
+                       "k": k, "batch": Q, "global_batch": Q * (nproc if replica else 1), "caller_streams": n_streams,
                        "pre_reorder_k": m if args.workload != "bf_dot" else None,
                        "pre_reorder_k_per_rank": (args.m_local or m) if sharded else None,
                        "exchange_bytes_per_link_per_step": (hip.comm_layout(Q, nproc, args.m_local, k)["block_bytes"]

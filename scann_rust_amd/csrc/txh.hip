@@ -5172,14 +5172,19 @@ __global__ __launch_bounds__(kSelectThreads) void small_fused_kernel(TxhIndexDev
 // spread over the chip, in three launches:
 //   1. wide_scan_kernel: leaf selection + scan as in small_fused_kernel; every group of g stream positions
 //      (wide_group: from the query's own stream length) also leaves its minimum approximate distance.
-//   2. wide_filter_kernel: a few dozen workgroups per query.  Each derives the same pivot -- the m-th smallest
-//      group minimum, which is >= the m-th smallest key's distance (the m smallest minima belong to m distinct
-//      points) and, with >= 3 m groups, lets ~1.2 m keys pass -- filters its share of the key list, decodes
-//      the passing keys, scores their rows exactly (exact_pair_8lanes) and appends (key, exact, index) to the
-//      query's compact arrays (one global atomic per batch of candidates).
-//   3. wide_final_kernel: a workgroup per query: the m-th smallest key among the entries (the candidates of
-//      mod.rs:283-293: everything above it drops out), then the k best of those by (exact, merge key)
-//      (mod.rs:342-364) through block_select -- exact under any number of ties.
+//   2. wide_filter_kernel: up to 256 workgroups per query.  Each derives the same pivot -- an upper bound of the
+//      m-th smallest group minimum (the upper edge of its bin in a 4096-bin histogram of the minima), which is
+//      >= the m-th smallest key's distance (the m smallest minima belong to m distinct points) and lets
+//      1.2-1.6 m keys pass -- filters its share of the key list (64-key chunks interleaved between the workgroups),
+//      decodes the passing keys, scores their rows exactly (exact_pair_8lanes) and appends (key, exact, index) to
+//      the query's compact arrays (one global atomic per batch of candidates).
+//   3. wide_final_kernel: a workgroup per query, the entries in registers: the m-th smallest key among them (the
+//      candidates of mod.rs:283-293: everything above it drops out), then the k best of those by (exact, merge
+//      key) (mod.rs:342-364): a histogram shortlist ranked by one wave, or the two-level tournament of
+//      small_finish_body when ties crowd the shortlist -- exact under any number of ties.
+// Measured (one query, MI355X): flat 1M x 128 hasher at m = 5000: 16 + 16 + 16 us of kernels, 0.061 ms per call
+// (the batched pipeline's twelve launches: 0.175); Tree-X-Hybrid 1M x 128, 1000 leaves, P = 10, m = 1000: 35 (of
+// which the leaf selection 27) + 12 + 16 us, 0.074 ms per call (three-launch small pipeline: 0.124).
 // Same keys, same arithmetic, same tie order as the other pipelines: rows are identical.  If the compact arrays
 // overflow (thousands of points tied at the pivot's distance: a dataset of few distinct code rows) the status word
 // says RESOURCE_EXHAUSTED and a host call's count row 0xFFFFFFFF; the host entry repeats the call on the batched
