@@ -587,6 +587,8 @@ def main():
         kernel_ms_timed, kernel_name = index.last_kernel_ms()
         index.enable_timing(False)
         device_status()
+        # rows of the LAST TIMED step, for the oracle check (the passes below reuse the buffers)
+        last_out = tuple(t.clone() for t in outs[(args.steps - 1) % n_bufs])
         # The dominant kernel ALONE on the machine, for the roofline: with two caller streams the timed region runs
         # kernels of consecutive batches side by side, so an event pair around one of them also measures its neighbours
         # (C3: 0.52 ms inside the region, 0.35 ms alone; rocprofv3 --kernel-trace agrees with each in its own run).  A
@@ -609,7 +611,6 @@ def main():
     if elapsed < 0.2:
         log("WARNING: the timed region is only %.3f s (%d steps); raise --steps for a stable number" % (elapsed, args.steps))
     qps = Q * args.steps * (nproc if replica else 1) / elapsed
-    last_out = tuple(t.clone() for t in outs[(args.steps - 1) % n_bufs])   # the sweep below reuses the buffers
     last_q = queries_all[((args.steps - 1) % nbatches) * Q:][:Q]
 
     # ---------------- batch-size sweep (batches {1, 100, 1024}, >= 10 reps, median) -----------

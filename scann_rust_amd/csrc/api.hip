@@ -759,15 +759,17 @@ static int resolve_params(const scann_hip_index *ix, uint32_t k, const scann_hip
                   k <= 64 && ms <= kSmallMaxStream && ix->tx.L <= 4096) ? 1 : 0;
     // Fewer queries still, over a long stream: the wide pipeline (three launches, every stage spread over the chip).
     // Its scan rebuilds the tables per leaf inside a workgroup of 1024 stream positions: leaves of >= 512 points
-    // (or one leaf, or an exact scan).  Streams of >= 8 m points: below that most of the stream is candidates anyway.
+    // (or one leaf); ADC scans only (Partitioned mode, 4 queries over 20 leaves of 1M x 128: 0.097 ms on the small-batch
+    // pipeline, 0.147 through this one).  Streams of >= 8 m points: below that most of the stream is candidates anyway.
     // SCANN_HIP_WIDE: 0 = never, 2 = whenever the limits allow (tests), else from kWideMinStream points.
     out->wide_cap2 = 0;
     {
         int mode = 1;
         if (const char *e = std::getenv("SCANN_HIP_WIDE")) mode = std::atoi(e);
         const bool limits = small_on && allow_wide && mode != 0 && nq <= kWideBatch && !ix->sharded && m >= 1 &&
-                            m <= kWideMaxCandidates && k <= 64 && ms <= kWideMaxStream && ix->tx.L <= 4096 && P <= 512;
-        const bool long_leaves = ix->tx.exact_scan || P == 1 || ix->tx.n_local / std::max(1u, ix->tx.L) >= 512;
+                            m <= kWideMaxCandidates && k <= 64 && ms <= kWideMaxStream && ix->tx.L <= 4096 && P <= 512 &&
+                            !ix->tx.exact_scan;
+        const bool long_leaves = P == 1 || ix->tx.n_local / std::max(1u, ix->tx.L) >= 512;
         const bool pays = ms >= kWideMinStream && ms >= 8ull * m && long_leaves;
         if (limits && (mode == 2 || pays)) {
             out->small = 2;

@@ -195,6 +195,8 @@ __device__ __forceinline__ void select_leaves_body(
     if (select_path) {
         // P << L: the P-th smallest key by histogram select, then sort only the P survivors
         // (keys are unique: exactly P of them are <= the P-th smallest)
+        // (Tried for P <= 16: per-wave tournaments of 64-bit wave minima, P rounds per wave and P over the finalists,
+        // which also yields the sorted order -- 12 cross-lane shuffles per round, no faster than this.)
         const uint64_t T = block_select<uint64_t>(skeys, L, P, cfg, s_hist, s_list, s_red);
         for (uint32_t i = tid; i < p_pow2; i += nt) s_top[i] = SCANN_KEY_MAX;
         if (tid == 0) s_scan[48] = 0;
@@ -5240,7 +5242,7 @@ __global__ __launch_bounds__(kSelectThreads) void wide_scan_kernel(TxhIndexDev i
     __syncthreads();
     for (uint32_t r = tid; r < P; r += nt) s_lrow[r] = ix.leaf_off[s_tok[r]];
     const uint32_t cnt = min(s_vb[P], a.cap);
-    const uint32_t chunk = a.chunk;   // stream positions per workgroup: <= nt for exact scans, nt * rep for ADC scans
+    const uint32_t chunk = a.chunk;   // stream positions per workgroup: nt * rep
     const uint32_t v0 = b * chunk;
     if (v0 >= cnt) return;            // an idle workgroup (block-uniform)
     __syncthreads();
@@ -5266,22 +5268,6 @@ __global__ __launch_bounds__(kSelectThreads) void wide_scan_kernel(TxhIndexDev i
         }
         if (slot && (tid & (g - 1u)) == 0 && v < cnt) mins[v / g] = d32;
     };
-    if (ix.exact_scan) {
-        float *s_qe = reinterpret_cast<float *>(s_dyn);
-        for (uint32_t d = tid; d < dim; d += nt) s_qe[d] = a.queries[(size_t)q * a.q_stride + d];
-        __syncthreads();
-        const uint32_t v = v0 + tid;
-        const bool have = tid < chunk && v < cnt;
-        uint64_t key = SCANN_KEY_MAX;
-        if (have) {
-            const uint32_t r = leaf_of(v), csr = s_lrow[r] + (v - s_vb[r]);
-            const float *row = ix.rows + (size_t)(ix.rows_csr ? csr : ix.leaf_ids[csr]) * ix.stride;
-            key = make_key(exact_pair_thread(ix.measure, dim, s_qe, row), v);
-            out[v] = key;
-        }
-        group_min((uint32_t)(key >> 32), v, tid < chunk);
-        return;
-    }
     const uint32_t S = ix.S, K = ix.K, dsub = ix.dsub, kp = ix.kp;
     float *s_lut = reinterpret_cast<float *>(s_dyn), *s_qr = s_lut + S * kp;
     const uint32_t vz = min(v0 + chunk, cnt);                      // end of this workgroup's positions
@@ -5836,10 +5822,10 @@ __global__ __launch_bounds__(kSelectThreads) void wide_final_kernel(SmallArgs a,
 static int launch_search_small(const TxhIndexDev &ix, const TxhWork &w, hipStream_t st, hipEvent_t ev0,
                                hipEvent_t ev1) {
     if (w.small == 2) {   // the wide few-query pipeline ("Few queries, long streams")
-        // exact scans: a row per thread, 128-1024 positions per workgroup (see below); ADC scans: 1024 x rep positions,
-        // rep <= kWideRep chosen so that one wave of workgroups (256 CUs) covers the stream
-        uint32_t chunk = kFusedChunk * std::min<uint32_t>(kWideRep, std::max(1u, ceil_div_u32(w.cap, 256u * kFusedChunk)));
-        if (ix.exact_scan) chunk = std::min(kFusedChunk, std::max(128u, (ceil_div_u32(w.cap, 256u) + 127u) & ~127u));
+        // 1024 x rep stream positions per workgroup, rep <= kWideRep chosen so that one wave of workgroups (256 CUs) covers
+        // the stream.  (ADC scans only: an exact scan wants a row per thread and ~128 rows per workgroup -- hundreds of
+        // workgroups per query that would each repeat the leaf selection; Partitioned mode keeps the pipelines above.)
+        const uint32_t chunk = kFusedChunk * std::min<uint32_t>(kWideRep, std::max(1u, ceil_div_u32(w.cap, 256u * kFusedChunk)));
         const uint32_t G = std::max(1u, ceil_div_u32(w.cap, chunk));
         SmallArgs a;
         a.nq = w.nq; a.P = w.P; a.m = w.m; a.k = w.k; a.cap = w.cap; a.q_stride = w.q_stride;
@@ -5860,7 +5846,7 @@ static int launch_search_small(const TxhIndexDev &ix, const TxhWork &w, hipStrea
         const size_t lds_sel = ix.ah_mode ? 0 : (size_t)(f.n_pow2 + f.p_pow2) * sizeof(uint64_t) + (size_t)lcfg.bins * 4 +
                                                 (size_t)lcfg.list * 8 + 48 * 8 + 64 * 4 + (size_t)ix.L * 8 +
                                                 (size_t)((ix.dim + 3u) & ~3u) * 4 + 16;
-        const size_t lds_scan = ((size_t)(ix.exact_scan ? 0u : ix.S * ix.kp) + ix.dim) * sizeof(float);
+        const size_t lds_scan = ((size_t)ix.S * ix.kp + ix.dim) * sizeof(float);
         SCANN_TRY(set_dyn_lds(wide_scan_kernel, std::max(lds_sel, lds_scan)));
         if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
         hipLaunchKernelGGL(wide_scan_kernel, dim3(G, w.nq), dim3(kSelectThreads), std::max(lds_sel, lds_scan), st, ix, a, f, wa);

@@ -1376,8 +1376,6 @@ def _wide_cases():
     yield "txh_residual", None
     yield "txh_byte_codes", None
     yield "ah_flat", None
-    for m_ in (hip.SQUARED_L2, hip.DOT_PRODUCT, hip.COSINE):
-        yield "partitioned", m_
 
 
 @pytest.mark.parametrize("kind,measure", list(_wide_cases()))
@@ -1481,6 +1479,68 @@ def test_wide_pipeline_uneven_leaves_and_overflow(monkeypatch):
         name = both(index2, q[:2], 25)
         # 5 code rows: 7200 points tie at the pivot, the compact arrays (2 m + 1024) overflow, the call is repeated
         assert (name == "wide_scan_kernel") == wide, (ncodes, m, name)
+
+
+def test_wide_pipeline_on_the_device_entry_points():
+    """scann_hip_search_batched_device with 1-4 queries over a long stream: the wide pipeline on the caller's stream
+    (a workspace per stream), rows equal to the host entry point's; calls on two streams back to back do not share
+    the dense key lists or the compact arrays.  An overflow of the compact arrays (few distinct code rows) is reported
+    by scann_hip_index_last_device_status with count rows 0 -- the host entry repeats such a call by itself."""
+    import ctypes
+
+    import torch
+    dev = torch.device("cuda:0")
+    k = 10
+    rows, data, stride, ix, kw = H.make_ah_case(70000, 64, 16, seed=74, pq_iters=3)
+    index = hip.txh_create(**kw)
+    o = hip.default_opts()
+    o.pre_reorder_k = 1500
+    L = hip.load()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    nqs = [1, 4]
+    qs = [synth.uniform_f32(nq, 64, 800 + i) for i, nq in enumerate(nqs)]
+    want = [index.search_batched(q, k, o) for q in qs]
+    qd = [torch.from_numpy(q).to(dev) for q in qs]
+    outs = [(torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev),
+             torch.empty((nq,), dtype=torch.int32, device=dev)) for nq in nqs]
+    index.enable_timing(True)
+    for rep in range(3):
+        for oi_, od_, oc_ in outs:
+            oi_.fill_(-1); od_.zero_(); oc_.zero_()
+        torch.cuda.synchronize()
+        for s in (0, 1, 0, 1):
+            hip.check(L.scann_hip_search_batched_device(index.h, p(qd[s]), nqs[s], 64, k, ctypes.byref(o), p(outs[s][0]),
+                                                        p(outs[s][1]), p(outs[s][2]), ctypes.c_void_p(streams[s].cuda_stream)))
+        for s in (0, 1):
+            hip.check(L.scann_hip_index_last_device_status(index.h, ctypes.c_void_p(streams[s].cuda_stream)))
+        torch.cuda.synchronize()
+        for s in (0, 1):
+            wi, wd, wc = want[s]
+            assert np.array_equal(outs[s][2].cpu().numpy().view(np.uint32), wc), (rep, s)
+            assert np.array_equal(bits(outs[s][1].cpu().numpy()), bits(wd)), (rep, s)
+            assert np.array_equal(outs[s][0].cpu().numpy().view(np.uint32), wi), (rep, s)
+    for i in range(4):
+        oi, od = orc.ah_search_with_reordering(ix["codebook"], ix["codes"], data, stride, qs[1][i], k, 1500)
+        H.assert_topk_equal_up_to_ties(outs[1][0][i].cpu().numpy().view(np.uint32), outs[1][1][i].cpu().numpy(), oi, od,
+                                       what="device wide q%d" % i)
+    # overflow: 5 distinct code rows, thousands of points tied at the pivot
+    base = synth.uniform_f32(37, 32, 72)
+    rows2 = np.ascontiguousarray(base[np.arange(36000) % 37])
+    rows2, centers2, kw2 = _random_tree_index([36000], 32, 8, seed=73, rows=rows2)
+    kw2["codes"] = np.ascontiguousarray(kw2["codes"][np.arange(36000) % 5])
+    index2 = hip.txh_create(**kw2)
+    o2 = hip.default_opts()
+    o2.partitions_to_search, o2.pre_reorder_k = 1, 200
+    q2 = torch.from_numpy(synth.uniform_f32(1, 32, 75)).to(dev)
+    o_i = torch.empty((1, k), dtype=torch.int32, device=dev); o_d = torch.empty((1, k), dtype=torch.float32, device=dev)
+    o_c = torch.full((1,), 7, dtype=torch.int32, device=dev)
+    st = ctypes.c_void_p(streams[0].cuda_stream)
+    hip.check(L.scann_hip_search_batched_device(index2.h, p(q2), 1, 32, k, ctypes.byref(o2), p(o_i), p(o_d), p(o_c), st))
+    status = L.scann_hip_index_last_device_status(index2.h, st)
+    torch.cuda.synchronize()
+    assert status == hip.RESOURCE_EXHAUSTED, status
+    assert int(o_c.cpu().numpy()[0]) == 0
 
 
 @pytest.mark.parametrize("kind,measure", list(_small_cases()))
