@@ -1414,6 +1414,27 @@ def test_wide_pipeline_matches_staged_pipeline(kind, measure, monkeypatch):
                 oi, od = oracle(q[i], 10)
                 assert gc[i] == oi.size
                 H.assert_topk_equal_up_to_ties(gi[i, :oi.size], gd[i, :oi.size], oi, od, what="%s wide q%d" % (kind, i))
+    # search_with_filter (an allow-bitmap) and the token outputs through the wide pipeline (device buffers, no pinned staging)
+    o.pre_reorder_k, o.exact_reorder = 120, 1
+    allow = hip.allow_bitmap(n, np.arange(1, n, 5))
+    res = []
+    for env in (None, "0"):
+        monkeypatch.setenv("SCANN_HIP_WIDE", "2")
+        if env is None:
+            monkeypatch.delenv("SCANN_HIP_SMALL", raising=False)
+        else:
+            monkeypatch.setenv("SCANN_HIP_SMALL", env)
+        P = 1 if kind == "ah_flat" else o.partitions_to_search
+        tok = np.zeros((3, P), np.uint32); tokd = np.zeros((3, P), np.float32)
+        o2 = hip.default_opts()
+        o2.partitions_to_search, o2.pre_reorder_k, o2.exact_reorder = o.partitions_to_search, 120, 1
+        o2.tokens, o2.token_dists = hip.ptr(tok, hip.u32p), hip.ptr(tokd, hip.f32p)
+        fa = index.search_batched(q[:3], 10, o2, allow=allow)
+        res.append((fa, tok.copy(), tokd.copy()))
+    (fa, ta, tda), (fb, tb, tdb) = res
+    assert np.array_equal(fa[0], fb[0]) and np.array_equal(bits(fa[1]), bits(fb[1])) and np.array_equal(fa[2], fb[2])
+    assert np.all(fa[0][fa[0] != 0xFFFFFFFF] % 5 == 1)
+    assert np.array_equal(ta, tb) and np.array_equal(bits(tda), bits(tdb))
     # five queries are above the wide pipeline's batch: the small-batch pipeline takes them
     monkeypatch.delenv("SCANN_HIP_SMALL", raising=False)
     index.search_batched(q[:5], 10, o)
