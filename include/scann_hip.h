@@ -257,7 +257,12 @@ int scann_hip_index_last_device_status(scann_hip_index *index, void *hip_stream)
 /* Local stage: this rank's best-m candidates per query by approximate distance, with
  * their exact distances, as (merge key u64, datapoint idx u32, exact f32) triples
  * [nq][m] (+ count [nq]).  The merge key orders candidates exactly as the reference's
- * flatten + stable sort does (mod.rs:283-290) and is identical on every rank. */
+ * flatten + stable sort does (mod.rs:283-290) and is identical on every rank.
+ * A candidate that provably cannot be among the k best exact distances of ANY prefix of
+ * this rank's list (k candidates with smaller merge keys are nearer: int8 row brackets,
+ * lists of > 512 candidates, SquaredL2) carries exact = +inf instead of its distance; it
+ * still counts as one of the m candidates.  Merging (scann_hip_txh_merge_device, with a
+ * num_neighbors <= the k of this call) returns the same rows as with every distance filled in. */
 int scann_hip_txh_search_local_device(scann_hip_index *index, const float *d_queries,
                                       uint32_t nq, uint32_t q_stride, uint32_t k,
                                       const scann_hip_search_opts *opts, uint64_t *d_keys,

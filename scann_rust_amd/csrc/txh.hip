@@ -3828,9 +3828,18 @@ struct ShortArgs {
     uint32_t *out_idx;
     float *out_dist;
     uint32_t *out_count;
+    // > 0: the LOCAL stage of a leaf-sharded search (lists sorted by merge key).  This rank's share of the global
+    // candidates (the m smallest keys over all ranks) is a PREFIX of its list, and the final rows are the k best exact
+    // distances within the union of those prefixes: a candidate past the first local_head entries whose lower bound
+    // lies above tau = the k-th smallest upper bound among the first local_head entries has k candidates with smaller
+    // keys AND smaller exact distances in every prefix that contains it, so it can never reach the final k.  Its exact
+    // distance is not computed: it travels as +inf (it still counts as one of the m candidates in the merge).  The
+    // first local_head entries always get their exact distance.  No final rows are written in this mode.
+    uint32_t local_head;
 };
 
 constexpr uint32_t kShortVPT = kMaxPreReorderK / 256;   // upper bounds per thread (registers)
+constexpr uint32_t kLocalHead = 256;                    // entries of a sharded rank's list that are always re-ranked exactly
 
 __global__ __launch_bounds__(256) void rerank_short_kernel(TxhIndexDev ix, ShortArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_q[];   // [dim]
@@ -3849,12 +3858,14 @@ __global__ __launch_bounds__(256) void rerank_short_kernel(TxhIndexDev ix, Short
     // tail rank, so the bounds stay in registers and only those under a pivot are ranked
     // (block_tail_select; an inexact result is the pivot, >= tau: a larger shortlist, still complete)
     uint32_t tau = 0xFFFFFFFFu;
-    if (nsel > k) {   // block-uniform
+    const uint32_t head = a.local_head;                        // (0: single-GPU final stage)
+    const uint32_t ntau = head ? min(nsel, head) : nsel;       // entries whose upper bounds define tau
+    if (ntau > k) {   // block-uniform
         uint32_t ubv[kShortVPT];   // (registers: 256 threads leave room, and the bounds are read once)
 #pragma unroll
         for (int u = 0; u < (int)kShortVPT; ++u) {
             const uint32_t i = (uint32_t)u * nt + tid;
-            ubv[u] = i < nsel ? a.ub[(size_t)q * m + i] : 0xFFFFFFFFu;
+            ubv[u] = i < ntau ? a.ub[(size_t)q * m + i] : 0xFFFFFFFFu;
         }
         auto v = [&](int u) -> uint32_t { return ubv[u]; };
         bool exact;
@@ -3863,13 +3874,14 @@ __global__ __launch_bounds__(256) void rerank_short_kernel(TxhIndexDev ix, Short
     __syncthreads();
     for (uint32_t b0 = 0; b0 < nsel; b0 += nt) {
         const uint32_t i = b0 + tid;
-        const bool keep = i < nsel && a.lb[(size_t)q * m + i] <= tau;
+        const bool keep = i < nsel && (i < head || a.lb[(size_t)q * m + i] <= tau);
         uint32_t wtot;
         const uint32_t wpre = wave_prefix_count(keep, &wtot);
         uint32_t base = 0;
         if ((tid & 63u) == 0 && wtot) base = atomicAdd(&s_ns, wtot);
         base = (uint32_t)__shfl((int)base, 0);
         if (keep && base + wpre < kShortMaxFast) s_pos[base + wpre] = i;
+        if (head && i < nsel && !keep) a.cand_exact[(size_t)q * m + i] = __builtin_inff();   // (local stage: see ShortArgs)
     }
     __syncthreads();
     const uint32_t ns = s_ns;
@@ -3893,7 +3905,7 @@ __global__ __launch_bounds__(256) void rerank_short_kernel(TxhIndexDev ix, Short
             listed[u] = false;
             if (act[u]) {
                 ci[u] = fast ? s_pos[jx[u]] : jx[u];
-                listed[u] = fast || a.lb[(size_t)q * m + ci[u]] <= tau;
+                listed[u] = fast || ci[u] < head || a.lb[(size_t)q * m + ci[u]] <= tau;
             }
             rowp[u] = ix.rows + (size_t)(listed[u] ? a.cand_row[(size_t)q * m + ci[u]] : 0u) * ix.stride;
         }
@@ -3919,7 +3931,7 @@ __global__ __launch_bounds__(256) void rerank_short_kernel(TxhIndexDev ix, Short
                 }
             if (!listed[u]) r = __builtin_inff();
             if (act[u] && lane8 == 0) {
-                if (fast) {
+                if (fast && !head) {
                     s_eb[jx[u]] = f32_to_ordered(r);
                     s_kk[jx[u]] = a.cand_key[(size_t)q * m + ci[u]];
                 } else {
@@ -3928,7 +3940,7 @@ __global__ __launch_bounds__(256) void rerank_short_kernel(TxhIndexDev ix, Short
             }
         }
     }
-    if (!fast) return;   // block-uniform: final_topk_kernel finishes this query from cand_exact
+    if (!fast || head) return;   // block-uniform: final_topk_kernel / the multi-GPU merge finish this query from cand_exact
     __syncthreads();
     // the k best of the shortlist by (exact, merge key) = the stable sort's first k: wave 0 runs k arg-min
     // rounds over its lanes' strided entries (ns <= 1024: <= 16 per lane)
@@ -6045,7 +6057,14 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
     const size_t lds_rr = (size_t)ix.dim * 4;
     // int8 row filter in front of the exact re-rank (K8b): single-GPU final stage, squared L2, lists long
     // enough for the two extra kernels to pay
-    const bool i8 = unsorted && w.use_i8 && ix.rows8 && ix.measure == SCANN_HIP_SQUARED_L2 && (ix.dim & 15u) == 0;
+    // (the local stage of a leaf-sharded search takes the same two kernels in their prefix form: ShortArgs::local_head;
+    // SCANN_HIP_LOCAL_PRUNE=0: every local candidate re-ranked exactly, as before)
+    bool local_prune_ok = true;   // (read per call: the tests flip it)
+    if (local_only)
+        if (const char *e = std::getenv("SCANN_HIP_LOCAL_PRUNE")) local_prune_ok = std::atoi(e) != 0;
+    const bool i8_local = local_only && local_prune_ok && w.exact_reorder && !w.need_sorted_cands && w.k <= kTopkMaxK &&
+                          w.m > 2 * kLocalHead;
+    const bool i8 = (unsorted || i8_local) && w.use_i8 && ix.rows8 && ix.measure == SCANN_HIP_SQUARED_L2 && (ix.dim & 15u) == 0;
     if (i8) {
         I8RerankArgs ia;
         ia.rows8 = ix.rows8; ia.meta = reinterpret_cast<const float2 *>(ix.rows8_meta); ia.queries = w.queries;
@@ -6067,6 +6086,7 @@ int txh_launch_search(const TxhIndexDev &ix, const TxhWork &w, bool local_only, 
         sa.m = w.m; sa.k = w.k; sa.queries = w.queries; sa.q_stride = w.q_stride; sa.lb = w.rr_lb; sa.ub = w.rr_ub;
         sa.cand_row = w.cand_row; sa.cand_idx = w.cand_idx; sa.cand_key = w.cand_key; sa.cand_count = w.cand_count;
         sa.cand_exact = w.cand_exact; sa.out_idx = w.out_idx; sa.out_dist = w.out_dist; sa.out_count = w.out_count;
+        sa.local_head = local_only ? kLocalHead : 0u;
         const size_t lds_sh = (size_t)ix.dim * 4;
         SCANN_TRY(set_dyn_lds(rerank_short_kernel, lds_sh));
         hipLaunchKernelGGL(rerank_short_kernel, dim3(w.nq), dim3(256), lds_sh, st, ix, sa);

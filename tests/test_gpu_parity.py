@@ -467,6 +467,69 @@ def test_sharded_local_plus_merge_equals_single_index(world, k, m):
     assert np.array_equal(mi, gi) and np.array_equal(md.view(np.uint32), gd.view(np.uint32))
 
 
+def test_sharded_local_stage_prunes_by_prefix_dominance(monkeypatch):
+    """Long local lists (m > 512, int8 row copy): the local stage computes exact distances only for the first 256
+    entries of a rank's key-ordered list and for the entries whose int8 lower bound does not exceed the k-th smallest
+    upper bound among those 256 (ShortArgs::local_head); the rest travel as +inf.  The merged rows must equal the
+    single index's, the distances that ARE filled in must equal the unpruned run's bit for bit, and most entries must
+    in fact have been pruned."""
+    import ctypes as C
+    import torch
+    from scann_rust_amd import sharding
+    monkeypatch.setenv("SCANN_HIP_RERANK_I8", "2")   # (shards of 45000 rows: below the default size for the int8 copy)
+    n, dim, L, S, P, nq, k, m, world = 90000, 64, 30, 16, 6, 40, 10, 1500, 2
+    rows, data, stride, ix, oix, kw = H.make_txh_case(n, dim, L, S, seed=14, P=P, mult=m / k, kmeans_iters=3, pq_iters=3)
+    full = hip.txh_create(**kw)
+    q = synth.uniform_f32(nq, dim, 56)
+    q[3] = rows[77]
+    o = hip.default_opts()
+    o.partitions_to_search, o.pre_reorder_k = P, m
+    want_idx, want_dist, want_cnt = full.search_batched(q, k, o)
+    Lh = hip.load()
+    dev = torch.device("cuda", 0)
+    sptr = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    qd = torch.from_numpy(q).to(dev)
+    shards = [hip.txh_create(partitions_to_search=P, pre_reorder_multiplier=m / k,
+                             **sharding.shard_txh_index(ix, data, stride, r, world)) for r in range(world)]
+    runs = {}
+    for prune in ("1", "0"):
+        monkeypatch.setenv("SCANN_HIP_LOCAL_PRUNE", prune)
+        g_keys = torch.zeros((world, nq, m), dtype=torch.int64, device=dev)
+        g_idx = torch.zeros((world, nq, m), dtype=torch.int32, device=dev)
+        g_ex = torch.zeros((world, nq, m), dtype=torch.float32, device=dev)
+        g_cnt = torch.zeros((world, nq), dtype=torch.int32, device=dev)
+        for r in range(world):
+            hip.check(Lh.scann_hip_txh_search_local_device(
+                shards[r].h, C.c_void_p(qd.data_ptr()), nq, dim, k, C.byref(o),
+                C.c_void_p(g_keys[r].data_ptr()), C.c_void_p(g_idx[r].data_ptr()),
+                C.c_void_p(g_ex[r].data_ptr()), C.c_void_p(g_cnt[r].data_ptr()), sptr))
+            hip.check(Lh.scann_hip_index_last_device_status(shards[r].h, sptr))
+        out_idx = torch.zeros((nq, k), dtype=torch.int32, device=dev)
+        out_dist = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+        out_cnt = torch.zeros((nq,), dtype=torch.int32, device=dev)
+        status = torch.zeros((1,), dtype=torch.int32, device=dev)
+        hip.check(Lh.scann_hip_txh_merge_device(hip.context(0), world, nq, m, m, k, 0,
+                                                C.c_void_p(g_keys.data_ptr()), C.c_void_p(g_idx.data_ptr()),
+                                                C.c_void_p(g_ex.data_ptr()), C.c_void_p(g_cnt.data_ptr()),
+                                                C.c_void_p(out_idx.data_ptr()), C.c_void_p(out_dist.data_ptr()),
+                                                C.c_void_p(out_cnt.data_ptr()), C.c_void_p(status.data_ptr()), sptr))
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0
+        assert np.array_equal(out_cnt.cpu().numpy().astype(np.uint32), want_cnt), prune
+        assert np.array_equal(out_dist.cpu().numpy().view(np.uint32), want_dist.view(np.uint32)), prune
+        assert np.array_equal(out_idx.cpu().numpy().view(np.uint32), want_idx), prune
+        runs[prune] = (g_keys.cpu().numpy(), g_idx.cpu().numpy(), g_ex.cpu().numpy(), g_cnt.cpu().numpy())
+    pk, pi, pe, pc = runs["1"]
+    fk, fi, fe, fc = runs["0"]
+    assert np.array_equal(pk, fk) and np.array_equal(pi, fi) and np.array_equal(pc, fc)
+    valid = np.arange(m)[None, None, :] < pc[:, :, None]
+    assert not np.isinf(fe[valid]).any()
+    pruned = np.isinf(pe) & valid
+    assert pruned.sum() > 0.5 * valid.sum(), (int(pruned.sum()), int(valid.sum()))
+    assert not pruned[:, :, :256].any()                       # the head of every list is always re-ranked
+    assert np.array_equal(pe[valid & ~pruned].view(np.uint32), fe[valid & ~pruned].view(np.uint32))
+
+
 # ---- index-build helper: TreePartitioner::partition(x, 1) for every row -----------------------------------
 @pytest.mark.parametrize("n,dim,k", [(3000, 128, 100), (1000, 96, 37), (700, 50, 5), (500, 7, 16), (64, 32, 1)])
 def test_assign_nearest_bit_exact(n, dim, k):
