@@ -4790,8 +4790,9 @@ template <typename F>
 static int set_dyn_lds_with_static(F kernel, size_t bytes, size_t static_bytes) {
     constexpr size_t kMaxLds = 160 * 1024;
     if (bytes + static_bytes > kMaxLds) return fail(SCANN_HIP_RESOURCE_EXHAUSTED, "kernel needs more than 160 KB of LDS");
-    SCANN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(kMaxLds - static_bytes)));
+    if (bytes > 64 * 1024)   // (the attribute bounds static + dynamic: 160 KB for a kernel with static arrays is refused)
+        SCANN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)(kMaxLds - static_bytes)));
     return SCANN_HIP_OK;
 }
 
@@ -5859,7 +5860,7 @@ static int launch_search_small(const TxhIndexDev &ix, const TxhWork &w, hipStrea
                                                 (size_t)lcfg.list * 8 + 48 * 8 + 64 * 4 + (size_t)ix.L * 8 +
                                                 (size_t)((ix.dim + 3u) & ~3u) * 4 + 16;
         const size_t lds_scan = ((size_t)ix.S * ix.kp + ix.dim) * sizeof(float);
-        SCANN_TRY(set_dyn_lds(wide_scan_kernel, std::max(lds_sel, lds_scan)));
+        SCANN_TRY(set_dyn_lds_with_static(wide_scan_kernel, std::max(lds_sel, lds_scan), 8 * 1024));   // (6160 B of static arrays)
         if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
         hipLaunchKernelGGL(wide_scan_kernel, dim3(G, w.nq), dim3(kSelectThreads), std::max(lds_sel, lds_scan), st, ix, a, f, wa);
         LAUNCH_CHECK();
@@ -5904,7 +5905,9 @@ static int launch_search_small(const TxhIndexDev &ix, const TxhWork &w, hipStrea
                                                     (size_t)((ix.dim + 3u) & ~3u) * 4 + 16;
             const size_t lds_scan = ((size_t)(ix.exact_scan ? 0u : ix.S * ix.kp) + ix.dim) * sizeof(float);
             const size_t lds = std::max(lds_sel, lds_scan);
-            SCANN_TRY(set_dyn_lds(small_fused_kernel, lds));
+            // (80272 B of static arrays -- the finish stage's: from ~2200 leaves the selection's dynamic part passes 64 KB, and
+            // the attribute must leave room for both)
+            SCANN_TRY(set_dyn_lds_with_static(small_fused_kernel, lds, 79 * 1024));
             if (ev0) SCANN_HIP_CHECK(hipEventRecord(ev0, st));
             hipLaunchKernelGGL(small_fused_kernel, dim3(G, w.nq), dim3(kSelectThreads), lds, st, ix, a, f);
             LAUNCH_CHECK();

@@ -1565,6 +1565,37 @@ def test_wide_pipeline_uneven_leaves_and_overflow(monkeypatch):
         assert (name == "wide_scan_kernel") == wide, (ncodes, m, name)
 
 
+def test_wide_pipeline_many_leaves(monkeypatch):
+    """4096 leaves: the leaf selection inside wide_scan_kernel needs more than 64 KB of dynamic LDS next to the kernel's
+    static arrays (the LDS attribute must leave room for both); rows equal the staged pipeline's."""
+    rows, centers, kw = _random_tree_index([15] * 4096, 32, 8, seed=81)
+    kw["partitions_to_search"] = 40
+    index = hip.txh_create(**kw)
+    index.enable_timing(True)
+    o = hip.default_opts()
+    o.partitions_to_search, o.pre_reorder_k = 40, 100
+    q = synth.uniform_f32(4, 32, 82)
+    for nq in (1, 4):
+        monkeypatch.setenv("SCANN_HIP_WIDE", "2")
+        monkeypatch.delenv("SCANN_HIP_SMALL", raising=False)
+        a = index.search_batched(q[:nq], 10, o)
+        assert index.last_kernel_ms()[1] == "wide_scan_kernel"
+        monkeypatch.setenv("SCANN_HIP_SMALL", "0")
+        b = index.search_batched(q[:nq], 10, o)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2])
+    # the same for the one-launch small-batch kernel (80 KB of static arrays) on a Partitioned index of 4096 leaves
+    monkeypatch.delenv("SCANN_HIP_WIDE", raising=False)
+    part = hip.txh_create(data=kw["data"], n_rows=kw["n_rows"], dim=32, stride=kw["stride"], centers=centers,
+                          leaf_offsets=kw["leaf_offsets"], leaf_ids=kw["leaf_ids"], codebook=None, codes=None,
+                          partitions_to_search=40, distance_measure=hip.SQUARED_L2)
+    for nq in (1, 3):
+        monkeypatch.delenv("SCANN_HIP_SMALL", raising=False)
+        a = part.search_batched(q[:nq], 10)
+        monkeypatch.setenv("SCANN_HIP_SMALL", "0")
+        b = part.search_batched(q[:nq], 10)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2])
+
+
 def test_wide_pipeline_on_the_device_entry_points():
     """scann_hip_search_batched_device with 1-4 queries over a long stream: the wide pipeline on the caller's stream
     (a workspace per stream), rows equal to the host entry point's; calls on two streams back to back do not share
